@@ -1,0 +1,541 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  Runs ONLY in the build container, where the reference
+checkout is mounted at /root/reference; nothing from the reference is copied -- the
+outputs are numeric arrays (inputs + the reference's own outputs) written to
+tests/golden/*.npz.  The GPU box never runs this script.
+
+Three import-only stand-ins are injected so that the reference's hot path imports here:
+  * omegaconf         (rendering/__init__.py:7 -- type conversion only)
+  * shapely.geometry  (infractions.py:7 -- only used by the `nograd` metric)
+  * cv2               a *recording* fake: fillConvexPoly() appends (points, color) to a log and
+                      returns the image untouched.  This pins everything the reference does up
+                      to the OpenCV boundary (trim, z-order, projection, truncation, colour
+                      quantisation) -- SURVEY.md section 8c, fixture G5.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get('TDS_REFERENCE', '/root/reference')
+
+
+# --------------------------------------------------------------------------------------
+# stand-ins
+# --------------------------------------------------------------------------------------
+def install_stubs():
+    om = types.ModuleType('omegaconf')
+
+    class DictConfig:  # never instantiated
+        pass
+
+    class OmegaConf:
+        @staticmethod
+        def to_container(*a, **k):
+            raise NotImplementedError
+
+    class SCMode:
+        INSTANTIATE = 0
+
+    om.DictConfig, om.OmegaConf, om.SCMode = DictConfig, OmegaConf, SCMode
+    sys.modules['omegaconf'] = om
+
+    sh = types.ModuleType('shapely')
+    shg = types.ModuleType('shapely.geometry')
+
+    class Polygon:
+        def __init__(self, *a, **k):
+            raise NotImplementedError('shapely stand-in')
+
+    shg.Polygon = Polygon
+    sh.geometry = shg
+    sys.modules['shapely'] = sh
+    sys.modules['shapely.geometry'] = shg
+
+    cv2 = types.ModuleType('cv2')
+    cv2.LINE_AA = 16
+    cv2.calls = []
+
+    def fillConvexPoly(img, points, color, shift=0, lineType=8):
+        assert shift == 0 and lineType == 16
+        assert img.dtype == np.float32 and img.ndim == 3 and img.shape[2] == 3
+        assert points.dtype == np.int32 and points.shape == (3, 2)
+        cv2.calls.append((points.copy(), list(color)))
+        return img
+
+    cv2.fillConvexPoly = fillConvexPoly
+    sys.modules['cv2'] = cv2
+    return cv2
+
+
+def seeded(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------
+# G1 kinematics
+# --------------------------------------------------------------------------------------
+def gen_kinematic(out):
+    from torchdrivesim.kinematic import (KinematicBicycle, BicycleNoReversing, SimpleKinematicModel,
+                                         OrientedKinematicModel)
+    g = seeded(101)
+    B, A = 3, 7
+    state = torch.stack([
+        (torch.rand(B, A, generator=g) - 0.5) * 600,
+        (torch.rand(B, A, generator=g) - 0.5) * 600,
+        (torch.rand(B, A, generator=g) - 0.5) * 4 * math.pi,
+        (torch.rand(B, A, generator=g) - 0.3) * 20,
+    ], dim=-1)
+    action = (torch.rand(B, A, 2, generator=g) - 0.5) * 2
+    action4 = (torch.rand(B, A, 4, generator=g) - 0.5) * 2
+    lr = 1.0 + torch.rand(B, A, generator=g)
+    d = dict(state=npy(state), action=npy(action), action4=npy(action4), lr=npy(lr))
+
+    def run_bicycle(cls, **kw):
+        m = cls(**kw)
+        m.set_params(lr=lr.clone())
+        m.set_state(state.clone())
+        m.step(action.clone())
+        return m
+
+    d['out_bicycle'] = npy(run_bicycle(KinematicBicycle).get_state())
+    d['out_bicycle_lh'] = npy(run_bicycle(KinematicBicycle, left_handed=True).get_state())
+    d['out_bicycle_dt'] = None
+    m = KinematicBicycle()
+    m.set_params(lr=lr.clone())
+    m.set_state(state.clone())
+    m.step(action.clone(), dt=0.25)
+    d['out_bicycle_dt'] = npy(m.get_state())
+    d['out_norev'] = npy(run_bicycle(BicycleNoReversing).get_state())
+    # two chained steps (state tensor is replaced, never mutated)
+    m = run_bicycle(KinematicBicycle)
+    m.step(action.flip(0).clone())
+    d['out_bicycle_2steps'] = npy(m.get_state())
+
+    for name, cls in (('simple', SimpleKinematicModel), ('oriented', OrientedKinematicModel)):
+        m = cls()
+        m.set_state(state.clone())
+        m.step(action4.clone())
+        d[f'out_{name}'] = npy(m.get_state())
+
+    # fit_action
+    future = state + torch.stack([
+        (torch.rand(B, A, generator=g) - 0.5) * 3,
+        (torch.rand(B, A, generator=g) - 0.5) * 3,
+        (torch.rand(B, A, generator=g) - 0.5) * 0.4,
+        (torch.rand(B, A, generator=g) - 0.5) * 2,
+    ], dim=-1)
+    future[0, 0, :2] = state[0, 0, :2]  # zero displacement -> sign(abs(v)) == 0 branch
+    d['future'] = npy(future)
+    for name, kw in (('fit_bicycle', {}), ('fit_bicycle_lh', dict(left_handed=True))):
+        m = KinematicBicycle(**kw)
+        m.set_params(lr=lr.clone())
+        m.set_state(state.clone())
+        d[name] = npy(m.fit_action(future.clone()))
+    for name, cls in (('fit_simple', SimpleKinematicModel), ('fit_oriented', OrientedKinematicModel)):
+        m = cls()
+        m.set_state(state.clone())
+        d[name] = npy(m.fit_action(future.clone()))
+
+    # known-answer
+    m = KinematicBicycle()
+    m.set_params(lr=torch.tensor([[1.5]]))
+    m.set_state(torch.tensor([[[1.0, 2.0, 0.5, 3.0]]]))
+    m.step(torch.tensor([[[0.4, -0.2]]]))
+    d['kat_out'] = npy(m.get_state())
+    np.savez_compressed(os.path.join(out, 'g1_kinematic.npz'), **d)
+    print('g1', {k: v.shape for k, v in d.items()})
+
+
+# --------------------------------------------------------------------------------------
+# G2 boxes / IoU / discs / collision
+# --------------------------------------------------------------------------------------
+def curated_pairs():
+    base = [0.0, 0.0, 4.0, 2.0, 0.0]
+    p = [
+        (base, base),  # identical
+        (base, [2.0, 0.0, 4.0, 2.0, 0.0]),  # shifted
+        (base, [0.0, 0.0, 4.0, 2.0, math.pi / 2]),  # perpendicular
+        (base, [0.0, 0.0, 4.0, 2.0, math.pi / 4]),
+        (base, [1.0, 0.5, 4.0, 2.0, math.radians(30)]),
+        (base, [0.0, 0.0, 2.0, 1.0, 0.3]),  # contained
+        (base, [4.0, 0.0, 4.0, 2.0, 0.0]),  # exactly touching
+        (base, [0.0, 2.0, 4.0, 2.0, 0.0]),  # touching along long edge
+        (base, [10.0, 10.0, 4.0, 2.0, 1.0]),  # far apart
+        (base, [3.9, 0.0, 4.0, 2.0, 0.0]),  # sliver overlap
+        (base, [0.0, 0.0, 1e-3, 1e-3, 0.0]),  # tiny
+        ([0.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 0.0]),  # zero size
+        ([5.0, -3.0, 4.5, 1.9, 2.0], [6.0, -2.0, 4.8, 2.1, -1.0]),
+        ([5.0, -3.0, 1.9, 4.5, 2.0], [6.0, -2.0, 2.1, 4.8, -1.0]),  # wid > len (discs yaw+pi/2 branch)
+        ([400.0, 330.0, 4.5, 2.0, 0.7], [401.5, 331.0, 4.5, 2.0, 2.4]),  # far from origin
+    ]
+    b1 = torch.tensor([a for a, _ in p], dtype=torch.float32)
+    b2 = torch.tensor([b for _, b in p], dtype=torch.float32)
+    return b1, b2
+
+
+def gen_collision(out):
+    from torchdrivesim import _iou_utils as iu
+    from torchdrivesim.infractions import iou_differentiable, collision_detection_with_discs
+    d = {}
+    b1, b2 = curated_pairs()
+    d['cur_box1'], d['cur_box2'] = npy(b1), npy(b2)
+    d['cur_corners1'] = npy(iu.box2corners_th(b1[None]))[0]
+    d['cur_iou'] = npy(iou_differentiable(b1[None], b2[None]))[0]
+    d['cur_discs'] = npy(collision_detection_with_discs(b1[None], b2[None]))[0]
+
+    def stages(box1, box2):
+        c1, c2 = iu.box2corners_th(box1), iu.box2corners_th(box2)
+        inters, mask_inter = iu.box_intersection_th(c1, c2)
+        c12, c21 = iu.box_in_box_th(c1, c2)
+        vertices, mask = iu.build_vertices(c1, c2, c12, c21, inters, mask_inter)
+        idx = iu.sort_indices(vertices, mask.clone())
+        area, _ = iu.calculate_area(idx, vertices)
+        return vertices, mask, idx, area
+
+    v, m, idx, area = stages(b1[None], b2[None])
+    d['cur_vertices'], d['cur_mask'], d['cur_idx'], d['cur_area'] = npy(v)[0], npy(m)[0], npy(idx)[0], npy(area)[0]
+
+    g = seeded(202)
+    for tag, off in (('rnd0', (0.0, 0.0)), ('rnd400', (400.0, 330.0))):
+        N = 4000
+        c = (torch.rand(N, 2, generator=g) - 0.5) * 4
+        box1 = torch.cat([c + torch.tensor(off), 3.5 + 2 * torch.rand(N, 1, generator=g),
+                          1.5 + torch.rand(N, 1, generator=g), (torch.rand(N, 1, generator=g) - 0.5) * 2 * math.pi], -1)
+        c2 = c + (torch.rand(N, 2, generator=g) - 0.5) * 9
+        box2 = torch.cat([c2 + torch.tensor(off), 3.5 + 2 * torch.rand(N, 1, generator=g),
+                          1.5 + torch.rand(N, 1, generator=g), (torch.rand(N, 1, generator=g) - 0.5) * 2 * math.pi], -1)
+        d[f'{tag}_box1'], d[f'{tag}_box2'] = npy(box1), npy(box2)
+        d[f'{tag}_iou'] = npy(iou_differentiable(box1[None], box2[None]))[0]
+        d[f'{tag}_discs'] = npy(collision_detection_with_discs(box1[None], box2[None]))[0]
+        v, m, idx, area = stages(box1[None], box2[None])
+        d[f'{tag}_nvalid'] = npy(m.sum(-1))[0].astype(np.int8)
+        d[f'{tag}_idx'] = npy(idx)[0].astype(np.int8)
+        d[f'{tag}_area'] = npy(area)[0]
+    np.savez_compressed(os.path.join(out, 'g2_boxes.npz'), **d)
+    print('g2 boxes ok; valid-count histogram', np.bincount(d['rnd0_nvalid']))
+
+
+def make_sim(state, size, present, lr=None, metric='iou', road_mesh=None, npc=None, left_handed=False,
+             renderer=None, agent_types=None, agent_type_names=None):
+    from torchdrivesim.simulator import Simulator, TorchDriveConfig, CollisionMetric, NPCController
+    from torchdrivesim.kinematic import KinematicBicycle
+    from torchdrivesim.mesh import BirdviewMesh
+    from torchdrivesim.rendering import DummyRendererConfig
+    B = state.shape[0]
+    if road_mesh is None:
+        road_mesh = BirdviewMesh.empty(batch_size=B)
+    km = KinematicBicycle()
+    km.set_params(lr=lr if lr is not None else torch.full(state.shape[:2], 1.5))
+    km.set_state(state)
+    cfg = TorchDriveConfig(collision_metric=CollisionMetric(metric), left_handed_coordinates=left_handed,
+                           renderer=DummyRendererConfig())
+    npc_controller = None
+    if npc is not None:
+        npc_controller = NPCController(npc_size=npc['size'], npc_state=npc['state'], npc_present_mask=npc['present'],
+                                       npc_types=torch.zeros_like(npc['present']).long())
+    return Simulator(road_mesh, km, size, present, cfg, renderer=renderer, npc_controller=npc_controller,
+                     agent_types=agent_types, agent_type_names=agent_type_names)
+
+
+def random_scene(g, B, A, spread=12.0, centre=(0.0, 0.0)):
+    xy = (torch.rand(B, A, 2, generator=g) - 0.5) * spread + torch.tensor(centre)
+    psi = (torch.rand(B, A, 1, generator=g) - 0.5) * 2 * math.pi
+    v = torch.rand(B, A, 1, generator=g) * 10
+    state = torch.cat([xy, psi, v], -1)
+    size = torch.cat([4.5 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g)),
+                      2.0 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g))], -1)
+    present = torch.rand(B, A, generator=g) < 0.8
+    present[:, 0] = True
+    return state, size, present
+
+
+def gen_scene_collision(out):
+    d = {}
+    g = seeded(303)
+    state, size, present = random_scene(g, 6, 8)
+    # quirk scene: three co-located boxes, present=[F,T,T]
+    state[0, :3] = torch.tensor([[0., 0., 0., 0.], [0., 0., 0., 0.], [30., 30., 0., 0.]])
+    size[0, :3] = torch.tensor([[4., 2.], [4., 2.], [4., 2.]])
+    present[0, :3] = torch.tensor([False, True, True])
+    state[1, 2, 0] = float('nan')  # NaN scrubbing path (simulator.py:1095-1103)
+    d['state'], d['size'], d['present'] = npy(state), npy(size), npy(present)
+    for metric in ('iou', 'discs'):
+        sim = make_sim(state.clone(), size.clone(), present.clone(), metric=metric)
+        d[f'coll_{metric}'] = npy(sim.compute_collision())
+    # with NPCs
+    ns, nz, npres = random_scene(g, 6, 3)
+    d['npc_state'], d['npc_size'], d['npc_present'] = npy(ns), npy(nz), npy(npres)
+    for metric in ('iou', 'discs'):
+        sim = make_sim(state.clone(), size.clone(), present.clone(), metric=metric,
+                       npc=dict(state=ns.clone(), size=nz.clone(), present=npres.clone()))
+        d[f'coll_npc_{metric}'] = npy(sim.compute_collision())
+    # far from the origin (fp32 translation sensitivity)
+    state2, size2, present2 = random_scene(g, 4, 8, centre=(380.0, 310.0))
+    d['far_state'], d['far_size'], d['far_present'] = npy(state2), npy(size2), npy(present2)
+    for metric in ('iou', 'discs'):
+        sim = make_sim(state2.clone(), size2.clone(), present2.clone(), metric=metric)
+        d[f'far_coll_{metric}'] = npy(sim.compute_collision())
+    np.savez_compressed(os.path.join(out, 'g2_scene_collision.npz'), **d)
+    print('g2 scenes: quirk row', d['coll_iou'][0, :3], d['coll_discs'][0, :3])
+
+
+# --------------------------------------------------------------------------------------
+# Town01 data fixture + crops
+# --------------------------------------------------------------------------------------
+def load_town01():
+    from torchdrivesim.mesh import BirdviewMesh
+    path = os.path.join(REF, 'torchdrivesim/resources/maps/carla_Town01/carla_Town01_mesh.json')
+    return BirdviewMesh.load(path)
+
+
+def crop_mesh(mesh, centre, half):
+    """Host-side crop used only to build a small fixture: faces with >=1 vertex inside the box."""
+    from torchdrivesim.mesh import BirdviewMesh
+    v = mesh.verts[0]
+    f = mesh.faces[0]
+    inside = ((v - torch.tensor(centre)).abs() <= half).all(-1)
+    keep = inside[f].any(-1)
+    f = f[keep]
+    used = torch.unique(f)
+    remap = torch.full((v.shape[0],), -1, dtype=torch.long)
+    remap[used] = torch.arange(len(used))
+    return BirdviewMesh(verts=v[used][None].clone(), faces=remap[f][None].clone(), categories=list(mesh.categories),
+                        colors=dict(mesh.colors), zs=dict(mesh.zs), vert_category=mesh.vert_category[0][used][None].clone())
+
+
+def gen_town01(out):
+    m = load_town01()
+    np.savez_compressed(os.path.join(out, 'town01_mesh.npz'),
+                        verts=npy(m.verts[0]).astype(np.float32), faces=npy(m.faces[0]).astype(np.int32),
+                        vert_category=npy(m.vert_category[0]).astype(np.uint8),
+                        categories=np.array(m.categories))
+    # a tiny json in the reference's own serialisation format (mesh.py:700-719) for the loader test
+    small = crop_mesh(m, (100.0, 2.0), 6.0)
+    small.save(os.path.join(out, 'town01_crop_small_mesh.json'))
+    print('town01', m.verts.shape, m.faces.shape, 'small crop', small.verts.shape, small.faces.shape)
+    return m
+
+
+# --------------------------------------------------------------------------------------
+# G3 offroad
+# --------------------------------------------------------------------------------------
+def gen_offroad(out, town):
+    from torchdrivesim.infractions import offroad_infraction_loss
+    from torchdrivesim.mesh import BaseMesh, BirdviewMesh
+    d = {}
+    # (a) 2-triangle road x in [-20,20], y in [-3,3]  (SURVEY R4 probe: 414.952)
+    verts = torch.tensor([[[-20., -3.], [20., -3.], [20., 3.], [-20., 3.]]])
+    faces = torch.tensor([[[0, 1, 2], [0, 2, 3]]])
+    road = BaseMesh(verts=verts, faces=faces)
+    st = torch.tensor([[[30., 0., 0.3, 0.], [0., 0., 0.1, 0.], [19., 2.5, 1.0, 0.], [0., 3.4, 0., 0.], [-21.5, 0., 0., 0.]]])
+    lw = torch.tensor([[[4., 2.]]]).expand(1, 5, 2).contiguous()
+    d['a_verts'], d['a_faces'], d['a_state'], d['a_lenwid'] = npy(verts[0]), npy(faces[0]), npy(st), npy(lw)
+    d['a_off_t05'] = npy(offroad_infraction_loss(st, lw, road, threshold=0.5, use_pytorch3d=False))
+    d['a_off_t0'] = npy(offroad_infraction_loss(st, lw, road, threshold=0.0, use_pytorch3d=False))
+    # (b) Town01 crop, two scenes; second scene's mesh is padded with [0,0,0] faces via collate
+    c1 = crop_mesh(town, (100.0, 2.0), 14.0)
+    c2 = crop_mesh(town, (92.0, 60.0), 9.0)
+    both = BirdviewMesh.collate([c1, c2])
+    g = seeded(404)
+    B, A = 2, 6
+    centres = torch.tensor([[100.0, 2.0], [92.0, 60.0]])
+    xy = centres[:, None] + (torch.rand(B, A, 2, generator=g) - 0.5) * 24
+    st = torch.cat([xy, (torch.rand(B, A, 1, generator=g) - 0.5) * 6.3, torch.zeros(B, A, 1)], -1)
+    lw = torch.cat([4.5 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g)), 2.0 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g))], -1)
+    d['b_verts'], d['b_faces'] = npy(both.verts), npy(both.faces).astype(np.int32)
+    d['b_nfaces'] = np.array([c1.faces_count, c2.faces_count])
+    d['b_state'], d['b_lenwid'] = npy(st), npy(lw)
+    d['b_off_t05'] = npy(offroad_infraction_loss(st, lw, both, threshold=0.5, use_pytorch3d=False))
+    d['b_off_t0'] = npy(offroad_infraction_loss(st, lw, both, threshold=0.0, use_pytorch3d=False))
+    # (c) through the Simulator (present-mask multiply, simulator.py:1043-1044), lenwid (B,2) form
+    present = torch.rand(B, A, generator=g) < 0.7
+    sim = make_sim(st.clone(), lw.clone(), present.clone(), road_mesh=both)
+    d['c_present'] = npy(present)
+    d['c_sim_offroad'] = npy(sim.compute_offroad())
+    np.savez_compressed(os.path.join(out, 'g3_offroad.npz'), **d)
+    print('g3 offroad', d['a_off_t05'], 'crop faces', d['b_nfaces'])
+
+
+# --------------------------------------------------------------------------------------
+# G4 / G5 mesh generation + pre-raster call lists
+# --------------------------------------------------------------------------------------
+def render_record(cv2, sim, res, fov, **kw):
+    from torchdrivesim.utils import Resolution
+    cv2.calls.clear()
+    img = sim.render_egocentric(res=Resolution(res, res), fov=fov, **kw)
+    n_img = img.shape[0] * img.shape[1]
+    calls = list(cv2.calls)
+    assert len(calls) % n_img == 0
+    per = len(calls) // n_img
+    tris = np.stack([c[0] for c in calls]).reshape(n_img, per, 3, 2).astype(np.int32)
+    cols = np.array([c[1] for c in calls], dtype=np.uint8).reshape(n_img, per, 3)
+    return tris, cols, tuple(img.shape)
+
+
+def gen_mesh_and_preraster(out, cv2, town):
+    from torchdrivesim.mesh import BirdviewRGBMeshGenerator, BirdviewMesh
+    from torchdrivesim.rendering import CV2RendererConfig, renderer_from_config
+    from torchdrivesim.rendering.base import get_default_color_map, get_default_rendering_levels
+    d = {}
+    g = seeded(505)
+    # ---- G4: actor template + generate() on a small background
+    B, A = 2, 4
+    state, size, present = random_scene(g, B, A, spread=20.0, centre=(100.0, 2.0))
+    small = crop_mesh(town, (100.0, 2.0), 6.0)
+    bg = small.expand(B)
+    gen = BirdviewRGBMeshGenerator(background_mesh=bg, color_map=get_default_color_map(),
+                                   rendering_levels=get_default_rendering_levels())
+    types_ = torch.zeros(B, A, dtype=torch.long)
+    gen.initialize_actors_mesh(size, types_, ['vehicle'])
+    d['g4_size'], d['g4_state'], d['g4_present'] = npy(size), npy(state), npy(present)
+    d['g4_bg_verts'], d['g4_bg_faces'] = npy(small.verts[0]), npy(small.faces[0]).astype(np.int32)
+    d['g4_bg_vert_category'] = npy(small.vert_category[0]).astype(np.uint8)
+    d['g4_tmpl_verts'], d['g4_tmpl_faces'], d['g4_tmpl_attrs'] = npy(gen.actor_mesh.verts), npy(gen.actor_mesh.faces).astype(np.int32), npy(gen.actor_mesh.attrs)
+    nc = A
+    mask = present[:, None].expand(B, nc, A)
+    rgb = gen.generate(nc, agent_state=state[:, None].expand(-1, nc, -1, -1), present_mask=mask)
+    nbg = small.verts_count
+    d['g4_gen_actor_verts'] = npy(rgb.verts[:, nbg:])
+    d['g4_gen_actor_faces'] = npy(rgb.faces[:, small.faces_count:]).astype(np.int32)
+    d['g4_gen_actor_attrs'] = npy(rgb.attrs[:, nbg:])
+    d['g4_gen_bg_attrs_z'] = np.concatenate([npy(rgb.attrs[0, :nbg]), npy(rgb.verts[0, :nbg, 2:3])], -1)
+
+    # ---- G5: full Simulator.render_egocentric with the CV2 backend up to the OpenCV boundary
+    def cv2_sim(state, size, present, road, left_handed=False, **kw):
+        r = renderer_from_config(CV2RendererConfig(left_handed_coordinates=left_handed))
+        return make_sim(state.clone(), size.clone(), present.clone(), road_mesh=road, renderer=r, left_handed=left_handed, **kw)
+
+    cases = []
+    # case 0: config-1 shape: full Town01, B=2 x A=8, 128x128, fov 35
+    B, A = 2, 8
+    vroad = town.verts[0][town.vert_category[0] == town.categories.index('road')]
+    pick = torch.randint(0, vroad.shape[0], (B, A), generator=g)
+    xy = vroad[pick] + torch.randn(B, A, 2, generator=g)
+    # keep agents of one scene within sight of each other
+    xy = xy[:, :1] + (xy - xy[:, :1]) * 0 + (torch.rand(B, A, 2, generator=g) - 0.5) * 30
+    state = torch.cat([xy, (torch.rand(B, A, 1, generator=g) - 0.5) * 2 * math.pi, torch.rand(B, A, 1, generator=g) * 10], -1)
+    size = torch.cat([4.5 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g)), 2.0 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g))], -1)
+    present = torch.rand(B, A, generator=g) < 0.85
+    present[:, 0] = True
+    cases.append(dict(name='town01_128', state=state, size=size, present=present, res=128, fov=35.0, lh=False, road='town01'))
+    # case 1: same scene, left-handed flag, 64x64, fov 50, agent 0 of scene 1 absent (stray-dot quirk Q10)
+    p2 = present.clone()
+    p2[1, 0] = False
+    cases.append(dict(name='town01_64_lh', state=state, size=size, present=p2, res=64, fov=50.0, lh=True, road='town01'))
+    # case 2: crop background, 256x256 fov 35, not ego-rotated
+    cases.append(dict(name='crop_256_norot', state=state[:1, :4].clone(), size=size[:1, :4].clone(), present=present[:1, :4].clone(),
+                      res=256, fov=35.0, lh=False, road='crop', centre=state[0, 0, :2].tolist(), ego_rotate=False))
+    # case 3: empty road mesh, agents only, small res (reference test shape tests/test_rendering.py)
+    st3 = torch.tensor([[[0., 0., 0., 0.], [3., 1., 0.5, 0.], [-2., 4., 2.0, 0.]]])
+    cases.append(dict(name='empty_32', state=st3, size=torch.tensor([[[4., 2.], [5., 2.2], [1., 1.]]]), present=torch.ones(1, 3, dtype=torch.bool),
+                      res=32, fov=20.0, lh=False, road='empty'))
+    meta = []
+    for c in cases:
+        if c['road'] == 'town01':
+            road = town.expand(c['state'].shape[0])
+        elif c['road'] == 'crop':
+            crop = crop_mesh(town, c['centre'], 40.0)
+            road = crop.expand(c['state'].shape[0])
+            d[f"g5_{c['name']}_road_verts"] = npy(crop.verts[0])
+            d[f"g5_{c['name']}_road_faces"] = npy(crop.faces[0]).astype(np.int32)
+            d[f"g5_{c['name']}_road_vert_category"] = npy(crop.vert_category[0]).astype(np.uint8)
+        else:
+            road = BirdviewMesh.empty(batch_size=c['state'].shape[0])
+        sim = cv2_sim(c['state'], c['size'], c['present'], road, left_handed=c['lh'])
+        kw = {}
+        if 'ego_rotate' in c:
+            kw['ego_rotate'] = c['ego_rotate']
+        tris, cols, shape = render_record(cv2, sim, c['res'], c['fov'], **kw)
+        n = c['name']
+        d[f'g5_{n}_state'], d[f'g5_{n}_size'], d[f'g5_{n}_present'] = npy(c['state']), npy(c['size']), npy(c['present'])
+        d[f'g5_{n}_tris'], d[f'g5_{n}_cols'] = tris, cols
+        # camera sin/cos exactly as the reference computes them (simulator.py:940)
+        psi = c['state'][..., 2:3] if kw.get('ego_rotate', True) else torch.ones_like(c['state'][..., 2:3]) * (np.pi / 2)
+        d[f'g5_{n}_cam_sc'] = npy(torch.cat([torch.sin(psi), torch.cos(psi)], -1))
+        meta.append(dict(name=n, res=c['res'], fov=c['fov'], left_handed=c['lh'], road=c['road'],
+                         ego_rotate=kw.get('ego_rotate', True), out_shape=list(shape)))
+        print('g5', n, tris.shape, 'distinct colours', len({tuple(x) for x in cols.reshape(-1, 3).tolist()}))
+    d['g5_meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(out, 'g45_mesh_preraster.npz'), **d)
+
+
+# --------------------------------------------------------------------------------------
+# G7 gradients
+# --------------------------------------------------------------------------------------
+def gen_grads(out, town):
+    d = {}
+    g = seeded(707)
+    B, A = 2, 6
+    crop = crop_mesh(town, (100.0, 2.0), 14.0)
+    road = crop.expand(B)
+    xy = torch.tensor([100.0, 2.0]) + (torch.rand(B, A, 2, generator=g) - 0.5) * torch.tensor([14.0, 8.0])
+    state0 = torch.cat([xy, (torch.rand(B, A, 1, generator=g) - 0.5) * 1.0, 2 + 6 * torch.rand(B, A, 1, generator=g)], -1)
+    size = torch.cat([4.5 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g)), 2.0 * (0.9 + 0.2 * torch.rand(B, A, 1, generator=g))], -1)
+    present = torch.ones(B, A, dtype=torch.bool)
+    present[1, 3] = False
+    action = (torch.rand(B, A, 2, generator=g) - 0.5) * 2
+    lr = 1.0 + torch.rand(B, A, generator=g)
+    d.update(state0=npy(state0), size=npy(size), present=npy(present), action=npy(action), lr=npy(lr),
+             road_verts=npy(crop.verts[0]), road_faces=npy(crop.faces[0]).astype(np.int32))
+    for metric in ('iou', 'discs'):
+        s = state0.clone().requires_grad_(True)
+        a = action.clone().requires_grad_(True)
+        sim = make_sim(s, size.clone(), present.clone(), lr=lr.clone(), metric=metric, road_mesh=road)
+        sim.step(a)
+        coll = sim.compute_collision()
+        off = sim.compute_offroad()
+        loss = coll.sum() + off.sum()
+        loss.backward()
+        d[f'{metric}_state1'] = npy(sim.get_state())
+        d[f'{metric}_coll'], d[f'{metric}_off'] = npy(coll), npy(off)
+        d[f'{metric}_grad_state'], d[f'{metric}_grad_action'] = npy(s.grad), npy(a.grad)
+        # separate grads of each term w.r.t. the post-step state (isolates K2 backward from K1 backward)
+        s1 = sim.get_state().detach().clone().requires_grad_(True)
+        sim2 = make_sim(s1, size.clone(), present.clone(), lr=lr.clone(), metric=metric, road_mesh=road)
+        c2 = sim2.compute_collision().sum()
+        d[f'{metric}_grad_coll_wrt_state1'] = npy(torch.autograd.grad(c2, s1)[0])
+        o2 = sim2.compute_offroad().sum()
+        d[f'{metric}_grad_off_wrt_state1'] = npy(torch.autograd.grad(o2, s1)[0])
+    np.savez_compressed(os.path.join(out, 'g7_grads.npz'), **d)
+    print('g7 |grad_state|', np.abs(d['iou_grad_state']).max(), np.abs(d['discs_grad_state']).max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    cv2 = install_stubs()
+    sys.path.insert(0, REF)
+    torch.set_num_threads(1)
+    import torchdrivesim  # noqa: F401  (the reference)
+    assert os.path.realpath(torchdrivesim.__path__[0]).startswith(os.path.realpath(REF))
+    gen_kinematic(args.out)
+    gen_collision(args.out)
+    gen_scene_collision(args.out)
+    town = gen_town01(args.out)
+    gen_offroad(args.out, town)
+    gen_mesh_and_preraster(args.out, cv2, town)
+    gen_grads(args.out, town)
+    with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
+        f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
+                f'torch {torch.__version__} CPU, numpy {np.__version__}\n')
+
+
+if __name__ == '__main__':
+    main()
