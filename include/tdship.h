@@ -1,0 +1,168 @@
+/*
+ * tdship.h -- C ABI of libtdship.so, the MI355X (gfx950) implementation of the torchdrivesim hot path.
+ *
+ * The reference (inverted-ai/torchdrivesim v0.2.3) is pure Python on torch and has no FFI of its own; each
+ * entry point below names the reference function whose inner loop it replaces (file:line into the reference
+ * checkout).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (torch tensors, `.data_ptr()`), except
+ *     in tds_map_create / tds_grid_*(), which take HOST arrays (map preparation happens once per map);
+ *   - tensors are dense, row-major, fp32 / int32 / uint8 as stated; shapes are given in comments;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); kernels are enqueued on it and the call
+ *     returns without synchronising; calls are re-entrant per device;
+ *   - return value: 0 on success, a negative TDS_E* code otherwise (never throws); tds_last_error() returns the
+ *     message for the calling thread.  The Python host raises RuntimeError on any non-zero code, so
+ *     BirdviewRenderer.render_frame's `except RuntimeError` (rendering/base.py:190-201) still applies;
+ *   - sin/cos of agent and camera headings are INPUTS ([sin, cos] pairs), computed by the caller with torch on the
+ *     same device, exactly where the reference calls torch.sin/torch.cos (simulator.py:940, utils.py:40-53,
+ *     _iou_utils.py:290-291); all remaining arithmetic is IEEE-754 binary32 with one rounding per operation in the
+ *     reference's order (no FMA contraction) so integer / boolean outputs can be compared bit for bit.
+ */
+#ifndef TDSHIP_H
+#define TDSHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDS_ABI_VERSION 1
+
+#define TDS_OK 0
+#define TDS_EINVAL (-1)     /* bad argument (null pointer, negative size, unsupported resolution ...) */
+#define TDS_EHIP (-2)       /* a HIP runtime call or kernel launch failed */
+#define TDS_ENOMEM (-3)
+#define TDS_ELIMIT (-4)     /* a documented capacity was exceeded (e.g. more than 255 rendering levels) */
+
+int tds_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int tds_last_error(char *buf, size_t n);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K1  kinematic models                                                                   kinematic.py:328-523
+ * state / out: n x 4 [x, y, psi, v]  (n = B*A agents);  `out` must not alias `state` (the reference replaces the
+ * state tensor, it never mutates it: kinematic.py:477, pack_state = torch.stack).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* KinematicBicycle.step (kinematic.py:462-477) and BicycleNoReversing.step (:513-523, no_reversing != 0).
+ * action: n x 2 normalised [acceleration, steering];  lr: n. */
+int tds_bicycle_step_f32(const float *state, const float *action, const float *lr, float *out, int64_t n,
+                         float dt, float max_acc, float max_steer, int left_handed, int no_reversing, void *stream);
+/* backward of the above: grad_out n x 4 -> grad_state n x 4, grad_action n x 2, grad_lr n (any may be NULL) */
+int tds_bicycle_step_bwd_f32(const float *state, const float *action, const float *lr, const float *grad_out,
+                             float *grad_state, float *grad_action, float *grad_lr, int64_t n, float dt, float max_acc,
+                             float max_steer, int left_handed, int no_reversing, void *stream);
+
+/* SimpleKinematicModel.step (:362-367) / OrientedKinematicModel.step (:384-389, oriented != 0).
+ * action: n x 4 normalised, norm: 4 host floats [max_dx, max_dx, max_dpsi, max_dv]. */
+int tds_simple_step_f32(const float *state, const float *action, float *out, int64_t n, float dt, const float *norm,
+                        int oriented, void *stream);
+int tds_simple_step_bwd_f32(const float *state, const float *action, const float *grad_out, float *grad_state,
+                            float *grad_action, int64_t n, float dt, const float *norm, int oriented, void *stream);
+
+/* UnicycleModel.step -- named by the north star, absent from the reference: action n x 2 normalised
+ * [acceleration, yaw rate]: v += a dt; x += v cos(psi) dt; y += v sin(psi) dt; psi += w dt. */
+int tds_unicycle_step_f32(const float *state, const float *action, float *out, int64_t n, float dt, float max_acc,
+                          float max_yaw_rate, void *stream);
+int tds_unicycle_step_bwd_f32(const float *state, const float *action, const float *grad_out, float *grad_state,
+                              float *grad_action, int64_t n, float dt, float max_acc, float max_yaw_rate, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K2a  collisions                     simulator.py:1064-1109,1161-1194; _iou_utils.py:42-367; infractions.py:378-545
+ * ---------------------------------------------------------------------------------------------------------- */
+#define TDS_METRIC_IOU 0
+#define TDS_METRIC_DISCS 1
+
+/* Simulator.compute_collision for all exposed agents of all scenes at once.
+ *   boxes   B x N x 5  [x, y, length, width, psi]   all agents = A exposed agents followed by N-A NPCs
+ *   sc      B x N x 2  [sin, cos] of the angle the metric uses: psi (iou) or psi + pi/2*(width > length) (discs)
+ *   present B x N      uint8 (already restricted to the requested agent types, simulator.py:1086-1089)
+ *   out     B x A      collision_i = sum_j o_ij present_j - max_j o_ij present_j   
+ *   overlap B x A      uint64 bit j set iff o_ij present_j > 0, j != i   (NULL to skip; requires N <= 64)
+ *   partner B x A      int32 arg-max_j!=i of o_ij present_j, -1 if none   (NULL to skip)   [new outputs, SURVEY R8] */
+int tds_collision_f32(const float *boxes, const float *sc, const uint8_t *present, float *out, uint64_t *overlap,
+                      int32_t *partner, int64_t B, int64_t A, int64_t N, int metric, void *stream);
+/* backward: grad_out B x A -> grad_boxes B x N x 5 (psi column = 0), grad_sc B x N x 2; both are OVERWRITTEN */
+int tds_collision_bwd_f32(const float *boxes, const float *sc, const uint8_t *present, const float *grad_out,
+                          float *grad_boxes, float *grad_sc, int64_t B, int64_t A, int64_t N, int metric, void *stream);
+
+/* iou_differentiable (infractions.py:307-324) / collision_detection_with_discs (:503-545), element-wise over n pairs.
+ * box1, box2: n x 5; sc1, sc2: n x 2 as above. */
+int tds_pairwise_overlap_f32(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out,
+                             int64_t n, int metric, void *stream);
+
+/* box2corners_th (_iou_utils.py:270-299): box n x 5, sc n x 2 -> corners n x 4 x 2 */
+int tds_box2corners_f32(const float *box, const float *sc, float *corners, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Static map handle: triangle mesh + uniform grid, built once per map and per device.
+ * Replaces the per-call `mesh.expand(...)` / `RGBMesh.concat([background.expand(Nc), ...])` dataflow of
+ * infractions.py:220-226 and mesh.py:1147-1156.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct tds_map tds_map_t;
+
+/* HOST inputs: verts V x 2, faces F x 3 (indices into verts; padded faces [0,0,0] allowed, mesh.py:69),
+ * face_z F (rendering level of the face's FIRST vertex, cv2.py:44-46), face_rgb F (colour of the first vertex already
+ * quantised as cv2.py:50: 0x00RRGGBB), levels: n_levels distinct rendering levels sorted DESCENDING that contain every
+ * face_z and every actor level that will be rendered with this map (<= 255).  face_z / face_rgb / levels may be NULL
+ * for a map that is only used by tds_offroad_f32.  cell_size <= 0 selects the default (8 m).
+ * The handle lives on the CURRENT HIP device. */
+int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
+                   int64_t F, const float *levels, int n_levels, float cell_size, tds_map_t **out);
+int tds_map_destroy(tds_map_t *map);
+/* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, reserved */
+int tds_map_info(const tds_map_t *map, int64_t *info);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K2b  offroad              simulator.py:1035-1044; infractions.py:86-229 (pure-torch path, squared distances)
+ *   state B x A x 4, lenwid B x A x 2, sc B x A x 2 ([sin,cos] of psi), present B x A uint8 or NULL,
+ *   out B x A = sum over the 4 corners of threshold(min over faces of squared distance) [* present]
+ * ---------------------------------------------------------------------------------------------------------- */
+int tds_offroad_f32(const tds_map_t *map, const float *state, const float *lenwid, const float *sc,
+                    const uint8_t *present, float *out, int64_t n_agents, float threshold, void *stream);
+/* backward: grad_out n -> grad_state n x 4 (x, y columns; psi, v = 0), grad_lenwid n x 2, grad_sc n x 2 (overwritten) */
+int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, const float *lenwid, const float *sc,
+                        const uint8_t *present, const float *grad_out, float *grad_state, float *grad_lenwid,
+                        float *grad_sc, int64_t n_agents, float threshold, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K3  bird's-eye-view rasteriser, CV2 semantics
+ *     simulator.py:920-1033 -> mesh.py:1053-1157 -> rendering/base.py:167-204 -> rendering/cv2.py:27-70
+ * ---------------------------------------------------------------------------------------------------------- */
+#define TDS_OUT_F32 0      /* reference-faithful float32 image with values 0..255 */
+#define TDS_OUT_U8 1       /* same values as uint8 (separate mode, 4x fewer bytes) */
+
+/* Fused scene path used by Simulator.render / render_egocentric: the static map comes from the handle, the actor
+ * mesh is generated on the fly from agent state (never materialised per camera).
+ *   state     B x N x 4   all agents (exposed + NPCs)
+ *   agent_sc  B x N x 2   [sin, cos] of psi
+ *   tmpl      B x N x 7 x 2   actor template verts in the agent frame (mesh.py:911-996), built once by the host
+ *   actor_key B x N x 2   uint32 (rank << 24 | 0x00RRGGBB) for (body, direction) faces, rank = 1 + index of the
+ *                         part's rendering level in the map's `levels`
+ *   mask      B x Nc x N  uint8, present & rendering mask (simulator.py:946-948)
+ *   cam_xy    B x Nc x 2, cam_sc B x Nc x 2 [sin, cos]
+ *   scale = 2 / fov (rendering/base.py:149), res = H = W
+ *   out       B x Nc x 3 x H x W   float32 or uint8 (out_mode)
+ * Equal-level faces of different colour are ordered by packed colour (documented tie-break). */
+int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
+                     const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc,
+                     int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *stream);
+
+/* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
+ *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,
+ *   levels: n_levels HOST floats sorted descending containing every z in use (<= 255)
+ *   out   n_img x 3 x H x W  (CHW, i.e. already permuted as render_frame returns it, base.py:202-203) */
+int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces, int64_t n_img, int64_t V, int64_t F,
+                    const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,
+                    int out_mode, void *out, void *stream);
+
+/* test / tuning hook: force the LDS strip width of K3 (0 = automatic, else 8, 16, 32 or 64 output rows) */
+int tds_raster_set_strip_width(int tw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDSHIP_H */

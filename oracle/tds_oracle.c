@@ -658,12 +658,25 @@ static void project_px(float vx, float vy, float s, float c, float scale, int W,
     *ox = (int32_t)rx; *oy = (int32_t)ry;
 }
 
-typedef struct { float z; int32_t f; } zface;
-static int zcmp(const void *a, const void *b) {      /* z descending, ties by original index (documented tie-break) */
+typedef struct { float z; uint32_t rgb; int32_t f; } zface;
+/* Painter order: z descending (cv2.py:47).  torch.argsort is not stable, so the reference leaves the order of
+ * equal-z faces unspecified; the documented tie-break of this project is: packed colour
+ * 0x00RRGGBB ascending (the larger colour is drawn later and wins), then original face index. */
+static int zcmp(const void *a, const void *b) {
     const zface *p = (const zface *)a, *q = (const zface *)b;
     if (p->z > q->z) return -1;
     if (p->z < q->z) return 1;
+    if (p->rgb != q->rgb) return p->rgb < q->rgb ? -1 : 1;
     return (p->f > q->f) - (p->f < q->f);
+}
+
+static void quantise_color(const float *attr, float col[3], uint32_t *packed) {       /* cv2.py:50 */
+    *packed = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        float q = floorf((attr[ch] * (float)(1.0 - 1e-3)) * 256.0f);
+        col[ch] = (float)(uint8_t)q;
+        *packed = (*packed << 8) | (uint8_t)q;
+    }
 }
 
 /* CV2Renderer.render_rgb_mesh, rendering/cv2.py:27-70, for ONE image.
@@ -686,7 +699,12 @@ ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, 
     int64_t nk = 0;
     for (int64_t f = 0; f < F; ++f) {                                 /* mesh.trim: keep iff >= 1 vertex inside */
         const int32_t *fv = faces + 3 * f;
-        if (ins[fv[0]] || ins[fv[1]] || ins[fv[2]]) { order[nk].z = verts[3 * fv[0] + 2]; order[nk].f = (int32_t)f; ++nk; }
+        if (ins[fv[0]] || ins[fv[1]] || ins[fv[2]]) {
+            float tmpc[3];
+            order[nk].z = verts[3 * fv[0] + 2]; order[nk].f = (int32_t)f;
+            quantise_color(attrs + 3 * fv[0], tmpc, &order[nk].rgb);
+            ++nk;
+        }
     }
     qsort(order, nk, sizeof(zface), zcmp);                            /* painter order, cv2.py:44-47 */
     float *raw = (float *)calloc((size_t)W * H * 3, sizeof(float));   /* OpenCV image: raw[y][x] */
@@ -695,10 +713,8 @@ ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, 
         int32_t pts[6];
         for (int j = 0; j < 3; ++j) project_px(sv[2 * fv[j]], sv[2 * fv[j] + 1], s, c, scale, W, H, &pts[2 * j], &pts[2 * j + 1]);
         float col[3];
-        for (int ch = 0; ch < 3; ++ch) {                              /* cv2.py:50 */
-            float q = floorf((attrs[3 * fv[0] + ch] * (float)(1.0 - 1e-3)) * 256.0f);
-            col[ch] = (float)(uint8_t)q;
-        }
+        uint32_t packed;
+        quantise_color(attrs + 3 * fv[0], col, &packed);
         if (rec_tris && k < rec_cap) {
             memcpy(rec_tris + 6 * k, pts, sizeof(pts));
             for (int ch = 0; ch < 3; ++ch) rec_cols[3 * k + ch] = (uint8_t)col[ch];

@@ -1,0 +1,109 @@
+"""
+ctypes binding of libtdship.so (C ABI: include/tdship.h).  The library is built in-tree by
+``torchdrivesim_amd/csrc/Makefile`` (``python -c "import __graft_entry__ as g; g.build()"``).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtdship.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+METRIC_IOU, METRIC_DISCS = 0, 1
+OUT_F32, OUT_U8 = 0, 1
+
+_lib = None
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes  (mirrors include/tdship.h; tests/test_abi.py checks that every declared symbol is exported)
+_SIGNATURES = {
+    'tds_version': [],
+    'tds_last_error': [ctypes.c_char_p, ctypes.c_size_t],
+    'tds_bicycle_step_f32': [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp],
+    'tds_bicycle_step_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp],
+    'tds_simple_step_f32': [_vp, _vp, _vp, _i64, _f32, ctypes.POINTER(_f32), _i32, _vp],
+    'tds_simple_step_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _f32, ctypes.POINTER(_f32), _i32, _vp],
+    'tds_unicycle_step_f32': [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
+    'tds_unicycle_step_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
+    'tds_collision_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    'tds_collision_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    'tds_pairwise_overlap_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    'tds_box2corners_f32': [_vp, _vp, _vp, _i64, _vp],
+    'tds_map_create': [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _f32, ctypes.POINTER(_vp)],
+    'tds_map_destroy': [_vp],
+    'tds_map_info': [_vp, ctypes.POINTER(_i64)],
+    'tds_offroad_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
+    'tds_offroad_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
+    'tds_raster_scene': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _vp],
+    'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp],
+    'tds_raster_set_strip_width': [_i32],
+}
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into torchdrivesim_amd/lib/libtdship.so (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))]
+    if force:
+        cmd.append('-B')
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the HIP extension has not been built. Run '
+                '`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). There is no CPU fallback.')
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().tds_last_error(buf, 512)
+    return buf.value.decode(errors='replace')
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed (code {rc}): {last_error()}')
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_ptr(t, dtype, name):
+    """Device pointer of a dense tensor; refuses anything the kernels cannot read as-is."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: torchdrivesim_amd kernels run on an MI355X; got a {t.device} tensor (no CPU fallback)')
+    if t.dtype != dtype:
+        raise RuntimeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name}: tensor must be contiguous')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, device, *args):
+    """Run a C-ABI entry point with `device` current (the stream argument must belong to it)."""
+    with torch.cuda.device(device):
+        rc = getattr(lib(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,347 @@
+"""
+Tensor-level entry points of the HIP kernels (device tensors in, device tensors out, launched on torch's current
+stream through the C ABI of include/tdship.h).  The reference-shaped classes in kinematic.py, infractions.py,
+rendering/ and simulator.py are thin layers over these.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from torchdrivesim_amd import _native as nat
+
+f32, u8, i32 = torch.float32, torch.uint8, torch.int32
+
+
+def _c(t, dtype=f32):
+    """dense tensor of the dtype the kernels read (no copy when already so)"""
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def heading_sc(psi):
+    """[sin, cos] of headings with torch on the tensor's device -- exactly where the reference calls torch.sin/cos
+    (simulator.py:940, utils.py:40-53, _iou_utils.py:290-291).  psi: (...,) -> (..., 2); differentiable."""
+    return torch.stack([torch.sin(psi), torch.cos(psi)], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1 kinematics
+# ---------------------------------------------------------------------------------------------------------------
+class _BicycleStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, action, lr, dt, max_acc, max_steer, left_handed, no_reversing):
+        state, action, lr = _c(state), _c(action), _c(lr)
+        out = torch.empty_like(state)
+        n = lr.numel()
+        nat.call('tds_bicycle_step_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(action, f32, 'action'),
+                 nat.dev_ptr(lr, f32, 'lr'), nat.dev_ptr(out, f32, 'out'), n, dt, max_acc, max_steer, int(left_handed),
+                 int(no_reversing), nat.stream_ptr(state.device))
+        ctx.save_for_backward(state, action, lr)
+        ctx.cfg = (dt, max_acc, max_steer, int(left_handed), int(no_reversing))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, action, lr = ctx.saved_tensors
+        dt, max_acc, max_steer, lh, norev = ctx.cfg
+        gout = _c(gout)
+        gs, ga, gl = torch.empty_like(state), torch.empty_like(action), torch.empty_like(lr)
+        nat.call('tds_bicycle_step_bwd_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(action, f32, 'action'),
+                 nat.dev_ptr(lr, f32, 'lr'), nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gs, f32, 'gs'), nat.dev_ptr(ga, f32, 'ga'),
+                 nat.dev_ptr(gl, f32, 'gl'), lr.numel(), dt, max_acc, max_steer, lh, norev, nat.stream_ptr(state.device))
+        return gs, ga, gl, None, None, None, None, None
+
+
+def bicycle_step(state, action, lr, dt=0.1, max_acc=5.0, max_steer=float(np.float32(np.pi / 2)), left_handed=False,
+                 no_reversing=False):
+    """state (...,4), action (...,2), lr (...) -> new state tensor (...,4) (kinematic.py:462-477 / :513-523)"""
+    assert state.shape[-1] == 4 and action.shape[-1] == 2 and state.shape[:-1] == action.shape[:-1] == lr.shape
+    return _BicycleStep.apply(state, action, lr, float(dt), float(max_acc), float(max_steer), bool(left_handed), bool(no_reversing))
+
+
+class _SimpleStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, action, dt, norm, oriented):
+        state, action = _c(state), _c(action)
+        out = torch.empty_like(state)
+        cn = (ctypes.c_float * 4)(*norm)
+        nat.call('tds_simple_step_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(action, f32, 'action'),
+                 nat.dev_ptr(out, f32, 'out'), state.numel() // 4, dt, cn, int(oriented), nat.stream_ptr(state.device))
+        ctx.save_for_backward(state, action)
+        ctx.cfg = (dt, tuple(norm), int(oriented))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, action = ctx.saved_tensors
+        dt, norm, oriented = ctx.cfg
+        gout = _c(gout)
+        gs, ga = torch.empty_like(state), torch.empty_like(action)
+        cn = (ctypes.c_float * 4)(*norm)
+        nat.call('tds_simple_step_bwd_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(action, f32, 'action'),
+                 nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gs, f32, 'gs'), nat.dev_ptr(ga, f32, 'ga'), state.numel() // 4, dt, cn,
+                 oriented, nat.stream_ptr(state.device))
+        return gs, ga, None, None, None
+
+
+def simple_step(state, action, dt=0.1, norm=(20.0, 20.0, 10 * np.pi, 5.0), oriented=False):
+    assert state.shape[-1] == 4 and action.shape == state.shape
+    return _SimpleStep.apply(state, action, float(dt), tuple(float(x) for x in norm), bool(oriented))
+
+
+class _UnicycleStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, action, dt, max_acc, max_w):
+        state, action = _c(state), _c(action)
+        out = torch.empty_like(state)
+        nat.call('tds_unicycle_step_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(action, f32, 'action'),
+                 nat.dev_ptr(out, f32, 'out'), state.numel() // 4, dt, max_acc, max_w, nat.stream_ptr(state.device))
+        ctx.save_for_backward(state, action)
+        ctx.cfg = (dt, max_acc, max_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, action = ctx.saved_tensors
+        dt, max_acc, max_w = ctx.cfg
+        gout = _c(gout)
+        gs, ga = torch.empty_like(state), torch.empty_like(action)
+        nat.call('tds_unicycle_step_bwd_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(action, f32, 'action'),
+                 nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gs, f32, 'gs'), nat.dev_ptr(ga, f32, 'ga'), state.numel() // 4, dt,
+                 max_acc, max_w, nat.stream_ptr(state.device))
+        return gs, ga, None, None, None
+
+
+def unicycle_step(state, action, dt=0.1, max_acc=5.0, max_yaw_rate=1.0):
+    assert state.shape[-1] == 4 and action.shape[-1] == 2
+    return _UnicycleStep.apply(state, action, float(dt), float(max_acc), float(max_yaw_rate))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K2a collisions
+# ---------------------------------------------------------------------------------------------------------------
+_METRICS = {'iou': nat.METRIC_IOU, 'discs': nat.METRIC_DISCS}
+
+
+def metric_sc(boxes, metric):
+    """[sin, cos] of the heading the metric uses: psi (iou, _iou_utils.py:290-291) or
+    psi + pi/2 * (width > length) (discs, infractions.py:404).  boxes (...,5)."""
+    psi = boxes[..., 4]
+    if metric == 'discs':
+        psi = psi + (np.pi / 2) * (boxes[..., 3] > boxes[..., 2])
+    return heading_sc(psi)
+
+
+def collision_forward(boxes, sc, present, n_exposed, metric, want_overlap=False, want_partner=False):
+    boxes, sc = _c(boxes), _c(sc)
+    present = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
+    B, N = boxes.shape[:2]
+    A = N if n_exposed is None else int(n_exposed)
+    out = torch.empty((B, A), dtype=f32, device=boxes.device)
+    overlap = torch.empty((B, A), dtype=torch.int64, device=boxes.device) if want_overlap else None
+    partner = torch.empty((B, A), dtype=i32, device=boxes.device) if want_partner else None
+    nat.call('tds_collision_f32', boxes.device, nat.dev_ptr(boxes, f32, 'boxes'), nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(present, u8, 'present'),
+             nat.dev_ptr(out, f32, 'out'), nat.dev_ptr(overlap, torch.int64, 'overlap'), nat.dev_ptr(partner, i32, 'partner'), B, A, N,
+             _METRICS[metric], nat.stream_ptr(boxes.device))
+    return out, overlap, partner
+
+
+class _Collision(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, boxes, sc, present, n_exposed, metric):
+        boxes, sc = _c(boxes), _c(sc)
+        out, _, _ = collision_forward(boxes, sc, present, n_exposed, metric)
+        ctx.save_for_backward(boxes, sc, present)
+        ctx.cfg = (n_exposed, metric)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        boxes, sc, present = ctx.saved_tensors
+        n_exposed, metric = ctx.cfg
+        B, N = boxes.shape[:2]
+        A = N if n_exposed is None else int(n_exposed)
+        gout = _c(gout)
+        pres = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
+        gb, gsc = torch.empty_like(boxes), torch.empty_like(sc)
+        nat.call('tds_collision_bwd_f32', boxes.device, nat.dev_ptr(boxes, f32, 'boxes'), nat.dev_ptr(sc, f32, 'sc'),
+                 nat.dev_ptr(pres, u8, 'present'), nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gb, f32, 'gb'), nat.dev_ptr(gsc, f32, 'gsc'),
+                 B, A, N, _METRICS[metric], nat.stream_ptr(boxes.device))
+        return gb, gsc, None, None, None
+
+
+def collision(boxes, present, n_exposed=None, metric='iou', sc=None):
+    """Simulator.compute_collision fused over a scene: boxes (B,N,5) [x,y,len,wid,psi], present (B,N) -> (B,A)."""
+    if sc is None:
+        sc = metric_sc(torch.nan_to_num(boxes, nan=0.0), metric)
+    return _Collision.apply(boxes, sc, present, n_exposed, metric)
+
+
+def pairwise_overlap(box1, box2, metric='iou', sc1=None, sc2=None):
+    """iou_differentiable / collision_detection_with_discs (infractions.py:307,503), element-wise; boxes (...,5).
+    Forward only (the fused scene entry point carries the gradient)."""
+    shape = box1.shape[:-1]
+    if sc1 is None:
+        sc1 = metric_sc(box1, metric)
+    if sc2 is None:
+        sc2 = metric_sc(box2, metric)
+    b1, b2, s1, s2 = _c(box1).reshape(-1, 5), _c(box2).reshape(-1, 5), _c(sc1).reshape(-1, 2), _c(sc2).reshape(-1, 2)
+    out = torch.empty(b1.shape[0], dtype=f32, device=b1.device)
+    nat.call('tds_pairwise_overlap_f32', b1.device, nat.dev_ptr(b1, f32, 'box1'), nat.dev_ptr(s1, f32, 'sc1'), nat.dev_ptr(b2, f32, 'box2'),
+             nat.dev_ptr(s2, f32, 'sc2'), nat.dev_ptr(out, f32, 'out'), b1.shape[0], _METRICS[metric], nat.stream_ptr(b1.device))
+    return out.reshape(shape)
+
+
+def box2corners(box, sc=None):
+    """_iou_utils.box2corners_th: (...,5) -> (...,4,2)"""
+    if sc is None:
+        sc = heading_sc(box[..., 4])
+    b, s = _c(box).reshape(-1, 5), _c(sc).reshape(-1, 2)
+    out = torch.empty((b.shape[0], 4, 2), dtype=f32, device=b.device)
+    nat.call('tds_box2corners_f32', b.device, nat.dev_ptr(b, f32, 'box'), nat.dev_ptr(s, f32, 'sc'), nat.dev_ptr(out, f32, 'out'), b.shape[0],
+             nat.stream_ptr(b.device))
+    return out.reshape(box.shape[:-1] + (4, 2))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# static map handle, K2b offroad
+# ---------------------------------------------------------------------------------------------------------------
+def quantise_colors(attrs):
+    """cv2.py:50: floor(attr * (1 - 1e-3) * 256) as uint8, packed 0x00RRGGBB.  attrs (...,3) float32 cpu tensor -> int64"""
+    q = (attrs.to(f32) * (1.0 - 1e-3) * 256).floor().to(torch.uint8).to(torch.int64)
+    return (q[..., 0] << 16) | (q[..., 1] << 8) | q[..., 2]
+
+
+class StaticMap:
+    """Device-resident static mesh + uniform grid (tds_map_t).  Built once per map and per device from HOST arrays."""
+
+    def __init__(self, verts, faces, face_z=None, face_rgb=None, levels=None, device='cuda', cell_size=0.0):
+        verts = np.ascontiguousarray(torch.as_tensor(verts).detach().cpu().numpy(), dtype=np.float32).reshape(-1, 2)
+        faces = np.ascontiguousarray(torch.as_tensor(faces).detach().cpu().numpy(), dtype=np.int32).reshape(-1, 3)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('StaticMap lives on an MI355X; there is no CPU implementation')
+        self.n_verts, self.n_faces = verts.shape[0], faces.shape[0]
+        self.levels = None if levels is None else [float(x) for x in levels]
+        vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        fz = None if face_z is None else np.ascontiguousarray(np.asarray(face_z), dtype=np.float32)
+        fc = None if face_rgb is None else np.ascontiguousarray(np.asarray(face_rgb), dtype=np.uint32)
+        lv = None if levels is None else np.ascontiguousarray(np.asarray(levels), dtype=np.float32)
+        handle = ctypes.c_void_p()
+        nat.call('tds_map_create', self.device, vp(verts), vp(faces), vp(fz), vp(fc), verts.shape[0], faces.shape[0], vp(lv),
+                 0 if lv is None else len(lv), float(cell_size), ctypes.byref(handle))
+        self._h = handle
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError('StaticMap was destroyed')
+        return self._h
+
+    def info(self):
+        buf = (ctypes.c_int64 * 8)()
+        nat.call('tds_map_info', self.device, self.handle, buf)
+        return dict(V=buf[0], F=buf[1], nx=buf[2], ny=buf[3], entries=buf[4], bytes=buf[5], n_levels=buf[6])
+
+    def rank_of(self, level):
+        """1-based painter rank of a rendering level (larger = drawn later = on top)"""
+        return self.levels.index(float(level)) + 1
+
+    def close(self):
+        if getattr(self, '_h', None) is not None:
+            h, self._h = self._h, None
+            nat.call('tds_map_destroy', self.device, h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def offroad_forward(smap, state, lenwid, sc, present, threshold):
+    state, lenwid, sc = _c(state), _c(lenwid), _c(sc)
+    n = state.numel() // 4
+    out = torch.empty(state.shape[:-1], dtype=f32, device=state.device)
+    pres = None
+    if present is not None:
+        pres = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
+    nat.call('tds_offroad_f32', state.device, smap.handle, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(lenwid, f32, 'lenwid'),
+             nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(pres, u8, 'present'), nat.dev_ptr(out, f32, 'out'), n, float(threshold),
+             nat.stream_ptr(state.device))
+    return out
+
+
+class _Offroad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, smap, state, lenwid, sc, present, threshold):
+        state, lenwid, sc = _c(state), _c(lenwid), _c(sc)
+        out = offroad_forward(smap, state, lenwid, sc, present, threshold)
+        ctx.save_for_backward(state, lenwid, sc)
+        ctx.cfg = (smap, present, threshold)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, lenwid, sc = ctx.saved_tensors
+        smap, present, threshold = ctx.cfg
+        gout = _c(gout)
+        pres = None
+        if present is not None:
+            pres = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
+        gs, gl, gsc = torch.empty_like(state), torch.empty_like(lenwid), torch.empty_like(sc)
+        nat.call('tds_offroad_bwd_f32', state.device, smap.handle, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(lenwid, f32, 'lenwid'),
+                 nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(pres, u8, 'present'), nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gs, f32, 'gs'),
+                 nat.dev_ptr(gl, f32, 'gl'), nat.dev_ptr(gsc, f32, 'gsc'), state.numel() // 4, float(threshold), nat.stream_ptr(state.device))
+        return None, gs, gl, gsc, None, None
+
+
+def offroad(smap, state, lenwid, threshold=0.5, present=None, sc=None):
+    """offroad_infraction_loss (infractions.py:176-229, pure path) [* present]: state (...,4), lenwid (...,2) -> (...)"""
+    if sc is None:
+        sc = heading_sc(state[..., 2])
+    return _Offroad.apply(smap, state, lenwid, sc, present, float(threshold))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K3 rasteriser
+# ---------------------------------------------------------------------------------------------------------------
+def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None):
+    """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns,
+    mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2) -> (B,Nc,3,res,res) float32 [0,255] or uint8."""
+    B, Nc = cam_xy.shape[:2]
+    N = state.shape[1]
+    dev = cam_xy.device
+    cam_xy, cam_sc = _c(cam_xy), _c(cam_sc)
+    if N > 0:
+        state, agent_sc, tmpl = _c(state), _c(agent_sc), _c(tmpl)
+        actor_key = _c(actor_key, i32)
+        mask = mask.contiguous().view(u8) if mask.dtype == torch.bool else _c(mask, u8)
+    assert out_dtype in (torch.float32, torch.uint8)
+    if out is None:
+        out = torch.empty((B, Nc, 3, res, res), dtype=out_dtype, device=dev)
+    else:
+        assert out.shape == (B, Nc, 3, res, res) and out.dtype == out_dtype and out.is_contiguous()
+    p = lambda t, d, nme: nat.dev_ptr(t, d, nme) if N > 0 else None
+    nat.call('tds_raster_scene', dev, smap.handle, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
+             p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
+             B, Nc, N, float(2.0 / fov), int(res), nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8,
+             nat.dev_ptr(out, out_dtype, 'out'), nat.stream_ptr(dev))
+    return out
+
+
+def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32):
+    """Generic render_rgb_mesh: verts (n,V,3), attrs (n,V,3), faces (n,F,3) -> (n,3,res,res)"""
+    n = cam_xy.shape[0]
+    dev = cam_xy.device
+    verts, attrs, cam_xy, cam_sc = _c(verts), _c(attrs), _c(cam_xy), _c(cam_sc)
+    faces = _c(faces, i32)
+    out = torch.empty((n, 3, res, res), dtype=out_dtype, device=dev)
+    lv = (ctypes.c_float * max(len(levels), 1))(*[float(x) for x in levels])
+    nat.call('tds_raster_mesh', dev, nat.dev_ptr(verts, f32, 'verts'), nat.dev_ptr(attrs, f32, 'attrs'), nat.dev_ptr(faces, i32, 'faces'),
+             n, verts.shape[1], faces.shape[1], nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
+             ctypes.cast(lv, ctypes.c_void_p), len(levels), float(scale), int(res),
+             nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8, nat.dev_ptr(out, out_dtype, 'out'), nat.stream_ptr(dev))
+    return out

@@ -1,0 +1,387 @@
+// K2a: pairwise oriented-box overlap (Rotated-IoU and 5-disc metric) and Simulator.compute_collision fused over all
+// exposed agents of a scene.  One wavefront owns a row i of a scene (lanes = other agents j); 4 rows per wave.
+// Reference: simulator.py:1064-1109,1161-1194; _iou_utils.py:42-367; infractions.py:378-426,503-545.
+// Compute bound (~2k VALU ops per surviving pair, 16 IEEE divisions); bytes are negligible (20 B/agent).
+#include "tds_common.h"
+
+namespace {
+
+constexpr int CBLOCK = 256;            // 4 waves
+constexpr int ROWS_PER_WAVE = 4;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct Box { float x, y, l, w; float s, c; };
+struct Corners { float x[4], y[4]; };
+
+__device__ __forceinline__ float scrub(float v) {          // torch.nan_to_num(nan=0) simulator.py:1095-1096
+    if (v != v) return 0.0f;
+    if (__builtin_isinf(v)) return v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    return v;
+}
+
+// box2corners_th, _iou_utils.py:270-299: corners @ [[c,s],[-s,c]] + centre, one rounding per op
+__device__ __forceinline__ Corners corners_of(const Box &b) {
+    const float sx[4] = {0.5f, -0.5f, -0.5f, 0.5f}, sy[4] = {0.5f, 0.5f, -0.5f, -0.5f};
+    Corners c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x4 = sx[k] * b.l, y4 = sy[k] * b.w;
+        float rx = x4 * b.c + y4 * (-b.s);
+        float ry = x4 * b.s + y4 * b.c;
+        c.x[k] = rx + b.x;
+        c.y[k] = ry + b.y;
+    }
+    return c;
+}
+
+// corner k of `p` inside box `q` (box1_in_box2, _iou_utils.py:87-114).
+// round(q*1e6)/1e6 in (-1e-6, 1+1e-6)  <=>  0 <= rint(q*1e6) <= 1e6  (both divisions by 1e6 are correctly rounded
+// and monotone, fl(-1/1e6) == fl32(-1e-6), fl(1000001/1e6) == fl32(1+1e-6)), which saves two divisions per test.
+__device__ __forceinline__ unsigned corners_in(const Corners &p, const Corners &q) {
+    float ax = q.x[0], ay = q.y[0];
+    float abx = q.x[1] - ax, aby = q.y[1] - ay;
+    float adx = q.x[3] - ax, ady = q.y[3] - ay;
+    float nab = abx * abx + aby * aby, nad = adx * adx + ady * ady;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float amx = p.x[k] - ax, amy = p.y[k] - ay;
+        float r1 = rintf(((abx * amx + aby * amy) / nab) * 1000000.0f);
+        float r2 = rintf(((adx * amx + ady * amy) / nad) * 1000000.0f);
+        bool in = (r1 >= 0.0f) && (r1 <= 1000000.0f) && (r2 >= 0.0f) && (r2 <= 1000000.0f);
+        m |= (in ? 1u : 0u) << k;
+    }
+    return m;
+}
+
+// Rare path (more than 8 valid candidates, _iou_utils.py:191-214) and the general definition: mirrors
+// sort_indices/calculate_area on arrays (lives in scratch; only entered when the fast path cannot apply).
+__device__ __noinline__ float area_general(const float *vx, const float *vy, unsigned mask, float cx, float cy) {
+    float ang[24];
+    int order[24];
+    int n = __popc(mask);
+    for (int k = 0; k < 24; ++k) {
+        float dx = vx[k] - cx, dy = vy[k] - cy;
+        float r = sqrtf(dx * dx + dy * dy);
+        float a = acosf(dx / r);
+        ang[k] = (dy > 0.0f) ? a : (2.0f * PI_F - a);
+    }
+    for (;;) {
+        for (int k = 0; k < 24; ++k) order[k] = k;
+        for (int a = 1; a < 24; ++a) {
+            int o = order[a];
+            float key = ((mask >> o) & 1) ? ang[o] : __builtin_inff();
+            int b = a - 1;
+            while (b >= 0) {
+                float kb = ((mask >> order[b]) & 1) ? ang[order[b]] : __builtin_inff();
+                bool gt = ((kb != kb) && (key == key)) || (kb > key);
+                if (!gt) break;
+                order[b + 1] = order[b];
+                --b;
+            }
+            order[b + 1] = o;
+        }
+        if (n <= 8) break;
+        int best = 0;
+        float bestd = __builtin_inff();
+        for (int k = 0; k < n - 1; ++k) {
+            float dx = vx[order[k]] - vx[order[k + 1]], dy = vy[order[k]] - vy[order[k + 1]];
+            float d = sqrtf(dx * dx + dy * dy);
+            if (d < bestd) { bestd = d; best = k; }
+        }
+        mask &= ~(1u << order[best]);
+        --n;
+    }
+    if (n < 3) return 0.0f;
+    float total = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        int a = order[k], b = order[(k + 1 == n) ? 0 : k + 1];
+        total = total + (vx[a] * vy[b] - vy[a] * vx[b]);
+    }
+    return fabsf(total) / 2.0f;
+}
+
+// Intersection area of two rectangles (oriented_box_intersection_2d, _iou_utils.py:250-267).
+// `scr` is this wave's LDS scratch: 16 planes of 64 floats (8 slots x {x,y}) addressed [plane*64 + lane].
+__device__ float intersection_area(const Corners &c1, const Corners &c2, float *scr, int lane) {
+    float acc_x[4] = {0.f, 0.f, 0.f, 0.f}, acc_y[4] = {0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    unsigned mask = 0;
+    auto push = [&](int k, float x, float y) {
+        acc_x[k & 3] = acc_x[k & 3] + x;           // torch.sum over the strided dim: 4 interleaved accumulators
+        acc_y[k & 3] = acc_y[k & 3] + y;
+        if (n < 8) { scr[(2 * n) * 64 + lane] = x; scr[(2 * n + 1) * 64 + lane] = y; }
+        ++n;
+        mask |= 1u << k;
+    };
+    unsigned in12 = corners_in(c1, c2), in21 = corners_in(c2, c1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((in12 >> k) & 1) push(k, c1.x[k], c1.y[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((in21 >> k) & 1) push(4 + k, c2.x[k], c2.y[k]);
+    // box_intersection_th, _iou_utils.py:42-84.  0 < fl(a/b) < 1  <=>  a, b same sign and |a| < |b| for finite floats,
+    // so the two mask divisions are replaced by comparisons; only the point itself needs den_t / (num + 1e-8).
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float x1 = c1.x[i], y1 = c1.y[i], x2 = c1.x[(i + 1) & 3], y2 = c1.y[(i + 1) & 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x3 = c2.x[j], y3 = c2.y[j], x4 = c2.x[(j + 1) & 3], y4 = c2.y[(j + 1) & 3];
+            float num = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+            float den_t = (x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4);
+            float nden_u = -((x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3));
+            float an = fabsf(num);
+            bool ok = !(an < (float)1e-4) && (an == an);
+            bool mt = ok && ((den_t > 0.0f) == (num > 0.0f)) && (den_t != 0.0f) && (fabsf(den_t) < an);
+            bool mu = ok && ((nden_u > 0.0f) == (num > 0.0f)) && (nden_u != 0.0f) && (fabsf(nden_u) < an);
+            if (mt && mu) {
+                float t = den_t / (num + (float)1e-8);
+                push(8 + i * 4 + j, x1 + t * (x2 - x1), y1 + t * (y2 - y1));
+            }
+        }
+    }
+    if (n < 3) return 0.0f;
+    float fn = (float)n;
+    float cx = (((acc_x[0] + acc_x[1]) + acc_x[2]) + acc_x[3]) / fn;
+    float cy = (((acc_y[0] + acc_y[1]) + acc_y[2]) + acc_y[3]) / fn;
+    if (n > 8) {
+        // rebuild the 24-candidate arrays for the general path (never seen in 1M random pairs)
+        float vx[24], vy[24];
+        for (int k = 0; k < 4; ++k) { vx[k] = c1.x[k]; vy[k] = c1.y[k]; vx[4 + k] = c2.x[k]; vy[4 + k] = c2.y[k]; }
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+            float x1 = c1.x[i], y1 = c1.y[i], x2 = c1.x[(i + 1) & 3], y2 = c1.y[(i + 1) & 3];
+            float x3 = c2.x[j], y3 = c2.y[j], x4 = c2.x[(j + 1) & 3], y4 = c2.y[(j + 1) & 3];
+            float num = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+            float den_t = (x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4);
+            float t = den_t / (num + (float)1e-8);
+            float fm = ((mask >> (8 + i * 4 + j)) & 1) ? 1.0f : 0.0f;
+            vx[8 + i * 4 + j] = (x1 + t * (x2 - x1)) * fm;
+            vy[8 + i * 4 + j] = (y1 + t * (y2 - y1)) * fm;
+        }
+        return area_general(vx, vy, mask, cx, cy);
+    }
+    // angular sort of the <= 8 valid vertices.  acos is monotone, so ordering by the angle equals ordering by
+    // key = (dy > 0) ? -q : 2 + q with q = dx / r  (_iou_utils.py:181-186); invalid slots sort last.
+    float sxv[8], syv[8], key[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        float x = scr[(2 * s) * 64 + lane], y = scr[(2 * s + 1) * 64 + lane];
+        float dx = x - cx, dy = y - cy;
+        float q = dx / sqrtf(dx * dx + dy * dy);
+        float k = (dy > 0.0f) ? -q : 2.0f + q;
+        bool live = s < n;
+        sxv[s] = live ? x : 0.0f;
+        syv[s] = live ? y : 0.0f;
+        key[s] = live ? ((k == k) ? k : 3.5f) : 4.0f;      // NaN keys after valid ones, dead slots last
+    }
+#define TDS_CSWAP(a, b)                                                                      \
+    {                                                                                        \
+        bool sw = key[a] > key[b];                                                           \
+        float tk = sw ? key[b] : key[a], uk = sw ? key[a] : key[b];                          \
+        float tx = sw ? sxv[b] : sxv[a], ux = sw ? sxv[a] : sxv[b];                          \
+        float ty = sw ? syv[b] : syv[a], uy = sw ? syv[a] : syv[b];                          \
+        key[a] = tk; key[b] = uk; sxv[a] = tx; sxv[b] = ux; syv[a] = ty; syv[b] = uy;        \
+    }
+    TDS_CSWAP(0, 1) TDS_CSWAP(2, 3) TDS_CSWAP(4, 5) TDS_CSWAP(6, 7)
+    TDS_CSWAP(0, 2) TDS_CSWAP(1, 3) TDS_CSWAP(4, 6) TDS_CSWAP(5, 7)
+    TDS_CSWAP(1, 2) TDS_CSWAP(5, 6) TDS_CSWAP(0, 4) TDS_CSWAP(3, 7)
+    TDS_CSWAP(1, 5) TDS_CSWAP(2, 6)
+    TDS_CSWAP(1, 4) TDS_CSWAP(3, 6)
+    TDS_CSWAP(2, 4) TDS_CSWAP(3, 5)
+    TDS_CSWAP(3, 4)
+#undef TDS_CSWAP
+    // shoelace over [v0..v(n-1), v0] (calculate_area, _iou_utils.py:230-247), summed in order
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float nx = (k + 1 < 8) ? sxv[k + 1] : 0.0f, ny = (k + 1 < 8) ? syv[k + 1] : 0.0f;
+        if (k + 1 >= n) { nx = sxv[0]; ny = syv[0]; }
+        float term = sxv[k] * ny - syv[k] * nx;
+        if (k < n) total = total + term;
+    }
+    return fabsf(total) / 2.0f;
+}
+
+__device__ float iou_pair(const Box &b1, const Corners &c1, const Box &b2, const Corners &c2, float *scr, int lane) {
+    float a1 = b1.l * b1.w, a2 = b2.l * b2.w;
+    // disjoint bounding circles (with margin) -> no valid candidate -> area 0 exactly, as in the reference
+    float dx = b1.x - b2.x, dy = b1.y - b2.y;
+    float r1 = 0.5f * sqrtf(b1.l * b1.l + b1.w * b1.w), r2 = 0.5f * sqrtf(b2.l * b2.l + b2.w * b2.w);
+    float reach = r1 + r2 + 0.05f + 1e-5f * fmaxf(fmaxf(fabsf(b1.x), fabsf(b1.y)), fmaxf(fabsf(b2.x), fabsf(b2.y)));
+    float inter = 0.0f;
+    if (!(dx * dx + dy * dy > reach * reach)) inter = intersection_area(c1, c2, scr, lane);
+    float u = a1 + a2 - inter;
+    return inter / u;                          // iou_differentiable_fast :363-367
+}
+
+// bbox2discs + cdist + relu, infractions.py:378-426,503-545.  b.s/b.c are of yaw + pi/2*(wid>len).
+__device__ float discs_pair(const Box &b1, const Box &b2) {
+    float ra = fminf(b1.l, b1.w) / 2.0f, rb = fminf(b2.l, b2.w) / 2.0f;
+    float ha = fmaxf(b1.l, b1.w) / 2.0f - ra, hb = fmaxf(b2.l, b2.w) / 2.0f - rb;
+    float d = __builtin_inff();
+    bool any_nan = false;
+#pragma unroll
+    for (int i = -2; i <= 2; ++i) {
+        float da = ((float)i * ha) / 2.0f;
+        float ax = (da * b1.c - 0.0f * b1.s) + b1.x, ay = (da * b1.s + 0.0f * b1.c) + b1.y;
+#pragma unroll
+        for (int j = -2; j <= 2; ++j) {
+            float db = ((float)j * hb) / 2.0f;
+            float bx = (db * b2.c - 0.0f * b2.s) + b2.x, by = (db * b2.s + 0.0f * b2.c) + b2.y;
+            float ex = ax - bx, ey = ay - by;
+            float dd = sqrtf(__fmaf_rn(ey, ey, ex * ex));    // torch.cdist accumulates with an FMA (probed)
+            any_nan |= (dd != dd);
+            d = fminf(d, dd);
+        }
+    }
+    if (any_nan) d = __builtin_nanf("");
+    float l = 1.0f - d / (ra + rb);
+    return (l != l) ? l : fmaxf(l, 0.0f);
+}
+
+__device__ __forceinline__ Box load_box(const float *boxes, const float *sc, int64_t idx) {
+    Box b;
+    const float *p = boxes + idx * 5;
+    b.x = scrub(p[0]); b.y = scrub(p[1]); b.l = scrub(p[2]); b.w = scrub(p[3]);
+    float psi = p[4];
+    b.s = sc[idx * 2]; b.c = sc[idx * 2 + 1];
+    if (psi != psi) { b.s = 0.0f; b.c = 1.0f; }      // a NaN heading is scrubbed to 0 before sin/cos (simulator.py:1095)
+    return b;
+}
+
+// grid = (B, ceil(A / (4 waves * ROWS_PER_WAVE))), dynamic LDS = 4 * (16*64 + Npad) floats
+template <int METRIC>
+__global__ void __launch_bounds__(CBLOCK) collision_kernel(const float *__restrict__ boxes, const float *__restrict__ sc,
+                                                           const uint8_t *__restrict__ present, float *__restrict__ out,
+                                                           uint64_t *__restrict__ overlap, int32_t *__restrict__ partner, int A, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npad = (N + 63) & ~63;
+    float *scr = smem + wave * (16 * 64 + npad);
+    float *rowbuf = scr + 16 * 64;
+    const int64_t b = blockIdx.x;
+    const int row0 = (blockIdx.y * (CBLOCK / 64) + wave) * ROWS_PER_WAVE;
+    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+        const int i = row0 + r;
+        if (i >= A) break;                                           // wave-uniform
+        Box bi = load_box(boxes, sc, b * N + i);
+        Corners ci = corners_of(bi);
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            int j = j0 + lane;
+            float o = 0.0f;
+            if (j < N) {
+                Box bj = load_box(boxes, sc, b * N + j);
+                if (METRIC == TDS_METRIC_IOU) {
+                    Corners cj = corners_of(bj);
+                    o = iou_pair(bi, ci, bj, cj, scr, lane);
+                } else {
+                    o = discs_pair(bi, bj);
+                }
+                o = scrub(o) * (present[b * N + j] ? 1.0f : 0.0f);   // simulator.py:1103-1104
+            }
+            rowbuf[j] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // sum_j o_ij in index order and max_j (simulator.py:1105-1108); lane 0 carries the result
+        if (lane == 0) {
+            float sum = 0.0f, mx = -__builtin_inff(), best = 0.0f;
+            int arg = -1;
+            uint64_t bits = 0;
+            for (int j = 0; j < N; ++j) {
+                float o = rowbuf[j];
+                sum = sum + o;
+                mx = fmaxf(mx, o);
+                if (j != i && o > 0.0f) {
+                    if (j < 64) bits |= (uint64_t)1 << j;
+                    if (o > best) { best = o; arg = j; }
+                }
+            }
+            out[b * A + i] = sum - mx;
+            if (overlap) overlap[b * A + i] = bits;
+            if (partner) partner[b * A + i] = arg;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(CBLOCK) pairwise_kernel(const float *__restrict__ box1, const float *__restrict__ sc1,
+                                                          const float *__restrict__ box2, const float *__restrict__ sc2,
+                                                          float *__restrict__ out, int64_t n) {
+    __shared__ float smem[(CBLOCK / 64) * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t i = (int64_t)blockIdx.x * CBLOCK + threadIdx.x;
+    if (i >= n) return;
+    // element-wise API: no NaN scrubbing here (iou_differentiable itself does none, infractions.py:307-324)
+    Box a, b;
+    a.x = box1[5 * i]; a.y = box1[5 * i + 1]; a.l = box1[5 * i + 2]; a.w = box1[5 * i + 3]; a.s = sc1[2 * i]; a.c = sc1[2 * i + 1];
+    b.x = box2[5 * i]; b.y = box2[5 * i + 1]; b.l = box2[5 * i + 2]; b.w = box2[5 * i + 3]; b.s = sc2[2 * i]; b.c = sc2[2 * i + 1];
+    float o;
+    if (METRIC == TDS_METRIC_IOU) {
+        Corners ca = corners_of(a), cb = corners_of(b);
+        o = iou_pair(a, ca, b, cb, smem + wave * 16 * 64, lane);
+    } else {
+        o = discs_pair(a, b);
+    }
+    out[i] = o;
+}
+
+__global__ void __launch_bounds__(CBLOCK) box2corners_kernel(const float *__restrict__ box, const float *__restrict__ sc,
+                                                             float *__restrict__ corners, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * CBLOCK + threadIdx.x;
+    if (i >= n) return;
+    Box b;
+    b.x = box[5 * i]; b.y = box[5 * i + 1]; b.l = box[5 * i + 2]; b.w = box[5 * i + 3]; b.s = sc[2 * i]; b.c = sc[2 * i + 1];
+    Corners c = corners_of(b);
+    float4 *o = (float4 *)(corners + 8 * i);
+    o[0] = make_float4(c.x[0], c.y[0], c.x[1], c.y[1]);
+    o[1] = make_float4(c.x[2], c.y[2], c.x[3], c.y[3]);
+}
+
+}  // namespace
+
+TDS_EXPORT int tds_collision_f32(const float *boxes, const float *sc, const uint8_t *present, float *out, uint64_t *overlap,
+                                 int32_t *partner, int64_t B, int64_t A, int64_t N, int metric, void *stream) {
+    TDS_CHECK_ARG(B >= 0 && A >= 0 && N >= A, "tds_collision_f32: bad sizes B=%lld A=%lld N=%lld", (long long)B, (long long)A, (long long)N);
+    TDS_CHECK_ARG(metric == TDS_METRIC_IOU || metric == TDS_METRIC_DISCS, "tds_collision_f32: unknown metric %d", metric);
+    if (B == 0 || A == 0) return TDS_OK;
+    TDS_CHECK_ARG(boxes && sc && present && out, "tds_collision_f32: null pointer");
+    TDS_CHECK_ARG(!overlap || N <= 64, "tds_collision_f32: overlap bit masks need N <= 64 (got %lld)", (long long)N);
+    TDS_CHECK_ARG(N <= 8192 && B < 65536 * 32768ll, "tds_collision_f32: N=%lld too large", (long long)N);
+    const int rows_per_block = (CBLOCK / 64) * ROWS_PER_WAVE;
+    dim3 grid((unsigned)B, (unsigned)((A + rows_per_block - 1) / rows_per_block));
+    size_t lds = (size_t)(CBLOCK / 64) * (16 * 64 + ((N + 63) & ~63)) * sizeof(float);
+    if (metric == TDS_METRIC_IOU)
+        hipLaunchKernelGGL(collision_kernel<TDS_METRIC_IOU>, grid, dim3(CBLOCK), lds, (hipStream_t)stream, boxes, sc, present, out,
+                           overlap, partner, (int)A, (int)N);
+    else
+        hipLaunchKernelGGL(collision_kernel<TDS_METRIC_DISCS>, grid, dim3(CBLOCK), lds, (hipStream_t)stream, boxes, sc, present, out,
+                           overlap, partner, (int)A, (int)N);
+    TDS_LAUNCH_CHECK("collision_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_pairwise_overlap_f32(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out,
+                                        int64_t n, int metric, void *stream) {
+    TDS_CHECK_ARG(n >= 0, "tds_pairwise_overlap_f32: negative n");
+    TDS_CHECK_ARG(metric == TDS_METRIC_IOU || metric == TDS_METRIC_DISCS, "tds_pairwise_overlap_f32: unknown metric %d", metric);
+    if (n == 0) return TDS_OK;
+    TDS_CHECK_ARG(box1 && sc1 && box2 && sc2 && out, "tds_pairwise_overlap_f32: null pointer");
+    dim3 grid((unsigned)((n + CBLOCK - 1) / CBLOCK));
+    if (metric == TDS_METRIC_IOU)
+        hipLaunchKernelGGL(pairwise_kernel<TDS_METRIC_IOU>, grid, dim3(CBLOCK), 0, (hipStream_t)stream, box1, sc1, box2, sc2, out, n);
+    else
+        hipLaunchKernelGGL(pairwise_kernel<TDS_METRIC_DISCS>, grid, dim3(CBLOCK), 0, (hipStream_t)stream, box1, sc1, box2, sc2, out, n);
+    TDS_LAUNCH_CHECK("pairwise_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_box2corners_f32(const float *box, const float *sc, float *corners, int64_t n, void *stream) {
+    TDS_CHECK_ARG(n >= 0, "tds_box2corners_f32: negative n");
+    if (n == 0) return TDS_OK;
+    TDS_CHECK_ARG(box && sc && corners, "tds_box2corners_f32: null pointer");
+    hipLaunchKernelGGL(box2corners_kernel, dim3((unsigned)((n + CBLOCK - 1) / CBLOCK)), dim3(CBLOCK), 0, (hipStream_t)stream, box, sc,
+                       corners, n);
+    TDS_LAUNCH_CHECK("box2corners_kernel");
+    return TDS_OK;
+}

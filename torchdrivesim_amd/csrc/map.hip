@@ -1,0 +1,272 @@
+// Static map handle (triangle soup binned into a uniform grid, built once per map on the host and uploaded) and
+// K2b: offroad = thresholded squared distance from the 4 corners of every agent to the nearest mesh face.
+// Reference: simulator.py:1035-1044; infractions.py:86-229 (pure-torch path), which materialises a
+// (B*A*4, F, 3, 3) tensor; here each corner walks grid rings outwards until the best distance is proven minimal.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "tds_common.h"
+
+using tds::GridEntry;
+using tds::MapView;
+
+// ------------------------------------------------------------------------------------------------------------
+// host: build + upload
+// ------------------------------------------------------------------------------------------------------------
+TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
+                              int64_t F, const float *levels, int n_levels, float cell_size, tds_map_t **out) {
+    TDS_CHECK_ARG(out, "tds_map_create: out is null");
+    *out = nullptr;
+    TDS_CHECK_ARG(V >= 0 && F >= 0, "tds_map_create: negative size");
+    TDS_CHECK_ARG((V == 0 || verts) && (F == 0 || faces), "tds_map_create: null mesh arrays");
+    TDS_CHECK_ARG(F < (1 << 24), "tds_map_create: more than 2^24 faces");
+    TDS_CHECK_ARG((face_z == nullptr) == (face_rgb == nullptr), "tds_map_create: face_z and face_rgb go together");
+    if (face_z) {
+        TDS_CHECK_ARG(levels && n_levels > 0, "tds_map_create: rendering data needs a level table");
+        if (n_levels > 255) { tds::set_error("tds_map_create: %d rendering levels (max 255)", n_levels); return TDS_ELIMIT; }
+        for (int i = 1; i < n_levels; ++i)
+            TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_map_create: levels must be strictly descending");
+    }
+    for (int64_t i = 0; i < 3 * F; ++i) TDS_CHECK_ARG(faces[i] >= 0 && faces[i] < V, "tds_map_create: face index %d out of range", faces[i]);
+
+    float cell = cell_size > 0 ? cell_size : 8.0f;
+    float minx = 0, miny = 0, maxx = 0, maxy = 0;
+    bool any = false;
+    for (int64_t f = 0; f < F; ++f)
+        for (int k = 0; k < 3; ++k) {
+            float x = verts[2 * faces[3 * f + k]], y = verts[2 * faces[3 * f + k] + 1];
+            if (!std::isfinite(x) || !std::isfinite(y)) continue;
+            if (!any) { minx = maxx = x; miny = maxy = y; any = true; }
+            minx = std::min(minx, x); maxx = std::max(maxx, x); miny = std::min(miny, y); maxy = std::max(maxy, y);
+        }
+    std::vector<int32_t> cell_start;
+    std::vector<GridEntry> entries;
+    int nx = 0, ny = 0;
+    float ox = minx, oy = miny, inv = 1.0f / cell;
+    for (int attempt = 0; attempt < 24 && any; ++attempt) {
+        inv = 1.0f / cell;
+        nx = tds::cell_coord(maxx, ox, inv) + 1;
+        ny = tds::cell_coord(maxy, oy, inv) + 1;
+        bool too_big = nx > 32767 || ny > 32767 || (int64_t)nx * ny > (int64_t)(1 << 26);
+        int64_t total = 0;
+        if (!too_big) {
+            cell_start.assign((size_t)nx * ny + 1, 0);
+            for (int64_t f = 0; f < F && !too_big; ++f) {
+                float fx0 = INFINITY, fy0 = INFINITY, fx1 = -INFINITY, fy1 = -INFINITY;
+                bool ok = true;
+                for (int k = 0; k < 3; ++k) {
+                    float x = verts[2 * faces[3 * f + k]], y = verts[2 * faces[3 * f + k] + 1];
+                    ok &= std::isfinite(x) && std::isfinite(y);
+                    fx0 = std::min(fx0, x); fx1 = std::max(fx1, x); fy0 = std::min(fy0, y); fy1 = std::max(fy1, y);
+                }
+                if (!ok) continue;       // faces with non-finite vertices are never binned (never drawn, never nearest)
+                int cx0 = tds::cell_coord(fx0, ox, inv), cx1 = tds::cell_coord(fx1, ox, inv);
+                int cy0 = tds::cell_coord(fy0, oy, inv), cy1 = tds::cell_coord(fy1, oy, inv);
+                total += (int64_t)(cx1 - cx0 + 1) * (cy1 - cy0 + 1);
+                if (total > 24 * F + (1 << 20)) { too_big = true; break; }
+                for (int cy = cy0; cy <= cy1; ++cy)
+                    for (int cx = cx0; cx <= cx1; ++cx) cell_start[(size_t)cy * nx + cx + 1]++;
+            }
+        }
+        if (too_big) { cell *= 2.0f; continue; }
+        for (size_t i = 1; i < cell_start.size(); ++i) cell_start[i] += cell_start[i - 1];
+        entries.resize((size_t)total);
+        std::vector<int32_t> cursor(cell_start.begin(), cell_start.end() - 1);
+        for (int64_t f = 0; f < F; ++f) {
+            GridEntry e;
+            const float *p0 = verts + 2 * faces[3 * f], *p1 = verts + 2 * faces[3 * f + 1], *p2 = verts + 2 * faces[3 * f + 2];
+            e.x0 = p0[0]; e.y0 = p0[1]; e.x1 = p1[0]; e.y1 = p1[1]; e.x2 = p2[0]; e.y2 = p2[1];
+            if (!(std::isfinite(e.x0) && std::isfinite(e.y0) && std::isfinite(e.x1) && std::isfinite(e.y1) && std::isfinite(e.x2) &&
+                  std::isfinite(e.y2)))
+                continue;
+            e.key = 0;
+            if (face_z) {
+                int rank = -1;
+                for (int l = 0; l < n_levels; ++l)
+                    if (levels[l] == face_z[f]) { rank = l + 1; break; }
+                TDS_CHECK_ARG(rank > 0, "tds_map_create: face %lld has level %g which is not in the level table", (long long)f, face_z[f]);
+                e.key = ((uint32_t)rank << 24) | (face_rgb[f] & 0xFFFFFFu);
+            }
+            float fx0 = std::min(e.x0, std::min(e.x1, e.x2)), fx1 = std::max(e.x0, std::max(e.x1, e.x2));
+            float fy0 = std::min(e.y0, std::min(e.y1, e.y2)), fy1 = std::max(e.y0, std::max(e.y1, e.y2));
+            int cx0 = tds::cell_coord(fx0, ox, inv), cx1 = tds::cell_coord(fx1, ox, inv);
+            int cy0 = tds::cell_coord(fy0, oy, inv), cy1 = tds::cell_coord(fy1, oy, inv);
+            for (int cy = cy0; cy <= cy1; ++cy)
+                for (int cx = cx0; cx <= cx1; ++cx) {
+                    e.ddx = (uint16_t)(cx - cx0); e.ddy = (uint16_t)(cy - cy0);
+                    entries[(size_t)cursor[(size_t)cy * nx + cx]++] = e;
+                }
+        }
+        break;
+    }
+    if (!any) { nx = ny = 0; cell_start.assign(1, 0); entries.clear(); }
+
+    tds_map *m = new (std::nothrow) tds_map();
+    if (!m) { tds::set_error("tds_map_create: out of host memory"); return TDS_ENOMEM; }
+    m->V = V; m->F = F; m->n_entries = (int64_t)entries.size(); m->n_levels = face_z ? n_levels : 0;
+    m->d_entries = nullptr; m->d_cell_start = nullptr;
+    hipError_t e = hipGetDevice(&m->device);
+    size_t be = std::max<size_t>(entries.size(), 1) * sizeof(GridEntry), bc = cell_start.size() * sizeof(int32_t);
+    if (e == hipSuccess) e = hipMalloc(&m->d_entries, be);
+    if (e == hipSuccess) e = hipMalloc(&m->d_cell_start, bc);
+    if (e == hipSuccess && !entries.empty()) e = hipMemcpy(m->d_entries, entries.data(), entries.size() * sizeof(GridEntry), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_cell_start, cell_start.data(), bc, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        tds::set_error("tds_map_create: %s", hipGetErrorString(e));
+        if (m->d_entries) (void)hipFree(m->d_entries);
+        if (m->d_cell_start) (void)hipFree(m->d_cell_start);
+        delete m;
+        return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
+    }
+    m->bytes = (int64_t)(be + bc);
+    m->view.entries = (const GridEntry *)m->d_entries;
+    m->view.cell_start = (const int32_t *)m->d_cell_start;
+    m->view.ox = ox; m->view.oy = oy; m->view.inv_cell = inv; m->view.cell = cell;
+    m->view.nx = nx; m->view.ny = ny; m->view.n_faces = F;
+    *out = m;
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_map_destroy(tds_map_t *map) {
+    if (!map) return TDS_OK;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != map->device) (void)hipSetDevice(map->device);
+    hipError_t e1 = hipFree(map->d_entries), e2 = hipFree(map->d_cell_start);
+    if (cur != map->device) (void)hipSetDevice(cur);
+    delete map;
+    if (e1 != hipSuccess || e2 != hipSuccess) { tds::set_error("tds_map_destroy: hipFree failed"); return TDS_EHIP; }
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_map_info(const tds_map_t *map, int64_t *info) {
+    TDS_CHECK_ARG(map && info, "tds_map_info: null pointer");
+    info[0] = map->V; info[1] = map->F; info[2] = map->view.nx; info[3] = map->view.ny;
+    info[4] = map->n_entries; info[5] = map->bytes; info[6] = map->n_levels; info[7] = 0;
+    return TDS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: offroad
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int OBLOCK = 256;
+
+__device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return (ax * bx + ay * by) + 0.0f; }
+
+// point_line_distance, infractions.py:147-159 (squared)
+__device__ __forceinline__ float seg_d2(float px, float py, float ax, float ay, float bx, float by) {
+    float ex = bx - ax, ey = by - ay;
+    float l2 = dot2(ex, ey, ex, ey);
+    float t = dot2(ex, ey, px - ax, py - ay) / (l2 + (float)1e-8);
+    float tt = fminf(fmaxf(t, 0.0f), 1.0f);
+    tt = (t != t) ? t : tt;                                  // torch.clamp propagates NaN
+    float qx = ax + tt * ex, qy = ay + tt * ey;
+    float d = dot2(px - qx, py - qy, px - qx, py - qy);
+    if (l2 <= (float)1e-8) d = dot2(px - bx, py - by, px - bx, py - by);
+    return d;
+}
+
+// point_to_mesh_distance_pt for one (point, triangle) in the z = 0 plane, infractions.py:100-170
+__device__ __forceinline__ float tri_d2(float px, float py, const GridEntry &e) {
+    float cz = (e.x2 - e.x0) * (e.y1 - e.y0) - (e.y2 - e.y0) * (e.x1 - e.x0);
+    float norm_normal = sqrtf(cz * cz);
+    float p0x = e.x1 - e.x0, p0y = e.y1 - e.y0, p1x = e.x2 - e.x0, p1y = e.y2 - e.y0;
+    float p2x = px - e.x0, p2y = py - e.y0;
+    float d00 = dot2(p0x, p0y, p0x, p0y), d01 = dot2(p0x, p0y, p1x, p1y), d11 = dot2(p1x, p1y, p1x, p1y);
+    float d20 = dot2(p2x, p2y, p0x, p0y), d21 = dot2(p2x, p2y, p1x, p1y);
+    float denom = d00 * d11 - d01 * d01 + (float)1e-8;
+    float w1 = (d11 * d20 - d01 * d21) / denom;
+    float w2 = (d00 * d21 - d01 * d20) / denom;
+    float w0 = 1.0f - w1 - w2;
+    bool inside = (0.0f <= w0) && (w0 <= 1.0f) && (0.0f <= w1) && (w1 <= 1.0f) && (0.0f <= w2) && (w2 <= 1.0f);
+    float area = fabsf(p0x * p1y - p0y * p1x) / 2.0f;
+    inside = inside && !(area < (float)5e-3) && (norm_normal > (float)1e-8);
+    float e01 = seg_d2(px, py, e.x0, e.y0, e.x1, e.y1);
+    float e02 = seg_d2(px, py, e.x0, e.y0, e.x2, e.y2);
+    float e12 = seg_d2(px, py, e.x1, e.y1, e.x2, e.y2);
+    float dist = fminf(fminf(e01, e02), e12);
+    return inside ? 0.0f : dist;
+}
+
+__device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, float py) {
+    float best = __builtin_inff();
+    if (m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return best;
+    // unclamped cell of the point (float -> int conversion saturates, keep it in a sane range first)
+    float fx = fminf(fmaxf((px - m.ox) * m.inv_cell, -1.0e6f), 1.0e6f), fy = fminf(fmaxf((py - m.oy) * m.inv_cell, -1.0e6f), 1.0e6f);
+    int cx = (int)floorf(fx), cy = (int)floorf(fy);
+    int k = max(max(0, max(-cx, cx - (m.nx - 1))), max(-cy, cy - (m.ny - 1)));
+    auto visit = [&](int x, int y) {
+        int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
+        for (int i = s; i < e; ++i) {
+            GridEntry ge = m.entries[i];
+            float d = tri_d2(px, py, ge);
+            best = (d < best) ? d : best;
+        }
+    };
+    for (;; ++k) {
+        // cells at Chebyshev distance exactly k from (cx, cy), clipped to the grid
+        int y0 = max(cy - k, 0), y1 = min(cy + k, m.ny - 1);
+        int x0 = max(cx - k, 0), x1 = min(cx + k, m.nx - 1);
+        for (int y = y0; y <= y1; ++y) {
+            if (y == cy - k || y == cy + k) {
+                for (int x = x0; x <= x1; ++x) visit(x, y);
+            } else {
+                if (cx - k >= 0 && cx - k < m.nx) visit(cx - k, y);
+                if (k > 0 && cx + k >= 0 && cx + k < m.nx) visit(cx + k, y);
+            }
+        }
+        if (best == 0.0f) break;
+        float bound = (float)k * m.cell * 0.999f;            // everything unvisited is at least this far away
+        if (best <= bound * bound) break;
+        if (cx - k <= 0 && cx + k >= m.nx - 1 && cy - k <= 0 && cy + k >= m.ny - 1) break;
+    }
+    return best;
+}
+
+// one thread per agent corner (4 consecutive lanes = one agent)
+__global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
+                                                         const float2 *__restrict__ sc, const uint8_t *__restrict__ present,
+                                                         float *__restrict__ out, int64_t n, float threshold) {
+    int64_t t = (int64_t)blockIdx.x * OBLOCK + threadIdx.x;
+    int64_t a = t >> 2;
+    int k = (int)(t & 3);
+    float v = 0.0f;
+    if (a < n && m.n_faces > 0) {
+        float4 s = state[a];
+        float2 lw = lenwid[a];
+        float2 scv = sc[a];
+        const float sx = (k == 0 || k == 3) ? 0.5f : -0.5f, sy = (k < 2) ? 0.5f : -0.5f;     // box2corners_th :285-288
+        float x4 = sx * lw.x, y4 = sy * lw.y;
+        float px = (x4 * scv.y + y4 * (-scv.x)) + s.x;
+        float py = (x4 * scv.x + y4 * scv.y) + s.y;
+        float d = nearest_face_d2(m, px, py);
+        d = (d != d) ? 0.0f : d;                                     // nan_to_num :171
+        if (__builtin_isinf(d)) d = 3.4028234663852886e38f;
+        v = (d > threshold) ? d : 0.0f;                              // F.threshold(d, thr, 0) :172
+    }
+    // sum of the 4 corners in order (infractions.py:228)
+    float v1 = __shfl_down(v, 1), v2 = __shfl_down(v, 2), v3 = __shfl_down(v, 3);
+    if (a < n && k == 0) {
+        float tot = ((v + v1) + v2) + v3;
+        if (present) tot = tot * (present[a] ? 1.0f : 0.0f);         // simulator.py:1044
+        out[a] = tot;
+    }
+}
+
+}  // namespace
+
+TDS_EXPORT int tds_offroad_f32(const tds_map_t *map, const float *state, const float *lenwid, const float *sc, const uint8_t *present,
+                               float *out, int64_t n_agents, float threshold, void *stream) {
+    TDS_CHECK_ARG(map, "tds_offroad_f32: null map");
+    TDS_CHECK_ARG(n_agents >= 0 && n_agents < ((int64_t)1 << 36), "tds_offroad_f32: bad agent count");
+    if (n_agents == 0) return TDS_OK;
+    TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_f32: null pointer");
+    int64_t threads = n_agents * 4;
+    hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, map->view,
+                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold);
+    TDS_LAUNCH_CHECK("offroad_kernel");
+    return TDS_OK;
+}

@@ -1,0 +1,728 @@
+// K3: bird's-eye-view rasteriser with the reference's CV2 semantics.
+// Reference dataflow being replaced: simulator.py:920-1033 -> BirdviewRGBMeshGenerator.generate (mesh.py:1053-1157,
+// which concatenates the WHOLE static map per camera) -> BirdviewRenderer.render_frame (rendering/base.py:167-204) ->
+// CV2Renderer.render_rgb_mesh (rendering/cv2.py:27-70: shift, trim, z-sort, project + int truncation, cv2.fillConvexPoly).
+//
+// Design (gfx950): one 256-thread workgroup owns a strip of TW image rows-of-the-output (OpenCV x range) of one camera.
+// The strip lives in LDS as one packed u32 per pixel: key = rank << 24 | 0x00RRGGBB, where rank orders rendering
+// levels (painter order: lower level drawn later = larger rank).  Painting = ds_max_u32, so the result is independent
+// of the order in which faces are processed.  Candidate faces come from the map's uniform grid (only the cells under
+// the strip are scanned), pass the reference's trim test, are projected with the reference's fp32 operation order and
+// truncated to int; survivors are compacted into a per-wave LDS queue and rasterised 64 at a time with the work split
+// per (face,row) and per (face,outline edge) across the wave.  The fill reproduces OpenCV's FillConvexPoly + 8-connected
+// Line + clipLine in closed form (16.16 fixed-point edge stepping; see oracle/tds_oracle.c for the restatement).
+// Finally the strip is converted and streamed to HBM as a flat, fully coalesced copy (the LDS layout [x][y] IS the
+// output layout out[img][ch][x][y]).  Roofline: HBM write, 3*H*W*4 B per camera (fp32) -- DESIGN.md.
+#include "tds_common.h"
+
+using tds::GridEntry;
+using tds::MapView;
+
+namespace {
+
+constexpr int RWAVES = 4;
+constexpr int RBLOCK = RWAVES * 64;
+constexpr int QCAP = 128;                         // per-wave face queue (entries)
+constexpr int Q_DW = 7 * QCAP;                    // key + 6 pixel coordinates
+constexpr int NPAR = 17;                          // scan-conversion record, dwords per face
+constexpr int WAVE_LDS_DW = Q_DW + NPAR * 64 + 64;   // + inclusive prefix of rows
+constexpr int NO_SWITCH = 0x7fffffff;
+
+struct SceneArgs {
+    MapView map;
+    const float4 *state;        // B x N
+    const float2 *agent_sc;     // B x N   [sin, cos]
+    const float2 *tmpl;         // B x N x 7
+    const uint32_t *actor_key;  // B x N x 2
+    const uint8_t *mask;        // B x Nc x N
+    int N, Nc;
+};
+
+struct MeshArgs {
+    const float *verts;         // n_img x V x 3
+    const float *attrs;         // n_img x V x 3
+    const int32_t *faces;       // n_img x F x 3
+    int64_t V, F;
+    float levels[64];           // descending
+    int n_levels;
+};
+
+struct CommonArgs {
+    const float2 *cam_xy, *cam_sc;
+    float scale;
+    int res;                    // H == W
+    int strips;
+    int64_t n_img;
+    void *out;
+};
+
+struct Camera {
+    float cx, cy, s, c;
+    float px[4], py[4];         // trim polygon (1.05 x view square) in camera-shifted coordinates
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// geometry helpers, fp32 with the reference's operation order
+// ---------------------------------------------------------------------------------------------------------
+
+// Cameras.reverse_transform_points_screen of the image corners + 1.05 margin (cv2.py:32-40, base.py:117-130)
+__device__ inline void make_polygon(Camera &cam, float scale, int res) {
+    const float cor[4][2] = {{0.f, 0.f}, {0.f, (float)res}, {(float)res, (float)res}, {(float)res, 0.f}};
+    float mn = (float)res / 2.0f;
+    float sumx = 0.0f, sumy = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = cor[k][0] - (float)res / 2.0f, y = cor[k][1] - (float)res / 2.0f;
+        x = x / mn; y = y / mn;
+        x = (-x) / scale; y = (-y) / scale;
+        float rx = cam.c * x + (-cam.s) * y;      // rot_mat^T = [[c,-s],[s,c]]
+        float ry = cam.s * x + cam.c * y;
+        cam.px[k] = rx + 0.0f; cam.py[k] = ry + 0.0f;
+        sumx = sumx + cam.px[k]; sumy = sumy + cam.py[k];
+    }
+    float mx = sumx / 4.0f, my = sumy / 4.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cam.px[k] = mx + (cam.px[k] - mx) * 1.05f;
+        cam.py[k] = my + (cam.py[k] - my) * 1.05f;
+    }
+}
+
+// utils.is_inside_polygon :99-122
+__device__ inline bool inside_polygon(const Camera &cam, float x, float y) {
+    bool all_right = true, all_left = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x0 = cam.px[k], y0 = cam.py[k], x1 = cam.px[(k + 1) & 3], y1 = cam.py[(k + 1) & 3];
+        float a = y1 - y0, b = x0 - x1;
+        float c = (-a) * x0 - b * y0;
+        bool right = ((a * x + b * y) + c) >= 0.0f;
+        all_right = all_right && right;
+        all_left = all_left && !right;
+    }
+    return all_right || all_left;
+}
+
+// Cameras.transform_points_screen (base.py:102-115) on camera-shifted coordinates, then .to(int32) (cv2.py:48)
+__device__ inline void project(const Camera &cam, float scale, int res, float vx, float vy, int &ox, int &oy) {
+    float x = vx - 0.0f, y = vy - 0.0f;
+    float rx = cam.c * x + cam.s * y;
+    float ry = (-cam.s) * x + cam.c * y;
+    rx = (-rx) * scale; ry = (-ry) * scale;
+    rx = (rx * (float)res) / 2.0f; ry = (ry * (float)res) / 2.0f;
+    rx = rx + (float)res / 2.0f; ry = ry + (float)res / 2.0f;
+    ox = (int)rx; oy = (int)ry;
+}
+
+// truncating division n / d for d > 0, |n| < 2^52: the correctly rounded double quotient can only hit an integer
+// when the exact quotient is one, so (long)(double) is exact; one correction step guards the claim.
+__device__ inline long long div_trunc(long long n, long long d) {
+    long long q = (long long)((double)n / (double)d);
+    long long r = n - q * d;
+    if (n >= 0) { if (r < 0) --q; else if (r >= d) ++q; }
+    else { if (r > 0) ++q; else if (r <= -d) --q; }
+    return q;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// OpenCV FillConvexPoly (shift 0, 8-connected) for a triangle, in closed form per row
+// ---------------------------------------------------------------------------------------------------------
+struct Chain { int xs1; long long dx1; int ysw; int xs2; long long dx2; };
+
+__device__ inline long long edge_dx(int xs, int xe, int dyy) {
+    long long D = ((long long)(xe - xs) << 17) + dyy;          // ((xe-xs)*2 + (ty-y)) with x in 16.16
+    return div_trunc(D, 2ll * dyy);
+}
+
+// chain visiting a0 -> a1 -> a2 (a0 = first top vertex)
+__device__ inline Chain make_chain(const int *px, const int *py, int a0, int a1, int a2) {
+    Chain c;
+    int ymin = py[a0];
+    c.ysw = NO_SWITCH; c.xs2 = 0; c.dx2 = 0;
+    if (py[a1] > ymin) {
+        c.xs1 = px[a0];
+        c.dx1 = edge_dx(px[a0], px[a1], py[a1] - ymin);
+        if (py[a2] > py[a1]) {
+            c.ysw = py[a1];
+            c.xs2 = px[a1];
+            c.dx2 = edge_dx(px[a1], px[a2], py[a2] - py[a1]);
+        }
+    } else {
+        int dyy = py[a2] - ymin;
+        c.xs1 = px[a1];
+        c.dx1 = dyy > 0 ? edge_dx(px[a1], px[a2], dyy) : 0;
+    }
+    return c;
+}
+
+__device__ inline long long chain_x(int xs1, long long dx1, int ysw, int xs2, long long dx2, int ymin, int y) {
+    bool second = y >= ysw;
+    long long x0 = (long long)(second ? xs2 : xs1) << 16;
+    long long dx = second ? dx2 : dx1;
+    int y0 = second ? ysw : ymin;
+    return x0 + (long long)(y - y0) * dx;
+}
+
+// cv::clipLine on int64 (drawing.cpp); returns false if nothing is left
+__device__ inline bool clip_line(int W, int H, long long &x1, long long &y1, long long &x2, long long &y2) {
+    long long right = W - 1, bottom = H - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+// cv::Line, 8-connected, leftToRight; paints the pixels that fall into the strip [X0, X0+TW)
+template <int TW>
+__device__ inline void draw_line(uint32_t *tile, int H, int W, int X0, int ax, int ay, int bx, int by, uint32_t key) {
+    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+    if ((unsigned long long)x1 >= (unsigned long long)W || (unsigned long long)x2 >= (unsigned long long)W ||
+        (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
+        if (!clip_line(W, H, x1, y1, x2, y2)) return;
+    }
+    int lo = (int)(x1 < x2 ? x1 : x2), hi = (int)(x1 < x2 ? x2 : x1);
+    if (hi < X0 || lo >= X0 + TW) return;
+    int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+    int px = (int)x1, py = (int)y1;
+    int step_y = 1;
+    if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }
+    if (dy < 0) { dy = -dy; step_y = -1; }
+    bool vert = dy > dx;
+    if (vert) { int t = dx; dx = dy; dy = t; }
+    int err = dx - (dy + dy), plus_delta = dx + dx, minus_delta = -(dy + dy);
+    int count = dx + 1;
+    for (int i = 0; i < count; ++i) {
+        unsigned lx = (unsigned)(px - X0);
+        if (lx < (unsigned)TW) atomicMax(&tile[lx * H + py], key);
+        bool neg = err < 0;
+        err += minus_delta + (neg ? plus_delta : 0);
+        if (vert) { py += step_y; px += neg ? 1 : 0; }
+        else { px += 1; py += neg ? step_y : 0; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-wave face queue and batch rasterisation
+// ---------------------------------------------------------------------------------------------------------
+struct WaveCtx {
+    uint32_t *tile;
+    uint32_t *q;        // [7][QCAP]
+    int *par;           // [NPAR][64]
+    int *pref;          // [64]
+    int qlen;           // wave-uniform
+    int lane;
+    int H, W, X0;
+};
+
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int TW>
+__device__ void process_batch(WaveCtx &w, int n) {
+    const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0;
+    wave_sync();
+    int nrows = 0;
+    if (lane < n) {
+        uint32_t key = w.q[lane];
+        int px[3], py[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { px[k] = (int)w.q[(1 + 2 * k) * QCAP + lane]; py[k] = (int)w.q[(2 + 2 * k) * QCAP + lane]; }
+        int ymin = py[0], ymax = py[0], xmin = px[0], xmax = px[0], imin = 0;
+#pragma unroll
+        for (int k = 1; k < 3; ++k) {
+            if (py[k] < ymin) { ymin = py[k]; imin = k; }
+            ymax = max(ymax, py[k]); xmin = min(xmin, px[k]); xmax = max(xmax, px[k]);
+        }
+        int ystart = max(ymin, 0), yend = min(ymax - 1, H - 1);
+        bool scan = !(xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) && (xmax >= X0) && (xmin < X0 + TW);
+        nrows = scan ? max(0, yend - ystart + 1) : 0;
+        if (nrows > 0) {
+            int i1 = imin == 2 ? 0 : imin + 1, i2 = imin == 0 ? 2 : imin - 1;
+            Chain a = make_chain(px, py, imin, i1, i2);
+            Chain b = make_chain(px, py, imin, i2, i1);
+            int *p = w.par + lane;
+            p[0 * 64] = (int)key; p[1 * 64] = ymin; p[2 * 64] = ystart;
+            p[3 * 64] = a.xs1; p[4 * 64] = (int)(a.dx1 & 0xffffffffll); p[5 * 64] = (int)(a.dx1 >> 32);
+            p[6 * 64] = a.ysw; p[7 * 64] = a.xs2; p[8 * 64] = (int)(a.dx2 & 0xffffffffll); p[9 * 64] = (int)(a.dx2 >> 32);
+            p[10 * 64] = b.xs1; p[11 * 64] = (int)(b.dx1 & 0xffffffffll); p[12 * 64] = (int)(b.dx1 >> 32);
+            p[13 * 64] = b.ysw; p[14 * 64] = b.xs2; p[15 * 64] = (int)(b.dx2 & 0xffffffffll); p[16 * 64] = (int)(b.dx2 >> 32);
+        }
+    }
+    // inclusive prefix of row counts across the wave
+    int incl = nrows;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    w.pref[lane] = incl;
+    int total = __shfl(incl, 63);
+    wave_sync();
+    // (face, row) items
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        int t = t0 + lane;
+        if (t < total) {
+            int lo = 0, hi = 63;                       // smallest f with pref[f] > t
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                int mid = (lo + hi) >> 1;
+                bool go = w.pref[mid] > t;
+                hi = go ? mid : hi;
+                lo = go ? lo : mid + 1;
+            }
+            int f = lo;
+            int excl = f > 0 ? w.pref[f - 1] : 0;
+            const int *p = w.par + f;
+            uint32_t key = (uint32_t)p[0 * 64];
+            int ymin = p[1 * 64];
+            int y = p[2 * 64] + (t - excl);
+            auto ll = [](int lo32, int hi32) { return (long long)(((unsigned long long)(unsigned)hi32 << 32) | (unsigned)lo32); };
+            long long xa = chain_x(p[3 * 64], ll(p[4 * 64], p[5 * 64]), p[6 * 64], p[7 * 64], ll(p[8 * 64], p[9 * 64]), ymin, y);
+            long long xb = chain_x(p[10 * 64], ll(p[11 * 64], p[12 * 64]), p[13 * 64], p[14 * 64], ll(p[15 * 64], p[16 * 64]), ymin, y);
+            long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+            long long xx1 = (xl + 32768) >> 16, xx2 = (xr + 32768) >> 16;
+            if (xx2 >= 0 && xx1 < W) {
+                int s0 = (int)(xx1 < 0 ? 0 : xx1), s1 = (int)(xx2 >= W ? W - 1 : xx2);
+                s0 = max(s0, X0); s1 = min(s1, X0 + TW - 1);
+                uint32_t *row = w.tile + y;
+                for (int x = s0; x <= s1; ++x) atomicMax(&row[(x - X0) * H], key);
+            }
+        }
+    }
+    // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2) before the scan conversion
+    for (int t0 = 0; t0 < 3 * n; t0 += 64) {
+        int t = t0 + lane;
+        if (t < 3 * n) {
+            int f = t / 3, l = t - 3 * f;
+            int ia = l == 0 ? 2 : l - 1, ib = l;
+            uint32_t key = w.q[f];
+            int ax = (int)w.q[(1 + 2 * ia) * QCAP + f], ay = (int)w.q[(2 + 2 * ia) * QCAP + f];
+            int bx = (int)w.q[(1 + 2 * ib) * QCAP + f], by = (int)w.q[(2 + 2 * ib) * QCAP + f];
+            draw_line<TW>(w.tile, H, W, X0, ax, ay, bx, by, key);
+        }
+    }
+    wave_sync();
+    // move the tail of the queue to the front
+    int rest = w.qlen - n;
+    uint32_t tmp[7];
+    if (lane < rest) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tmp[k] = w.q[k * QCAP + n + lane];
+    }
+    wave_sync();
+    if (lane < rest) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) w.q[k * QCAP + lane] = tmp[k];
+    }
+    w.qlen = rest;
+}
+
+// wave-collective append of the faces flagged `accept`
+template <int TW>
+__device__ inline void enqueue(WaveCtx &w, bool accept, uint32_t key, const int *px, const int *py) {
+    unsigned long long bal = __ballot(accept);
+    int cnt = __popcll(bal);
+    if (cnt == 0) return;
+    if (accept) {
+        int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+        int slot = w.qlen + rank;
+        w.q[slot] = key;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { w.q[(1 + 2 * k) * QCAP + slot] = (uint32_t)px[k]; w.q[(2 + 2 * k) * QCAP + slot] = (uint32_t)py[k]; }
+    }
+    w.qlen += cnt;
+    if (w.qlen >= 64) process_batch<TW>(w, 64);
+}
+
+// trim (>= 1 vertex inside the 1.05x view), project, reject faces whose pixel bounding box misses the strip
+__device__ inline bool trim_project(const Camera &cam, float scale, int res, int X0, int TW, const float *sx, const float *sy,
+                                    int *px, int *py) {
+    bool any = inside_polygon(cam, sx[0], sy[0]) || inside_polygon(cam, sx[1], sy[1]) || inside_polygon(cam, sx[2], sy[2]);
+    if (!any) return false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) project(cam, scale, res, sx[k], sy[k], px[k], py[k]);
+    int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
+    int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
+    return !(xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res);
+}
+
+template <int TW, typename OutT>
+__device__ inline void write_out(const uint32_t *tile, OutT *out, int64_t img, int res, int X0, int tid) {
+    const int H = res, W = res;
+    const int tw = min(TW, W - X0);
+    const int n = tw * H;
+    const int64_t plane = (int64_t)W * H;
+    OutT *o = out + img * 3 * plane + (int64_t)X0 * H;
+    if constexpr (sizeof(OutT) == 4) {
+        if ((H & 3) == 0) {
+            for (int i = tid * 4; i < n; i += RBLOCK * 4) {
+                uint4 k = *(const uint4 *)(tile + i);
+                float4 r = make_float4((float)((k.x >> 16) & 255), (float)((k.y >> 16) & 255), (float)((k.z >> 16) & 255), (float)((k.w >> 16) & 255));
+                float4 g = make_float4((float)((k.x >> 8) & 255), (float)((k.y >> 8) & 255), (float)((k.z >> 8) & 255), (float)((k.w >> 8) & 255));
+                float4 b = make_float4((float)(k.x & 255), (float)(k.y & 255), (float)(k.z & 255), (float)(k.w & 255));
+                *(float4 *)(o + i) = r;
+                *(float4 *)(o + plane + i) = g;
+                *(float4 *)(o + 2 * plane + i) = b;
+            }
+            return;
+        }
+    } else {
+        if ((H & 15) == 0) {
+            for (int i = tid * 16; i < n; i += RBLOCK * 16) {
+                uint32_t r[4], g[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint4 k = *(const uint4 *)(tile + i + 4 * q);
+                    r[q] = ((k.x >> 16) & 255) | (((k.y >> 16) & 255) << 8) | (((k.z >> 16) & 255) << 16) | (((k.w >> 16) & 255) << 24);
+                    g[q] = ((k.x >> 8) & 255) | (((k.y >> 8) & 255) << 8) | (((k.z >> 8) & 255) << 16) | (((k.w >> 8) & 255) << 24);
+                    b[q] = (k.x & 255) | ((k.y & 255) << 8) | ((k.z & 255) << 16) | ((k.w & 255) << 24);
+                }
+                *(uint4 *)(o + i) = make_uint4(r[0], r[1], r[2], r[3]);
+                *(uint4 *)(o + plane + i) = make_uint4(g[0], g[1], g[2], g[3]);
+                *(uint4 *)(o + 2 * plane + i) = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            return;
+        }
+    }
+    for (int i = tid; i < n; i += RBLOCK) {
+        uint32_t k = tile[i];
+        o[i] = (OutT)((k >> 16) & 255);
+        o[plane + i] = (OutT)((k >> 8) & 255);
+        o[2 * plane + i] = (OutT)(k & 255);
+    }
+}
+
+__device__ inline void block_to_image(int64_t nblk, int strips, int64_t &img, int &strip) {
+    // blocks are dealt round-robin to the 8 XCDs; give consecutive logical ids to the same XCD so that the strips of
+    // one camera (and neighbouring cameras of a scene) share an L2
+    int64_t b = blockIdx.x, L = b;
+    if ((nblk & 7) == 0) L = (b & 7) * (nblk >> 3) + (b >> 3);
+    img = L / strips;
+    strip = (int)(L - img * strips);
+}
+
+template <int TW, typename OutT>
+__global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, CommonArgs c) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int res = c.res, H = res, W = res;
+    int64_t img;
+    int strip;
+    block_to_image(c.n_img * c.strips, c.strips, img, strip);
+    const int X0 = strip * TW;
+    uint32_t *tile = smem;
+    for (int i = tid * 4; i < TW * H; i += RBLOCK * 4) *(uint4 *)(tile + i) = make_uint4(0, 0, 0, 0);
+
+    WaveCtx w;
+    w.tile = tile;
+    w.q = smem + TW * H + wave * WAVE_LDS_DW;
+    w.par = (int *)(w.q + Q_DW);
+    w.pref = w.par + NPAR * 64;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0;
+
+    Camera cam;
+    {
+        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
+        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
+        make_polygon(cam, c.scale, res);
+    }
+    __syncthreads();
+
+    const int64_t b = img / a.Nc;
+    // ---- actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction)
+    if (a.N > 0) {
+        // vertex 0 of agent 0: every face of a masked agent collapses onto it (mesh.py:1083-1089 + concat offsets)
+        float p0x, p0y;
+        {
+            float4 s0 = a.state[b * a.N];
+            float2 sc0 = a.agent_sc[b * a.N];
+            float2 t0 = a.tmpl[b * a.N * 7];
+            float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
+            p0x = wx + (-cam.cx); p0y = wy + (-cam.cy);
+        }
+        for (int a0 = wave * 64; a0 < a.N; a0 += RBLOCK) {
+            int ag = a0 + lane;
+            bool live = ag < a.N;
+            float sx[7], sy[7];
+            bool on = false;
+            uint32_t kbody = 0, kdir = 0;
+            if (live) {
+                int64_t ia = b * a.N + ag;
+                float4 s = a.state[ia];
+                float2 sc = a.agent_sc[ia];
+                on = a.mask[img * a.N + ag] != 0;
+                kbody = a.actor_key[2 * ia]; kdir = a.actor_key[2 * ia + 1];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    float2 t = a.tmpl[ia * 7 + k];
+                    float wx = (sc.y * t.x + (-sc.x) * t.y) + s.x;      // utils.transform :82-96
+                    float wy = (sc.x * t.x + sc.y * t.y) + s.y;
+                    sx[k] = wx + (-cam.cx); sy[k] = wy + (-cam.cy);      // mesh.translate(-cameras.xy) cv2.py:29-31
+                }
+            }
+            const int fv[3][3] = {{0, 1, 3}, {1, 3, 2}, {4, 5, 6}};
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                float fx[3], fy[3];
+                int px[3], py[3];
+                uint32_t key = f == 2 ? kdir : kbody;
+                bool use = live && (on || f == 0);
+                if (on) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { fx[k] = sx[fv[f][k]]; fy[k] = sy[fv[f][k]]; }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { fx[k] = p0x; fy[k] = p0y; }
+                    key = a.actor_key[2 * b * a.N];
+                }
+                bool acc = use && trim_project(cam, c.scale, res, X0, TW, fx, fy, px, py);
+                enqueue<TW>(w, acc, key, px, py);
+            }
+        }
+    }
+    // ---- static map: grid cells under this strip
+    if (a.map.nx > 0) {
+        const MapView &m = a.map;
+        // world-space bounding box of the strip (2 px margin: int truncation moves a vertex by < 1 px)
+        float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
+        const float half = (float)res / 2.0f;
+        const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TW, W) + 2.0f}, pys[2] = {-2.0f, (float)H + 2.0f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float x = -((pxs[i] - half) / half) / c.scale, y = -((pys[j] - half) / half) / c.scale;
+                float rx = cam.c * x - cam.s * y + cam.cx, ry = cam.s * x + cam.c * y + cam.cy;
+                wx0 = fminf(wx0, rx); wx1 = fmaxf(wx1, rx); wy0 = fminf(wy0, ry); wy1 = fmaxf(wy1, ry);
+            }
+        const float eps = 1e-3f + 1e-6f * (fabsf(cam.cx) + fabsf(cam.cy));
+        float fx0 = fminf(fmaxf((wx0 - eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx), fx1 = fminf(fmaxf((wx1 + eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx);
+        float fy0 = fminf(fmaxf((wy0 - eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny), fy1 = fminf(fmaxf((wy1 + eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny);
+        int sx0 = max((int)floorf(fx0), 0), sx1 = min((int)floorf(fx1), m.nx - 1);
+        int sy0 = max((int)floorf(fy0), 0), sy1 = min((int)floorf(fy1), m.ny - 1);
+        if (sx0 <= sx1 && sy0 <= sy1) {
+            int chunk = wave;       // chunks of 64 consecutive entries, dealt round-robin to the waves
+            for (int cy = sy0; cy <= sy1; ++cy) {
+                // the cells sx0..sx1 of one grid row are one contiguous range of entries
+                const int e0 = m.cell_start[cy * m.nx + sx0], e1 = m.cell_start[cy * m.nx + sx1 + 1];
+                const int first_end = m.cell_start[cy * m.nx + sx0 + 1];
+                const int nchunks = (e1 - e0 + 63) >> 6;
+                for (; chunk < nchunks; chunk += RWAVES) {
+                    int i = e0 + chunk * 64 + lane;
+                    bool acc = false;
+                    uint32_t key = 0;
+                    int px[3], py[3];
+                    if (i < e1) {
+                        const uint4 *ep = (const uint4 *)(m.entries + i);
+                        uint4 u0 = ep[0], u1 = ep[1];
+                        unsigned dd = u1.w;                                     // bx0 | by0 << 16 = offsets from the bbox-min cell
+                        // exactly one of the scanned cells owns the face: the first one its bounding box touches
+                        bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && (((dd >> 16) == 0) || (cy == sy0));
+                        if (owner) {
+                            float vx[3] = {__uint_as_float(u0.x), __uint_as_float(u0.z), __uint_as_float(u1.x)};
+                            float vy[3] = {__uint_as_float(u0.y), __uint_as_float(u0.w), __uint_as_float(u1.y)};
+                            float sxv[3], syv[3];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { sxv[k] = vx[k] + (-cam.cx); syv[k] = vy[k] + (-cam.cy); }
+                            key = u1.z;
+                            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py);
+                        }
+                    }
+                    enqueue<TW>(w, acc, key, px, py);
+                }
+                chunk -= nchunks;
+            }
+        }
+    }
+    if (w.qlen > 0) process_batch<TW>(w, w.qlen);
+    __syncthreads();
+    write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+}
+
+// Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
+template <int TW, typename OutT>
+__global__ void __launch_bounds__(RBLOCK) raster_mesh_kernel(MeshArgs a, CommonArgs c) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int res = c.res, H = res, W = res;
+    int64_t img;
+    int strip;
+    block_to_image(c.n_img * c.strips, c.strips, img, strip);
+    const int X0 = strip * TW;
+    uint32_t *tile = smem;
+    for (int i = tid * 4; i < TW * H; i += RBLOCK * 4) *(uint4 *)(tile + i) = make_uint4(0, 0, 0, 0);
+    WaveCtx w;
+    w.tile = tile;
+    w.q = smem + TW * H + wave * WAVE_LDS_DW;
+    w.par = (int *)(w.q + Q_DW);
+    w.pref = w.par + NPAR * 64;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0;
+    Camera cam;
+    {
+        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
+        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
+        make_polygon(cam, c.scale, res);
+    }
+    __syncthreads();
+    const float *V = a.verts + img * a.V * 3, *A = a.attrs + img * a.V * 3;
+    const int32_t *Fp = a.faces + img * a.F * 3;
+    for (int64_t f0 = (int64_t)wave * 64; f0 < a.F; f0 += RBLOCK) {
+        int64_t f = f0 + lane;
+        bool acc = false;
+        uint32_t key = 0;
+        int px[3], py[3];
+        if (f < a.F) {
+            int v0 = Fp[3 * f], v1 = Fp[3 * f + 1], v2 = Fp[3 * f + 2];
+            float sxv[3] = {V[3 * v0] + (-cam.cx), V[3 * v1] + (-cam.cx), V[3 * v2] + (-cam.cx)};
+            float syv[3] = {V[3 * v0 + 1] + (-cam.cy), V[3 * v1 + 1] + (-cam.cy), V[3 * v2 + 1] + (-cam.cy)};
+            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py);
+            if (acc) {
+                float z = V[3 * v0 + 2];                                         // level of the first vertex, cv2.py:44-46
+                int rank = 0;
+                for (int l = 0; l < a.n_levels; ++l) rank += (a.levels[l] >= z) ? 1 : 0;   // 1 + index in the descending table
+                acc = rank > 0;
+                uint32_t rgb = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {                                 // cv2.py:50
+                    float q = floorf((A[3 * v0 + ch] * (float)(1.0 - 1e-3)) * 256.0f);
+                    rgb = (rgb << 8) | ((uint32_t)(int)q & 255u);
+                }
+                key = ((uint32_t)rank << 24) | rgb;
+            }
+        }
+        enqueue<TW>(w, acc, key, px, py);
+    }
+    if (w.qlen > 0) process_batch<TW>(w, w.qlen);
+    __syncthreads();
+    write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+}
+
+inline size_t lds_bytes(int tw, int res) { return ((size_t)tw * res + (size_t)RWAVES * WAVE_LDS_DW) * sizeof(uint32_t); }
+
+// strip width: the widest of {64,32,16,8} whose tile leaves room for two workgroups per CU (160 KiB LDS), else one
+inline int pick_tw(int res) {
+    const int cands[4] = {64, 32, 16, 8};
+    for (int tw : cands)
+        if (lds_bytes(tw, res) <= 80 * 1024) return tw;
+    for (int tw : cands)
+        if (lds_bytes(tw, res) <= 160 * 1024) return tw;
+    return 0;
+}
+
+int g_force_tw = 0;
+
+}  // namespace
+
+// test/benchmark hook: force the strip width (0 = automatic)
+TDS_EXPORT int tds_raster_set_strip_width(int tw) {
+    TDS_CHECK_ARG(tw == 0 || tw == 8 || tw == 16 || tw == 32 || tw == 64, "strip width must be 0, 8, 16, 32 or 64");
+    g_force_tw = tw;
+    return TDS_OK;
+}
+
+#define TDS_LAUNCH_RASTER(KERNEL, ARGS)                                                                                        \
+    do {                                                                                                                       \
+        size_t lds = lds_bytes(tw, res);                                                                                       \
+        dim3 grid((unsigned)(n_img * cm.strips));                                                                              \
+        auto launch = [&](auto kern) {                                                                                         \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(kern, grid, dim3(RBLOCK), lds, (hipStream_t)stream, ARGS, cm);                                  \
+        };                                                                                                                     \
+        if (out_mode == TDS_OUT_F32) {                                                                                         \
+            if (tw == 64) launch(KERNEL<64, float>); else if (tw == 32) launch(KERNEL<32, float>);                             \
+            else if (tw == 16) launch(KERNEL<16, float>); else launch(KERNEL<8, float>);                                       \
+        } else {                                                                                                               \
+            if (tw == 64) launch(KERNEL<64, uint8_t>); else if (tw == 32) launch(KERNEL<32, uint8_t>);                         \
+            else if (tw == 16) launch(KERNEL<16, uint8_t>); else launch(KERNEL<8, uint8_t>);                                   \
+        }                                                                                                                      \
+    } while (0)
+
+static int common_checks(const char *fn, int64_t n_img, int res, int out_mode, const void *out, int &tw) {
+    TDS_CHECK_ARG(n_img >= 0, "%s: negative image count", fn);
+    TDS_CHECK_ARG(res > 0 && res <= 4096, "%s: resolution %d out of range (1..4096)", fn, res);
+    TDS_CHECK_ARG(out_mode == TDS_OUT_F32 || out_mode == TDS_OUT_U8, "%s: unknown output mode %d", fn, out_mode);
+    TDS_CHECK_ARG(out || n_img == 0, "%s: null output", fn);
+    tw = g_force_tw ? g_force_tw : pick_tw(res);
+    if (tw == 0 || lds_bytes(tw, res) > 160 * 1024) { tds::set_error("%s: resolution %d does not fit the LDS tile", fn, res); return TDS_ELIMIT; }
+    TDS_CHECK_ARG(n_img * ((res + tw - 1) / tw) < ((int64_t)1 << 31), "%s: too many strips", fn);
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
+                                const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
+                                int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *stream) {
+    TDS_CHECK_ARG(map, "tds_raster_scene: null map");
+    TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
+    TDS_CHECK_ARG(map->n_levels > 0 || map->view.nx == 0, "tds_raster_scene: the map was created without rendering data");
+    int64_t n_img = B * Nc;
+    int tw = 0;
+    int rc = common_checks("tds_raster_scene", n_img, res, out_mode, out, tw);
+    if (rc != TDS_OK) return rc;
+    if (n_img == 0) return TDS_OK;
+    TDS_CHECK_ARG(cam_xy && cam_sc, "tds_raster_scene: null camera arrays");
+    TDS_CHECK_ARG(N == 0 || (state && agent_sc && tmpl && actor_key && mask), "tds_raster_scene: null agent arrays");
+    TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene: scale must be positive");
+    SceneArgs a;
+    a.map = map->view; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
+    a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc;
+    CommonArgs cm;
+    cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out;
+    TDS_LAUNCH_RASTER(raster_scene_kernel, a);
+    TDS_LAUNCH_CHECK("raster_scene_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces, int64_t n_img, int64_t V, int64_t F,
+                               const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,
+                               int out_mode, void *out, void *stream) {
+    TDS_CHECK_ARG(V >= 0 && F >= 0, "tds_raster_mesh: negative size");
+    int tw = 0;
+    int rc = common_checks("tds_raster_mesh", n_img, res, out_mode, out, tw);
+    if (rc != TDS_OK) return rc;
+    if (n_img == 0) return TDS_OK;
+    TDS_CHECK_ARG(cam_xy && cam_sc, "tds_raster_mesh: null camera arrays");
+    TDS_CHECK_ARG(F == 0 || (verts && attrs && faces && levels), "tds_raster_mesh: null mesh arrays");
+    TDS_CHECK_ARG(scale > 0.0f, "tds_raster_mesh: scale must be positive");
+    if (n_levels > 64) { tds::set_error("tds_raster_mesh: %d rendering levels (max 64 on the generic path)", n_levels); return TDS_ELIMIT; }
+    MeshArgs a;
+    a.verts = verts; a.attrs = attrs; a.faces = faces; a.V = V; a.F = F; a.n_levels = n_levels;
+    for (int i = 0; i < 64; ++i) a.levels[i] = i < n_levels ? levels[i] : -3.0e38f;
+    for (int i = 1; i < n_levels; ++i) TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_raster_mesh: levels must be strictly descending");
+    CommonArgs cm;
+    cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out;
+    TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
+    TDS_LAUNCH_CHECK("raster_mesh_kernel");
+    return TDS_OK;
+}

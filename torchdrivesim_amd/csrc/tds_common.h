@@ -1,0 +1,75 @@
+// Shared host/device helpers of libtdship (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/tdship.h"
+
+#define TDS_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace tds {
+
+void set_error(const char *fmt, ...);
+
+#define TDS_CHECK_ARG(cond, ...)                       \
+    do {                                               \
+        if (!(cond)) {                                 \
+            tds::set_error(__VA_ARGS__);               \
+            return TDS_EINVAL;                         \
+        }                                              \
+    } while (0)
+
+#define TDS_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            tds::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return TDS_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+// kernel launch check (no sync): picks up invalid configuration / missing device code immediately
+#define TDS_LAUNCH_CHECK(name)                                                                 \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) {                                                                \
+            tds::set_error("launch of %s failed: %s", name, hipGetErrorString(e_));            \
+            return TDS_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// ---- static map handle (device side view is MapView) -------------------------------------------------------
+struct GridEntry {          // 32 bytes, one per (cell, face whose bounding box touches the cell)
+    float x0, y0, x1, y1, x2, y2;   // world coordinates of the three vertices
+    uint32_t key;                   // rank << 24 | 0x00RRGGBB  (0 when the map carries no rendering data)
+    uint16_t ddx, ddy;              // this cell minus the cell of the face's bounding-box minimum (owner rule)
+};
+
+struct MapView {
+    const GridEntry *entries;
+    const int32_t *cell_start;      // nx*ny + 1
+    float ox, oy, inv_cell, cell;
+    int nx, ny;
+    int64_t n_faces;
+};
+
+// the ONE definition of "which cell does this coordinate fall in" -- used by the host builder and by the kernels
+// (IEEE binary32, one rounding per operation on both sides: the library is built with -ffp-contract=off)
+__host__ __device__ inline int cell_coord(float v, float origin, float inv_cell) {
+    return (int)floorf((v - origin) * inv_cell);
+}
+
+}  // namespace tds
+
+struct tds_map {
+    tds::MapView view;
+    void *d_entries;
+    void *d_cell_start;
+    int device;
+    int64_t V, F, n_entries, bytes;
+    int n_levels;
+};
