@@ -1,0 +1,132 @@
+"""End-to-end parity through the reference-shaped API (Simulator / KinematicBicycle / HipRenderer) on an MI355X."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def town_mesh(B, crop=None):
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    t = load_golden('town01_mesh.npz')
+    return BirdviewMesh(verts=torch.from_numpy(t['verts'])[None], faces=torch.from_numpy(t['faces'].astype(np.int64))[None],
+                        categories=[str(c) for c in t['categories']], colors={}, zs={},
+                        vert_category=torch.from_numpy(t['vert_category'].astype(np.int64))[None]).expand(B).to(DEV), t
+
+
+def make_sim(state, size, present, road, metric='iou', npc=None, lr=None):
+    from torchdrivesim_amd.kinematic import KinematicBicycle
+    from torchdrivesim_amd.rendering import HipRendererConfig
+    from torchdrivesim_amd.simulator import Simulator, TorchDriveConfig, CollisionMetric, NPCController
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    km = KinematicBicycle()
+    km.set_params(lr=d(lr) if lr is not None else torch.full(state.shape[:2], 1.5, device=DEV))
+    km.set_state(d(state))
+    ctrl = None
+    if npc is not None:
+        ctrl = NPCController(npc_size=d(npc['size']), npc_state=d(npc['state']), npc_present_mask=d(npc['present']))
+    cfg = TorchDriveConfig(collision_metric=CollisionMetric(metric), renderer=HipRendererConfig())
+    return Simulator(road, km, d(size), d(present), cfg, npc_controller=ctrl)
+
+
+def test_smoke_entry_point():
+    import __graft_entry__
+    __graft_entry__.smoke()
+
+
+@pytest.mark.parametrize('metric', ['iou', 'discs'])
+def test_compute_collision_matches_reference(metric):
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    g = load_golden('g2_scene_collision.npz')
+    B = g['state'].shape[0]
+    road = BirdviewMesh.empty(batch_size=B).to(DEV)
+    sim = make_sim(g['state'], g['size'], g['present'], road, metric)
+    out = sim.compute_collision().cpu().numpy()
+    np.testing.assert_array_equal(out > 0, g['coll_' + metric] > 0)
+    np.testing.assert_allclose(out, g['coll_' + metric], atol=2e-6, rtol=0)
+    sim = make_sim(g['state'], g['size'], g['present'], road, metric, npc=dict(state=g['npc_state'], size=g['npc_size'], present=g['npc_present']))
+    out = sim.compute_collision().cpu().numpy()
+    assert out.shape == (B, 8)
+    np.testing.assert_array_equal(out > 0, g['coll_npc_' + metric] > 0)
+    np.testing.assert_allclose(out, g['coll_npc_' + metric], atol=2e-6, rtol=0)
+
+
+def test_nograd_counts_overlapping_present_agents():
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    from torchdrivesim_amd.simulator import CollisionMetric
+    state = np.array([[[0, 0, 0, 0], [2, 0, 0, 0], [30, 30, 0, 0], [1, 0.5, 0.5, 0], [4, 0, 0, 0]]], np.float32)
+    size = np.tile(np.array([4.0, 2.0], np.float32), (1, 5, 1))
+    present = np.array([[True, True, True, False, True]])
+    sim = make_sim(state, size, present, BirdviewMesh.empty(batch_size=1).to(DEV))
+    sim.cfg.collision_metric = CollisionMetric.nograd
+    # 0-1 overlap, 1-4 overlap, 0-4 only touch (no area), 3 is absent, 2 is far away
+    assert sim.compute_collision().cpu().tolist() == [[1.0, 2.0, 0.0, 0.0, 1.0]]
+
+
+def test_compute_offroad_matches_reference():
+    from torchdrivesim_amd.mesh import BaseMesh
+    g = load_golden('g3_offroad.npz')
+    road = BaseMesh(verts=torch.from_numpy(g['b_verts']), faces=torch.from_numpy(g['b_faces'].astype(np.int64))).to(DEV)   # two different scenes
+    sim = make_sim(g['b_state'], g['b_lenwid'], g['c_present'], road)
+    out = sim.compute_offroad().cpu().numpy()
+    np.testing.assert_allclose(out, g['c_sim_offroad'], rtol=2e-6, atol=1e-6)
+    np.testing.assert_array_equal(out > 0, g['c_sim_offroad'] > 0)
+    from torchdrivesim_amd.infractions import offroad_infraction_loss
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    np.testing.assert_allclose(offroad_infraction_loss(d(g['b_state']), d(g['b_lenwid']), road, threshold=0.0).cpu().numpy(), g['b_off_t0'],
+                               rtol=2e-6, atol=1e-6)
+
+
+def test_render_egocentric_matches_reference_pipeline(oracle):
+    """G5 case `town01_128`: images through Simulator.render_egocentric vs the oracle fed with the golden inputs; the
+    oracle's pre-raster stage is pinned to the reference's call lists in test_oracle_golden.py."""
+    from torchdrivesim_amd.utils import Resolution
+    g = load_golden('g45_mesh_preraster.npz')
+    meta = {m['name']: m for m in json.loads(str(g['g5_meta']))}
+    for name in ('town01_128', 'town01_64_lh'):
+        m = meta[name]
+        st, sz, pr = g[f'g5_{name}_state'], g[f'g5_{name}_size'], g[f'g5_{name}_present']
+        B, A = st.shape[:2]
+        road, t = town_mesh(B)
+        sim = make_sim(st, sz, pr, road)
+        sim.cfg.left_handed_coordinates = m['left_handed']
+        img = sim.render_egocentric(res=Resolution(m['res'], m['res']), fov=m['fov'])
+        assert tuple(img.shape) == tuple(m['out_shape'])
+        sv, sa, sf = oracle.static_mesh_arrays(t['verts'], t['faces'], t['vert_category'], [str(c) for c in t['categories']])
+        s = sim.get_state()
+        sc = torch.stack([torch.sin(s[..., 2]), torch.cos(s[..., 2])], -1).cpu().numpy()
+        mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
+        ref = oracle.render_scenes(st, sz, mask, st[..., :2].copy(), sc, sv, sa, sf, m['fov'], m['res'], agent_sc=sc)
+        np.testing.assert_array_equal(img.cpu().numpy(), ref)
+        # the generic BirdviewRenderer.render_frame dataflow (explicit per-camera mesh) gives the same pixels
+        if name == 'town01_64_lh':
+            gen = sim.birdview_mesh_generator
+            rgb = gen.generate(A, agent_state=s[:, None].expand(-1, A, -1, -1), present_mask=torch.from_numpy(mask).to(DEV))
+            cam_sc = torch.from_numpy(sc).to(DEV)
+            img2 = sim.renderer.render_frame(rgb, s[..., :2], cam_sc, res=Resolution(m['res'], m['res']), fov=m['fov'])
+            np.testing.assert_array_equal(img2.reshape(img.shape).cpu().numpy(), ref)
+
+
+def test_step_render_loop_and_single_agent_rendering():
+    from torchdrivesim_amd.utils import Resolution
+    g = load_golden('g45_mesh_preraster.npz')
+    st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']
+    road, _ = town_mesh(st.shape[0])
+    sim = make_sim(st, sz, pr, road)
+    before = sim.get_state().clone()
+    act = torch.zeros(st.shape[0], st.shape[1], 2, device=DEV)
+    act[0, 0, 0] = 1.0
+    sim.step(act)
+    moved = (sim.get_state() - before).abs().sum(-1) > 0
+    assert bool(moved[0, 0])                                   # test_simulator.py:134-138: the actuated agent moves
+    img = sim.render_egocentric(res=Resolution(64, 64))
+    assert img.shape == (2, 8, 3, 64, 64) and img.dtype == torch.float32
+    sim.cfg.single_agent_rendering = True
+    solo = sim.render_egocentric(res=Resolution(64, 64))
+    veh = torch.tensor([32.0, 74.0, 135.0], device=DEV).view(1, 1, 3, 1, 1)
+    assert ((solo == veh).all(2).flatten(2).sum(-1) <= (img == veh).all(2).flatten(2).sum(-1)).all()

@@ -1,0 +1,140 @@
+"""CPU-only tests of the host-side mirror of the reference interface (no kernel is launched): shapes and bookkeeping that
+the reference's own tests check (tests/simulator/test_simulator.py:90-160, tests/test_mesh.py), mesh file formats."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+
+def make_sim(B=2, A=3, npc=0):
+    from torchdrivesim_amd.kinematic import KinematicBicycle
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    from torchdrivesim_amd.rendering import HipRendererConfig
+    from torchdrivesim_amd.simulator import Simulator, TorchDriveConfig, NPCController
+    km = KinematicBicycle()
+    km.set_params(lr=torch.ones(B, A))
+    km.set_state(torch.arange(B * A * 4, dtype=torch.float32).reshape(B, A, 4))
+    ctrl = None
+    if npc:
+        ctrl = NPCController(npc_size=torch.ones(B, npc, 2), npc_state=torch.zeros(B, npc, 4), npc_present_mask=torch.ones(B, npc, dtype=torch.bool))
+    return Simulator(BirdviewMesh.empty(batch_size=B), km, torch.ones(B, A, 2), torch.ones(B, A, dtype=torch.bool),
+                     TorchDriveConfig(renderer=HipRendererConfig()), npc_controller=ctrl)
+
+
+def test_accessor_shapes():
+    sim = make_sim(2, 3, npc=2)
+    assert sim.get_state().shape == (2, 3, 4) and sim.get_agent_size().shape == (2, 3, 2)
+    assert sim.get_all_agent_state().shape == (2, 5, 4) and sim.get_all_agent_present_mask().shape == (2, 5)
+    assert sim.get_all_agents_absolute().shape == (2, 5, 6)
+    assert sim.get_all_agents_relative().shape == (2, 3, 4, 6)
+    assert sim.get_all_agents_relative(exclude_self=False).shape == (2, 3, 5, 6)
+    assert sim.compute_wrong_way().shape == (2, 3) and not sim.compute_wrong_way().any()
+    assert sim.agent_count == 3 and sim.npc_count == 2 and sim.action_size == 2
+
+
+def test_relative_excludes_self_like_boolean_indexing():
+    sim = make_sim(2, 4, npc=1)
+    full = sim.get_all_agents_relative(exclude_self=False)
+    rel = sim.get_all_agents_relative(exclude_self=True)
+    keep = torch.cat([~torch.eye(4, dtype=torch.bool), torch.ones(4, 1, dtype=torch.bool)], -1).flatten()
+    ref = full.flatten(-3, -2)[..., keep, :].reshape(2, 4, 4, 6)          # the reference's formulation (simulator.py:774-781)
+    assert torch.equal(rel, ref)
+
+
+def test_copy_extend_select():
+    sim = make_sim(2, 3)
+    other = sim.copy()
+    other.set_state(torch.zeros(2, 3, 4))
+    assert not torch.equal(other.get_state(), sim.get_state())          # copy is independent (test_simulator.py:90-95)
+    ext = sim.extend(3, in_place=False)
+    assert ext.batch_size == 6 and ext.get_state().shape == (6, 3, 4) and sim.batch_size == 2
+    assert torch.equal(ext.get_state()[0], ext.get_state()[2]) and torch.equal(ext.get_state()[0], sim.get_state()[0])
+    sel = sim[[1]]
+    assert sel.batch_size == 1 and torch.equal(sel.get_state()[0], sim.get_state()[1])
+    sim.set_state(torch.ones(2, 3, 4), mask=torch.tensor([[True, False, False], [False, False, True]]))
+    assert sim.get_state()[0, 0].tolist() == [1, 1, 1, 1] and sim.get_state()[0, 1].tolist() == [4, 5, 6, 7]
+
+
+def test_out_of_scope_arguments_are_refused():
+    from torchdrivesim_amd.simulator import Simulator
+    sim = make_sim()
+    with pytest.raises(NotImplementedError):
+        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, traffic_controls={'traffic_light': object()})
+
+
+def test_kinematic_bookkeeping_and_fit_action():
+    from torchdrivesim_amd.kinematic import KinematicBicycle, BicycleModel, SimpleKinematicModel, OrientedKinematicModel
+    assert BicycleModel is KinematicBicycle
+    g = load_golden('g1_kinematic.npz')
+    km = KinematicBicycle()
+    km.set_params(lr=torch.from_numpy(g['lr']))
+    km.set_state(torch.from_numpy(g['state']))
+    np.testing.assert_allclose(km.fit_action(torch.from_numpy(g['future'])).numpy(), g['fit_bicycle'], atol=1e-6)
+    km2 = KinematicBicycle(left_handed=True)
+    km2.set_params(lr=torch.from_numpy(g['lr']))
+    km2.set_state(torch.from_numpy(g['state']))
+    np.testing.assert_allclose(km2.fit_action(torch.from_numpy(g['future'])).numpy(), g['fit_bicycle_lh'], atol=1e-6)
+    for cls, key in ((SimpleKinematicModel, 'fit_simple'), (OrientedKinematicModel, 'fit_oriented')):
+        m = cls()
+        m.set_state(torch.from_numpy(g['state']))
+        np.testing.assert_allclose(m.fit_action(torch.from_numpy(g['future'])).numpy(), g[key], rtol=1e-5, atol=1e-5)
+    c = km.copy()
+    assert c is not km and c.get_state() is km.get_state() and c.lr is km.lr
+    km.extend(2)
+    assert km.get_state().shape == (6, 7, 4) and km.lr.shape == (6, 7)
+    km.select_batch_elements([0, 3])
+    assert km.get_state().shape == (2, 7, 4)
+
+
+def test_mesh_json_format_and_fill_attr():
+    from torchdrivesim_amd.mesh import BirdviewMesh, set_colors_with_defaults
+    from torchdrivesim_amd.rendering import get_default_color_map, get_default_rendering_levels
+    m = BirdviewMesh.load(os.path.join(GOLDEN, 'town01_crop_small_mesh.json'))       # written by the reference's save()
+    g = load_golden('g45_mesh_preraster.npz')
+    np.testing.assert_array_equal(m.verts[0].numpy(), g['g4_bg_verts'])
+    np.testing.assert_array_equal(m.faces[0].numpy(), g['g4_bg_faces'])
+    assert m.categories == ['right_lane', 'left_lane', 'road']
+    rgb = set_colors_with_defaults(m.clone(), get_default_color_map(), get_default_rendering_levels())
+    ref = g['g4_gen_bg_attrs_z']                                                        # reference fill_attr output
+    np.testing.assert_array_equal(rgb.attrs[0].numpy(), ref[:, :3])
+    np.testing.assert_array_equal(rgb.verts[0, :, 2].numpy(), ref[:, 3])
+
+
+def test_mesh_roundtrip_expand_concat_collate(tmp_path):
+    from torchdrivesim_amd.mesh import BirdviewMesh, BaseMesh
+    m = BirdviewMesh.load(os.path.join(GOLDEN, 'town01_crop_small_mesh.json'))
+    p = tmp_path / 'm.json'
+    m.save(str(p))
+    m2 = BirdviewMesh.load(str(p))
+    assert torch.equal(m.verts, m2.verts) and torch.equal(m.faces, m2.faces) and torch.equal(m.vert_category, m2.vert_category)
+    e = m.expand(3)
+    assert e.batch_size == 3 and e.verts.shape[1:] == m.verts.shape[1:]
+    cc = BirdviewMesh.concat([m, m])
+    assert cc.verts_count == 2 * m.verts_count and int(cc.faces.max()) == 2 * m.verts_count - 1
+    small = BaseMesh(verts=torch.zeros(1, 2, 2), faces=torch.zeros(1, 1, 3, dtype=torch.long))
+    col = BaseMesh.collate([BaseMesh(m.verts, m.faces), small])
+    assert col.batch_size == 2 and col.faces_count == m.faces_count and (col.faces[1, 1:] == 0).all()     # padded [0,0,0] faces
+    sep = m.separate_by_category()
+    assert set(sep) == {'right_lane', 'left_lane', 'road'} and sum(v.faces_count for v in sep.values()) >= m.faces_count
+
+
+def test_generator_matches_reference_generate():
+    """BirdviewRGBMeshGenerator.generate (generic dataflow) against G4 from the reference (mesh.py:1053-1157)."""
+    from torchdrivesim_amd.mesh import BirdviewMesh, BirdviewRGBMeshGenerator
+    from torchdrivesim_amd.rendering import get_default_color_map, get_default_rendering_levels
+    g = load_golden('g45_mesh_preraster.npz')
+    bg = BirdviewMesh.load(os.path.join(GOLDEN, 'town01_crop_small_mesh.json')).expand(2)
+    gen = BirdviewRGBMeshGenerator(bg, get_default_color_map(), get_default_rendering_levels())
+    size, state, present = torch.from_numpy(g['g4_size']), torch.from_numpy(g['g4_state']), torch.from_numpy(g['g4_present'])
+    gen.initialize_actors_mesh(size, torch.zeros(2, 4, dtype=torch.long), ['vehicle'])
+    np.testing.assert_array_equal(gen.actor_mesh.verts.numpy(), g['g4_tmpl_verts'])
+    np.testing.assert_array_equal(gen.actor_mesh.faces.numpy(), g['g4_tmpl_faces'])
+    np.testing.assert_array_equal(gen.actor_mesh.attrs.numpy(), g['g4_tmpl_attrs'])
+    rgb = gen.generate(4, agent_state=state[:, None].expand(-1, 4, -1, -1), present_mask=present[:, None].expand(2, 4, 4))
+    nv, nf = g['g4_bg_verts'].shape[0], g['g4_bg_faces'].shape[0]
+    np.testing.assert_array_equal(rgb.verts[:, nv:].numpy(), g['g4_gen_actor_verts'])
+    np.testing.assert_array_equal(rgb.faces[:, nf:].numpy(), g['g4_gen_actor_faces'])       # masked agents alias the first actor vertex
+    np.testing.assert_array_equal(rgb.attrs[:, nv:].numpy(), g['g4_gen_actor_attrs'])

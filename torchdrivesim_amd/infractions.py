@@ -1,0 +1,88 @@
+"""
+Infraction metrics with the reference's names and signatures (torchdrivesim/infractions.py), computed by the K2 HIP
+kernels: oriented-box IoU, 5-disc overlap, and off-road distance to the driving-surface mesh.
+"""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from torchdrivesim_amd import _ops
+from torchdrivesim_amd.mesh import BaseMesh
+
+
+def iou_differentiable(box1: Tensor, box2: Tensor, fast: bool = True) -> Tensor:
+    """Approximate IoU of oriented boxes, element-wise over BxAx5 tensors [x,y,length,width,psi] (infractions.py:307-324,
+    _iou_utils.py:344-367).  Forward only; `Simulator.compute_collision` is the differentiable entry point."""
+    if not fast:
+        raise NotImplementedError('only the fast Rotated-IoU variant exists (the reference imports the slow one from a private package)')
+    return _ops.pairwise_overlap(box1, box2, 'iou')
+
+
+def collision_detection_with_discs(box1: Tensor, box2: Tensor, num_discs: int = 5, backend: str = 'torch') -> Tensor:
+    """TrafficSim-style overlap of 5 discs per box, relu(1 - d / (r1 + r2)) (infractions.py:503-545)."""
+    if num_discs != 5:
+        raise NotImplementedError('the HIP kernel implements the default num_discs=5')
+    if backend != 'torch':
+        raise ValueError('Unknown backend framework.')
+    return _ops.pairwise_overlap(box1, box2, 'discs')
+
+
+def box2corners_th(box: Tensor) -> Tensor:
+    """(B,N,5) boxes -> (B,N,4,2) corners (_iou_utils.py:270-299)"""
+    return _ops.box2corners(box)
+
+
+def _static_maps_for(mesh: BaseMesh, device) -> List:
+    """One device map per DISTINCT batch element of the mesh, cached on the mesh object: [(StaticMap, scene indices)]."""
+    key = (mesh.verts.data_ptr(), mesh.faces.data_ptr(), tuple(mesh.verts.shape), tuple(mesh.faces.shape), str(device))
+    cache = getattr(mesh, '_tds_offroad_maps', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    verts, faces = mesh.verts[..., :2].detach(), mesh.faces.detach()
+    B = mesh.batch_size
+    same = B == 1 or (verts.stride(0) == 0 and faces.stride(0) == 0) or \
+        (bool((verts == verts[:1]).all()) and bool((faces == faces[:1]).all()))
+    if same:
+        maps = [(_ops.StaticMap(verts[0], faces[0], device=device), None)]
+    else:
+        maps = [(_ops.StaticMap(verts[b], faces[b], device=device), b) for b in range(B)]
+    try:
+        object.__setattr__(mesh, '_tds_offroad_maps', (key, maps))
+    except Exception:
+        pass
+    return maps
+
+
+def offroad_infraction_loss(agent_states: Tensor, lenwid: Tensor, driving_surface_mesh: Union[BaseMesh, _ops.StaticMap],
+                            threshold: float = 0, use_pytorch3d: Optional[bool] = None) -> Tensor:
+    """Sum over the 4 agent corners of the thresholded SQUARED distance to the mesh (infractions.py:176-229, the pure
+    torch path: `F.threshold(d, threshold, 0)` keeps d).  agent_states BxAx4, lenwid BxAx2 or Bx2 -> BxA."""
+    if use_pytorch3d:
+        raise NotImplementedError('pytorch3d is not part of this framework; the HIP kernel follows the pure-torch path')
+    B, A = agent_states.shape[:2]
+    if isinstance(driving_surface_mesh, _ops.StaticMap):
+        maps = [(driving_surface_mesh, None)]
+        n_faces = driving_surface_mesh.n_faces
+    else:
+        n_faces = driving_surface_mesh.faces_count
+        maps = None
+    if A == 0 or n_faces == 0:
+        return torch.zeros_like(agent_states[..., 0])
+    if lenwid.dim() == 2:
+        lenwid = lenwid.unsqueeze(-2).expand((lenwid.shape[0], A, lenwid.shape[1]))
+    if maps is None:
+        maps = _static_maps_for(driving_surface_mesh, agent_states.device)
+    if maps[0][1] is None:
+        return _ops.offroad(maps[0][0], agent_states, lenwid, threshold=threshold)
+    return torch.cat([_ops.offroad(m, agent_states[b:b + 1], lenwid[b:b + 1], threshold=threshold) for m, b in maps], dim=0)
+
+
+def lanelet_orientation_loss(lanelet_maps, agents_state: Tensor, recenter_offset: Optional[Tensor] = None,
+                             direction_angle_threshold: float = np.pi / 2, lanelet_dist_tolerance: float = 1.0) -> Tensor:
+    """Wrong-way loss (infractions.py:232-304).  Needs Lanelet2, which is outside this framework's scope:
+    scenes without a map give zeros exactly as the reference does; a real map is refused loudly."""
+    if any(m is not None for m in lanelet_maps):
+        raise NotImplementedError('lanelet2-based wrong-way detection is not available in torchdrivesim_amd')
+    return torch.zeros(agents_state.shape[:2], dtype=torch.float, device=agents_state.device)

@@ -1,0 +1,579 @@
+"""
+`Simulator` facade with the reference's surface (torchdrivesim/simulator.py:280-1194): constructor injection of a
+`KinematicModel` and a `BirdviewRenderer`, `TorchDriveConfig.collision_metric` dispatch, `step`, `render`,
+`render_egocentric`, `compute_collision`, `compute_offroad`, `compute_wrong_way`, state accessors and the batch plumbing
+(`copy`, `extend`, `select_batch_elements`, `to`).  Every hot call goes to a HIP kernel:
+
+    step               -> K1 (kinematic.py)                                  reference: simulator.py:841-861
+    render[_egocentric]-> K3 fused scene path (rendering/hip.py)             reference: simulator.py:920-1033
+    compute_collision  -> K2a, all agents of all scenes in one launch        reference: simulator.py:1064-1194 (A launches)
+    compute_offroad    -> K2b over the device-resident map grid              reference: simulator.py:1035-1044
+
+Out of scope: lanelet maps, traffic controls, waypoint goals, observation noise; passing them
+raises NotImplementedError instead of silently ignoring them.
+"""
+import logging
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from torchdrivesim_amd import _ops
+from torchdrivesim_amd.kinematic import KinematicModel
+from torchdrivesim_amd.mesh import BirdviewMesh, BirdviewRGBMeshGenerator, actor_template, set_colors_with_defaults
+from torchdrivesim_amd.rendering import BirdviewRenderer, RendererConfig, renderer_from_config, HipRenderer
+from torchdrivesim_amd.utils import Resolution, is_inside_polygon, relative, assert_equal
+
+logger = logging.getLogger(__name__)
+
+
+class CollisionMetric(Enum):
+    """How collisions between agents are measured (simulator.py:27-34)."""
+    iou = 'iou'                            #: approximate differentiable IoU of oriented rectangles
+    discs = 'discs'                        #: differentiable overlap of rectangles approximated by 5 discs (default)
+    nograd = 'nograd'                      #: number of other present agents whose rectangle overlaps (no gradient)
+    nograd_pytorch3d = 'nograd-pytorch3d'  #: not available here
+
+
+@dataclass
+class TorchDriveConfig:
+    """Top-level simulator configuration (simulator.py:37-51)."""
+    renderer: RendererConfig = field(default_factory=lambda: RendererConfig())
+    single_agent_rendering: bool = False
+    collision_metric: CollisionMetric = field(default_factory=lambda: CollisionMetric.discs)
+    offroad_threshold: float = 0.5
+    left_handed_coordinates: bool = False
+    wrong_way_angle_threshold: float = np.pi / 2
+    lanelet_inclusion_tolerance: float = 1.0
+    waypoint_removal_threshold: float = 2.0
+
+
+def _enlarge(x: Tensor, n: int) -> Tensor:
+    return x.unsqueeze(1).expand((x.shape[0], n) + x.shape[1:]).reshape((n * x.shape[0],) + x.shape[1:])
+
+
+class SpawnController:
+    """Despawns NPCs that leave `exit_boundary` and spawns scheduled ones (simulator.py:54-124)."""
+
+    def __init__(self, exit_boundary: Optional[Tensor] = None, spawn_states: Optional[Tensor] = None, spawn_masks: Optional[Tensor] = None):
+        self.exit_boundary, self.spawn_states, self.spawn_masks = exit_boundary, spawn_states, spawn_masks
+        self.time = 0
+
+    def spawn_despawn_npcs(self, simulator: 'Simulator') -> None:
+        ctrl = simulator.npc_controller
+        mask, states = ctrl.npc_present_mask, ctrl.npc_state
+        if self.exit_boundary is not None:
+            mask = mask & is_inside_polygon(states[..., :2], self.exit_boundary)
+        if self.spawn_states is not None and self.spawn_masks is not None:
+            to_spawn = self.spawn_masks[..., self.time] & ~mask
+            mask = mask | to_spawn
+            states = self.spawn_states[..., self.time, :].where(to_spawn.unsqueeze(-1), states)
+        ctrl.npc_present_mask, ctrl.npc_state = mask, states
+        self.time += 1
+
+    def _map(self, f):
+        for k in ('exit_boundary', 'spawn_states', 'spawn_masks'):
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, f(v))
+        return self
+
+    def to(self, device):
+        return self._map(lambda x: x.to(device))
+
+    def copy(self):
+        return self.__class__(self.exit_boundary, self.spawn_states, self.spawn_masks)
+
+    def extend(self, n, in_place=True):
+        return (self if in_place else self.copy())._map(lambda x: _enlarge(x, n))
+
+    def select_batch_elements(self, idx, in_place=True):
+        return (self if in_place else self.copy())._map(lambda x: x[idx])
+
+
+class NPCController:
+    """Non-playable agents; the base class leaves them where they are (simulator.py:128-203)."""
+
+    def __init__(self, npc_size: Tensor, npc_state: Tensor, npc_present_mask: Optional[Tensor] = None, npc_types: Optional[Tensor] = None,
+                 agent_type_names: Optional[List[str]] = None, spawn_controller: Optional[SpawnController] = None):
+        self.npc_size, self.npc_state = npc_size, npc_state
+        self.npc_present_mask = npc_present_mask if npc_present_mask is not None else torch.ones_like(npc_state[..., 0], dtype=torch.bool)
+        self.npc_types = npc_types if npc_types is not None else torch.zeros_like(self.npc_present_mask).long()
+        self.agent_type_names = agent_type_names if agent_type_names is not None else ['vehicle']
+        self.spawn_controller = spawn_controller if spawn_controller is not None else SpawnController()
+
+    def get_npc_state(self):
+        return self.npc_state
+
+    def get_npc_size(self):
+        return self.npc_size
+
+    def get_npc_types(self):
+        return self.npc_types
+
+    def get_npc_present_mask(self):
+        return self.npc_present_mask
+
+    def spawn_despawn_npcs(self, simulator: 'Simulator') -> None:
+        self.spawn_controller.spawn_despawn_npcs(simulator)
+
+    def advance_npcs(self, simulator: 'Simulator') -> None:
+        self.spawn_despawn_npcs(simulator)
+
+    def _map(self, f):
+        self.npc_size, self.npc_state = f(self.npc_size), f(self.npc_state)
+        self.npc_present_mask, self.npc_types = f(self.npc_present_mask), f(self.npc_types)
+        return self
+
+    def to(self, device):
+        self.spawn_controller.to(device)
+        return self._map(lambda x: x.to(device))
+
+    def copy(self):
+        return self.__class__(self.npc_size, self.npc_state, self.npc_present_mask, self.npc_types, self.agent_type_names, self.spawn_controller.copy())
+
+    def extend(self, n, in_place=True):
+        me = self if in_place else self.copy()
+        me.spawn_controller.extend(n, in_place=True)
+        return me._map(lambda x: _enlarge(x, n))
+
+    def select_batch_elements(self, idx, in_place=True):
+        me = self if in_place else self.copy()
+        me.spawn_controller.select_batch_elements(idx, in_place=True)
+        return me._map(lambda x: x[idx])
+
+
+class Simulator:
+    """Batched 2-D driving simulator; see the module docstring.  Arguments follow simulator.py:283-309."""
+
+    def __init__(self, road_mesh: BirdviewMesh, kinematic_model: KinematicModel, agent_size: Tensor, initial_present_mask: Tensor,
+                 cfg: TorchDriveConfig, renderer: Optional[BirdviewRenderer] = None, lanelet_map=None, recenter_offset: Optional[Tensor] = None,
+                 birdview_mesh_generator: Optional[BirdviewRGBMeshGenerator] = None, internal_time: int = 0, traffic_controls=None,
+                 waypoint_goals=None, agent_types: Optional[Tensor] = None, agent_type_names: Optional[List[str]] = None,
+                 npc_controller: Optional[NPCController] = None, agent_lr: Optional[Tensor] = None, lane_features=None,
+                 observation_noise_model=None, action_model_extras: Optional[Dict[str, Any]] = None):
+        for name, val in (('lanelet_map', lanelet_map), ('traffic_controls', traffic_controls), ('waypoint_goals', waypoint_goals),
+                          ('lane_features', lane_features), ('observation_noise_model', observation_noise_model)):
+            if val is not None and not (name == 'lanelet_map' and all(m is None for m in val)):
+                raise NotImplementedError(f'`{name}` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
+        self.road_mesh = road_mesh
+        self.lanelet_map = lanelet_map
+        self.recenter_offset = recenter_offset
+        self.kinematic_model = kinematic_model
+        self.agent_size = agent_size
+        self.present_mask = initial_present_mask
+        self.action_model_extras = action_model_extras
+        self.traffic_controls = None
+        self.waypoint_goals = None
+        self.lane_features = None
+
+        if not agent_type_names:
+            agent_type_names = ['vehicle']
+        if agent_types is None:
+            agent_types = torch.zeros_like(initial_present_mask).long()
+        if len(agent_types) == 1:
+            agent_types = agent_types.expand_as(initial_present_mask)
+        if agent_lr is None:
+            agent_lr = torch.zeros_like(initial_present_mask).to(agent_size.dtype)
+        if len(agent_lr) == 1:
+            agent_lr = agent_lr.expand_as(initial_present_mask)
+        self._agent_types = agent_type_names
+        self._batch_size = self.road_mesh.batch_size
+        self.agent_type = agent_types
+        self.agent_lr = agent_lr
+
+        self.npc_controller = npc_controller
+        if self.npc_controller is None:
+            dev = initial_present_mask.device
+            self.npc_controller = NPCController(
+                npc_size=torch.zeros((self._batch_size, 0, 2), dtype=self.agent_size.dtype, device=dev),
+                npc_state=torch.zeros((self._batch_size, 0, 4), dtype=self.get_state().dtype, device=dev),
+                npc_present_mask=torch.zeros((self._batch_size, 0), dtype=torch.bool, device=dev),
+                npc_types=torch.zeros((self._batch_size, 0), dtype=torch.long, device=dev), agent_type_names=agent_type_names)
+        self.validate_tensor_shapes()
+
+        self.cfg: TorchDriveConfig = cfg
+        if renderer is None:
+            cfg.renderer.left_handed_coordinates = cfg.left_handed_coordinates
+            self.renderer: BirdviewRenderer = renderer_from_config(cfg=cfg.renderer)
+        else:
+            self.renderer = renderer
+        if cfg.left_handed_coordinates:
+            self.kinematic_model.left_handed = cfg.left_handed_coordinates
+        self.warned_no_lanelet = False
+        self.internal_time = internal_time
+
+        if birdview_mesh_generator is None:
+            self.birdview_mesh_generator = BirdviewRGBMeshGenerator(background_mesh=self.road_mesh, color_map=self.renderer.color_map,
+                                                                    rendering_levels=self.renderer.rendering_levels)
+            self.birdview_mesh_generator.initialize_actors_mesh(self.get_all_agent_size(), self.get_all_agent_type(), self.agent_types)
+        else:
+            self.birdview_mesh_generator = birdview_mesh_generator
+        self._scene_cache = None        # device-resident static maps + actor templates/keys, rebuilt lazily
+
+    # ------------------------------------------------------------------------------------------------- properties
+    @property
+    def agent_types(self) -> Optional[List[str]]:
+        return self._agent_types
+
+    @property
+    def action_size(self) -> int:
+        return self.kinematic_model.action_size
+
+    @property
+    def batch_size(self) -> int:
+        return self._batch_size
+
+    @property
+    def agent_count(self) -> int:
+        return self.get_agent_size().shape[-2]
+
+    @property
+    def npc_count(self) -> int:
+        return self.get_npc_size().shape[-2]
+
+    # ------------------------------------------------------------------------------------------------- plumbing
+    def to(self, device):
+        self.road_mesh = self.road_mesh.to(device)
+        self.recenter_offset = self.recenter_offset.to(device) if self.recenter_offset is not None else None
+        self.agent_size, self.agent_type = self.agent_size.to(device), self.agent_type.to(device)
+        self.agent_lr, self.present_mask = self.agent_lr.to(device), self.present_mask.to(device)
+        self.kinematic_model = self.kinematic_model.to(device)
+        self.birdview_mesh_generator = self.birdview_mesh_generator.to(device)
+        self.npc_controller = self.npc_controller.to(device)
+        self._scene_cache = None
+        return self
+
+    def copy(self):
+        """Independent simulator sharing the tensors (shallow, simulator.py:421-442)."""
+        other = self.__class__(
+            road_mesh=self.road_mesh, kinematic_model=self.kinematic_model.copy(), agent_size=self.agent_size,
+            initial_present_mask=self.present_mask, cfg=self.cfg, renderer=self.renderer.copy(), lanelet_map=self.lanelet_map,
+            birdview_mesh_generator=self.birdview_mesh_generator.copy(), recenter_offset=self.recenter_offset, internal_time=self.internal_time,
+            agent_types=self.agent_type, agent_type_names=self.agent_types, agent_lr=self.agent_lr, npc_controller=self.npc_controller.copy())
+        other._scene_cache = self._scene_cache          # static maps are immutable and can be shared
+        return other
+
+    def extend(self, n: int, in_place: bool = True):
+        if not in_place:
+            other = self.copy()
+            other.extend(n, in_place=True)
+            return other
+        self.road_mesh = self.road_mesh.expand(n)
+        self.agent_size, self.agent_type = _enlarge(self.agent_size, n), _enlarge(self.agent_type, n)
+        self.agent_lr, self.present_mask = _enlarge(self.agent_lr, n), _enlarge(self.present_mask, n)
+        self.recenter_offset = _enlarge(self.recenter_offset, n) if self.recenter_offset is not None else None
+        self.lanelet_map = [m for m in self.lanelet_map for _ in range(n)] if self.lanelet_map is not None else None
+        self.kinematic_model.extend(n)
+        self._batch_size *= n
+        self.birdview_mesh_generator = self.birdview_mesh_generator.expand(n)
+        self.npc_controller = self.npc_controller.extend(n)
+        self._scene_cache = None
+        return self
+
+    def select_batch_elements(self, idx, in_place=True):
+        if not in_place:
+            other = self.copy()
+            other.select_batch_elements(idx, in_place=True)
+            return other
+        self.road_mesh = self.road_mesh[idx]
+        self.recenter_offset = self.recenter_offset[idx] if self.recenter_offset is not None else None
+        self.lanelet_map = [self.lanelet_map[i] for i in idx] if self.lanelet_map is not None else None
+        self.agent_size, self.agent_type = self.agent_size[idx], self.agent_type[idx]
+        self.agent_lr, self.present_mask = self.agent_lr[idx], self.present_mask[idx]
+        self.kinematic_model.select_batch_elements(idx)
+        self._batch_size = len(idx)
+        self.birdview_mesh_generator = self.birdview_mesh_generator.select_batch_elements(idx)
+        self.npc_controller = self.npc_controller.select_batch_elements(idx)
+        self._scene_cache = None
+        return self
+
+    def __getitem__(self, item):
+        return self.select_batch_elements(item, in_place=False)
+
+    def validate_agent_types(self):
+        return
+
+    def validate_tensor_shapes(self):
+        assert_equal(len(self.kinematic_model.get_state().shape), 3)
+        assert_equal(len(self.agent_size.shape), 3)
+        assert_equal(len(self.agent_type.shape), 2)
+        assert_equal(len(self.agent_lr.shape), 2)
+        assert_equal(len(self.present_mask.shape), 2)
+        b = self.batch_size
+        for t in (self.kinematic_model.get_state(), self.agent_size, self.agent_type, self.agent_lr, self.present_mask):
+            assert_equal(t.shape[0], b)
+        assert_equal(self.road_mesh.batch_size, b)
+        n = self.agent_count
+        assert_equal(self.kinematic_model.get_state().shape[-2], n)
+        assert_equal(self.agent_type.shape[-1], n)
+        assert_equal(self.agent_lr.shape[-1], n)
+        assert_equal(self.present_mask.shape[-1], n)
+
+    # ------------------------------------------------------------------------------------------------- accessors
+    def get_action_model_extras(self) -> Dict[str, Any]:
+        return dict(self.action_model_extras) if self.action_model_extras else {}
+
+    def get_world_center(self) -> Tensor:
+        return self.birdview_mesh_generator.world_center
+
+    def get_state(self) -> Tensor:
+        return self.kinematic_model.get_state()
+
+    def get_waypoints(self, count: int = 1):
+        return None
+
+    def get_waypoints_state(self):
+        return None
+
+    def get_waypoints_mask(self, count: int = 1):
+        return None
+
+    def get_agent_size(self) -> Tensor:
+        return self.agent_size
+
+    def get_agent_type(self) -> Tensor:
+        return self.agent_type
+
+    def get_agent_type_names(self) -> List[str]:
+        return self._agent_types
+
+    def get_agent_lr(self) -> Tensor:
+        return self.agent_lr
+
+    def get_present_mask(self) -> Tensor:
+        return self.present_mask
+
+    def get_npc_state(self) -> Tensor:
+        return self.npc_controller.get_npc_state()
+
+    def get_npc_size(self) -> Tensor:
+        return self.npc_controller.get_npc_size()
+
+    def get_npc_present_mask(self) -> Tensor:
+        return self.npc_controller.get_npc_present_mask()
+
+    def get_npc_types(self) -> Tensor:
+        return self.npc_controller.get_npc_types()
+
+    def get_all_agent_state(self) -> Tensor:
+        return self.get_state() if self.npc_count == 0 else torch.cat([self.get_state(), self.get_npc_state()], dim=-2)
+
+    def get_all_agent_size(self) -> Tensor:
+        return self.get_agent_size() if self.npc_count == 0 else torch.cat([self.get_agent_size(), self.get_npc_size()], dim=-2)
+
+    def get_all_agent_present_mask(self) -> Tensor:
+        return self.get_present_mask() if self.npc_count == 0 else torch.cat([self.get_present_mask(), self.get_npc_present_mask()], dim=-1)
+
+    def get_all_agent_type(self) -> Tensor:
+        return self.get_agent_type() if self.npc_count == 0 else torch.cat([self.get_agent_type(), self.get_npc_types()], dim=-1)
+
+    def get_all_agents_absolute(self) -> Tensor:
+        """Bx(A+Npc)x6: x, y, psi, length, width, present (simulator.py:730-738)."""
+        return torch.cat([self.get_all_agent_state()[..., :3], self.get_all_agent_size(),
+                          self.get_all_agent_present_mask().unsqueeze(-1).to(self.get_state().dtype)], dim=-1)
+
+    def get_all_agents_relative(self, exclude_self: bool = True) -> Tensor:
+        """BxAx(All[-1])x6: pose of every agent in the frame of each exposed agent (simulator.py:748-782); the diagonal is
+        removed with a reshape trick instead of boolean indexing, so no device synchronisation is needed."""
+        absolute = self.get_all_agents_absolute()
+        A, total = self.agent_count, self.agent_count + self.npc_count
+        xy, psi = absolute[..., :A, :2], absolute[..., :A, 2:3]
+        rel_xy, rel_psi = relative(origin_xy=xy.unsqueeze(-2), origin_psi=psi.unsqueeze(-2), target_xy=absolute[..., :2].unsqueeze(-3),
+                                   target_psi=absolute[..., 2:3].unsqueeze(-3))
+        rel = torch.cat([rel_xy, rel_psi, absolute[..., 3:].unsqueeze(-3).expand(rel_xy.shape[:-1] + (3,))], dim=-1)
+        if exclude_self:
+            if A == 1:
+                rel = rel[..., 1:, :]
+            else:
+                B = rel.shape[0]
+                own, npc = rel[..., :A, :], rel[..., A:, :]
+                # drop element (i, i) of an A x A block: flatten, skip every (A+1)-th entry
+                own = own.reshape(B, A * A, 6)[:, 1:, :].reshape(B, A - 1, A + 1, 6)[:, :, :A, :].reshape(B, A, A - 1, 6)
+                rel = torch.cat([own, npc], dim=-2)
+                assert rel.shape[-2] == total - 1
+        return rel
+
+    def get_traffic_controls(self):
+        return self.traffic_controls
+
+    # ------------------------------------------------------------------------------------------------- dynamics
+    def step(self, agent_action: Tensor) -> None:
+        """One simulation step for BxAxAc actions (simulator.py:841-861)."""
+        self.internal_time += 1
+        assert_equal(len(agent_action.shape), 3)
+        assert_equal(agent_action.shape[0], self.batch_size)
+        assert_equal(agent_action.shape[-2], self.agent_count)
+        self.npc_controller.advance_npcs(self)
+        self.kinematic_model.step(agent_action)
+
+    def set_state(self, agent_state: Tensor, mask: Optional[Tensor] = None) -> None:
+        if mask is None:
+            mask = torch.ones_like(agent_state[..., 0], dtype=torch.bool)
+        assert_equal(len(agent_state.shape), 3)
+        assert_equal(len(mask.shape), 2)
+        assert_equal(agent_state.shape[0], self.batch_size)
+        assert_equal(agent_state.shape[-2], self.agent_count)
+        current = self.kinematic_model.get_state()
+        k, full = agent_state.shape[-1], current.shape[-1]
+        assert k <= full
+        state = agent_state if k == full else torch.cat([agent_state, current[..., (k - full):]], dim=-1)
+        self.kinematic_model.set_state(state.where(mask.unsqueeze(-1).expand_as(state), current))
+
+    def update_present_mask(self, present_mask: Tensor) -> None:
+        assert_equal(len(present_mask.shape), 2)
+        assert_equal(present_mask.shape[0], self.batch_size)
+        assert_equal(present_mask.shape[-1], self.agent_count)
+        self.present_mask = present_mask
+
+    def fit_action(self, future_state: Tensor, current_state: Optional[Tensor] = None) -> Tensor:
+        return self.kinematic_model.fit_action(future_state=future_state, current_state=current_state)
+
+    # ------------------------------------------------------------------------------------------------- device scene data
+    def _scene(self):
+        """Static maps (one per distinct road mesh in the batch), actor templates and packed actor keys; rebuilt after
+        `to` / `extend` / `select_batch_elements` or when sizes / types tensors are replaced."""
+        gen = self.birdview_mesh_generator
+        sizes, types = self.get_all_agent_size(), self.get_all_agent_type()
+        stamp = (sizes.data_ptr(), tuple(sizes.shape), types.data_ptr(), gen.background_mesh.verts.data_ptr(), str(sizes.device), self.batch_size)
+        if self._scene_cache is not None and self._scene_cache['stamp'] == stamp:
+            return self._scene_cache
+        if not isinstance(self.renderer, HipRenderer):
+            raise RuntimeError(f'{type(self.renderer).__name__} cannot take the fused scene path; use HipRenderer')
+        dev = sizes.device
+        bg = gen.background_mesh                                   # RGBMesh, batch B, (x, y, z) + colour per vertex
+        names = list(self.agent_types)
+        lv, cm = self.renderer.rendering_levels, self.renderer.color_map
+        actor_levels = [float(lv[n]) for n in names] + [float(lv['direction'])]
+        B = self.batch_size
+        same = B == 1 or (bg.verts.stride(0) == 0 and bg.faces.stride(0) == 0) or \
+            (bool((bg.verts == bg.verts[:1]).all()) and bool((bg.faces == bg.faces[:1]).all()) and bool((bg.attrs == bg.attrs[:1]).all()))
+        if same:
+            maps = [(self.renderer.make_static_map(bg[0:1], actor_levels, device=dev), None)]
+        else:
+            maps = [(self.renderer.make_static_map(bg[b:b + 1], actor_levels, device=dev), b) for b in range(B)]
+        tmpl = actor_template(sizes).contiguous()                   # B x N x 7 x 2
+        keys = []
+        for smap, _ in maps:
+            body = torch.tensor([(smap.rank_of(lv[n]) << 24) | int(_ops.quantise_colors(torch.tensor(cm[n], dtype=torch.float32) / 255.0)) for n in names],
+                                dtype=torch.int64, device=dev)
+            dkey = (smap.rank_of(lv['direction']) << 24) | int(_ops.quantise_colors(torch.tensor(cm['direction'], dtype=torch.float32) / 255.0))
+            k = torch.stack([body[types.long()], torch.full_like(types.long(), dkey)], dim=-1)
+            keys.append(k.to(torch.int32).contiguous())             # bit pattern of the uint32 key
+        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys)
+        return self._scene_cache
+
+    # ------------------------------------------------------------------------------------------------- rendering
+    def render(self, camera_xy: Tensor, camera_psi: Tensor, res: Optional[Resolution] = None, rendering_mask: Optional[Tensor] = None,
+               fov: Optional[float] = None, waypoints: Optional[Tensor] = None, waypoints_rendering_mask: Optional[Tensor] = None,
+               custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False) -> Tensor:
+        """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992)."""
+        if waypoints is not None or noisy_perception:
+            raise NotImplementedError('waypoints / noisy perception are outside the scope of torchdrivesim_amd')
+        camera_sc = torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
+        if camera_xy.dim() == 2:
+            camera_xy, camera_sc = camera_xy.unsqueeze(1), camera_sc.unsqueeze(1)
+        n_cam = camera_xy.shape[-2]
+        present = self.get_all_agent_present_mask()
+        mask = present.unsqueeze(-2).expand(present.shape[:-1] + (n_cam,) + present.shape[-1:])
+        if rendering_mask is not None:
+            mask = mask.logical_and(rendering_mask.to(torch.bool))
+        if isinstance(self.renderer, HipRenderer):
+            scene = self._scene()
+            state = self.get_all_agent_state().detach()
+            agent_sc = _ops.heading_sc(state[..., 2])
+            out = []
+            for (smap, b), keys in zip(scene['maps'], scene['keys']):
+                sl = slice(None) if b is None else slice(b, b + 1)
+                k = keys[sl]
+                if custom_agent_colors is not None:
+                    raise NotImplementedError('custom_agent_colors: per-camera colours are not wired into the fused path yet')
+                out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], scene['tmpl'][sl], k, mask[sl].contiguous(),
+                                                      camera_xy[sl].detach(), camera_sc[sl].detach(), res=res, fov=fov))
+            return out[0] if len(out) == 1 else torch.cat(out, dim=0)
+        # any other BirdviewRenderer: the reference's generic dataflow (explicit per-camera mesh)
+        rgb_mesh = self.birdview_mesh_generator.generate(n_cam, agent_state=self.get_all_agent_state()[:, None].expand(-1, n_cam, -1, -1),
+                                                         present_mask=mask, custom_agent_colors=custom_agent_colors)
+        img = self.renderer.render_frame(rgb_mesh, camera_xy, camera_sc, res=res, fov=fov)
+        return img.reshape((self.batch_size, n_cam) + img.shape[1:])
+
+    def render_egocentric(self, ego_rotate: bool = True, res: Optional[Resolution] = None, fov: Optional[float] = None,
+                          visibility_matrix: Optional[Tensor] = None, custom_agent_colors: Optional[Tensor] = None,
+                          n_subsequent_waypoints: int = 1, noisy_perception: bool = False) -> Tensor:
+        """One camera per exposed agent -> BxAx3xHxW (simulator.py:994-1033)."""
+        state = self.get_state()
+        camera_xy, camera_psi = state[..., :2], state[..., 2:3]
+        if not ego_rotate:
+            camera_psi = torch.ones_like(camera_psi) * (np.pi / 2)
+        rendering_mask = visibility_matrix
+        if self.cfg.single_agent_rendering:
+            # the reference builds eye(2) here regardless of A; the intended eye(A) over all agents is used
+            A, total = self.agent_count, self.agent_count + self.npc_count
+            rendering_mask = torch.eye(A, total, dtype=torch.bool, device=state.device).unsqueeze(0).expand(self.batch_size, -1, -1)
+        return self.render(camera_xy, camera_psi, rendering_mask=rendering_mask, res=res, fov=fov, custom_agent_colors=custom_agent_colors,
+                           noisy_perception=noisy_perception)
+
+    # ------------------------------------------------------------------------------------------------- infractions
+    def compute_offroad(self) -> Tensor:
+        """BxA off-road loss = thresholded squared corner-to-mesh distance x present (simulator.py:1035-1044).
+        The whole road_mesh is the driving surface, lane markings included."""
+        state = self.get_state()
+        if self.agent_count == 0 or self.road_mesh.faces_count == 0:
+            return torch.zeros_like(state[..., 0])
+        if isinstance(self.renderer, HipRenderer):
+            maps = self._scene()['maps']                 # the raster map holds the same triangles
+        else:
+            from torchdrivesim_amd.infractions import _static_maps_for
+            maps = _static_maps_for(self.road_mesh, state.device)
+        size, present = self.get_agent_size(), self.get_present_mask()
+        out = []
+        for smap, b in maps:
+            sl = slice(None) if b is None else slice(b, b + 1)
+            out.append(_ops.offroad(smap, state[sl], size[sl], threshold=self.cfg.offroad_threshold, present=present[sl]))
+        return out[0] if len(out) == 1 else torch.cat(out, dim=0)
+
+    def compute_wrong_way(self) -> Tensor:
+        """Zeros without a lanelet map, as the reference (simulator.py:607-630)."""
+        state = self.get_state()
+        return torch.zeros(state.shape[0], state.shape[1], device=state.device)
+
+    def compute_traffic_lights_violations(self) -> Tensor:
+        state = self.get_state()
+        return torch.zeros(state.shape[0], state.shape[1], dtype=torch.bool, device=state.device)
+
+    def _all_boxes(self):
+        states, sizes = self.get_all_agent_state(), self.get_all_agent_size()
+        return torch.cat([states[..., :2], sizes, states[..., 2:3]], dim=-1)
+
+    def _collision_mask(self, agent_types: Optional[List[str]]):
+        mask = self.get_all_agent_present_mask()
+        if agent_types is not None:
+            allowed = torch.tensor([self.agent_types.index(t) for t in agent_types if t in self.agent_types], device=mask.device)
+            mask = mask.logical_and(torch.isin(self.get_all_agent_type(), allowed))
+        return mask
+
+    def compute_collision(self, agent_types: Optional[List[str]] = None) -> Tensor:
+        """BxA collision metric of the exposed agents against ALL agents (simulator.py:1161-1194).  For `iou` / `discs`:
+        collision_i = sum_j o_ij present_j - max_j o_ij present_j, self overlap assumed to be the max."""
+        metric = self.cfg.collision_metric
+        A = self.agent_count
+        if A == 0:
+            return torch.zeros_like(self.get_state()[..., 0])
+        if metric in (CollisionMetric.iou, CollisionMetric.discs):
+            return _ops.collision(self._all_boxes(), self._collision_mask(agent_types), n_exposed=A, metric=metric.value)
+        if metric == CollisionMetric.nograd:
+            assert agent_types is None, 'The argument `agent_types` is not supported by the selected collision metric.'
+            # count of other present exposed agents whose rectangle overlaps (simulator.py:1111-1149, shapely); here the
+            # overlap flags of the IoU kernel (touching rectangles do not count; parity unpinned -- shapely is absent)
+            state, size, present = self.get_state().detach(), self.get_agent_size(), self.get_present_mask()
+            boxes = torch.cat([state[..., :2], size, state[..., 2:3]], dim=-1)
+            if A > 64:
+                raise NotImplementedError('nograd metric: overlap bit masks support up to 64 agents')
+            _, bits, _ = _ops.collision_forward(boxes, _ops.metric_sc(torch.nan_to_num(boxes, nan=0.0), 'iou'), present, A, 'iou', want_overlap=True)
+            shifts = torch.arange(A, device=bits.device)
+            counts = ((bits.unsqueeze(-1) >> shifts) & 1).sum(-1)
+            return (counts * present).to(torch.float64)
+        raise ValueError('Unrecognized collision metric: ' + str(metric))
