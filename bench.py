@@ -88,8 +88,8 @@ def cpu_baseline(host, n_scenes, A):
     for label, threads in (('all', cores), ('one', 1)):
         orc.set_num_threads(threads)
         if threads == 1:
-            state, size, present, act, lr = state[:1], size[:1], present[:1], act[:1], lr[:1]      # 1 scene for the scalar run
-            n_scenes = 1
+            n_scenes = min(4, n_scenes)                                                            # bounded scalar run
+            state, size, present, act, lr = state[:n_scenes], size[:n_scenes], present[:n_scenes], act[:n_scenes], lr[:n_scenes]
         t0 = time.perf_counter()
         one_step()
         dt = time.perf_counter() - t0
@@ -97,7 +97,7 @@ def cpu_baseline(host, n_scenes, A):
     orc.set_num_threads(cores)
     return dict(value=out['all'][0], unit='agent-steps/s', cores=cores, kind='port',
                 sample=f"{out['all'][2]} scenes x {A} agents, 1 step of the same workload (oracle/tds_oracle.c, OpenMP over images) in "
-                       f"{out['all'][1]:.1f} s; single thread: {out['one'][0]:.1f} agent-steps/s on {out['one'][2]} scene ({out['one'][1]:.1f} s)",
+                       f"{out['all'][1]:.2f} s; single thread: {out['one'][0]:.1f} agent-steps/s on {out['one'][2]} scenes ({out['one'][1]:.2f} s)",
                 value_single_thread=out['one'][0])
 
 
@@ -109,7 +109,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='scenes per GPU')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-scenes', type=int, default=4)
+    ap.add_argument('--cpu-scenes', type=int, default=64, help='scenes of the CPU-baseline sample (all cores); the single-thread run uses 4')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -130,16 +130,12 @@ def main():
     from torchdrivesim_amd.utils import Resolution
     res = Resolution(RES, RES)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    from torchdrivesim_amd import _ops
     sink = {}
 
-    def step(i, timed_idx=None):
+    def step(i):
         sim.step(actions[i % actions.shape[0]])
-        if timed_idx is not None:
-            ev[timed_idx][0].record()
         sink['img'] = sim.render_egocentric(res=res, fov=FOV)
-        if timed_idx is not None:
-            ev[timed_idx][1].record()
         sink['col'] = sim.compute_collision()
         sink['off'] = sim.compute_offroad()
 
@@ -151,16 +147,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    _ops.raster_events = []             # HIP events around every raster launch of the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, timed_idx=i)
+        step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    raster_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float('nan')
+    raster_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else float('nan')
+    _ops.raster_events = None
 
     if rank == 0:
         value = world * B * A * args.steps / elapsed

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Runs only the K3 raster kernel on the bench workload (for rocprofv3 and for ablations).
+   python tools/profile_raster.py [--batch 256] [--iters 5] [--tw 0] [--debug 0] [--u8]"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--agents', type=int, default=64)
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--tw', type=int, nargs='*', default=[0])
+    ap.add_argument('--debug', type=int, nargs='*', default=[0])
+    ap.add_argument('--u8', action='store_true')
+    ap.add_argument('--steps-before', type=int, default=5, help='simulation steps before rendering (spreads the agents)')
+    args = ap.parse_args()
+    from torchdrivesim_amd import _native, _ops
+    from torchdrivesim_amd.utils import Resolution
+    dev = torch.device('cuda', 0)
+    sim, actions, _ = bench.build_simulator(args.batch, args.agents, dev, seed=1234)
+    if args.u8:
+        sim.renderer.cfg.out_dtype = 'uint8'
+    for i in range(args.steps_before):
+        sim.step(actions[i % 8])
+    res = Resolution(bench.RES, bench.RES)
+    L = _native.lib()
+    L.tds_raster_set_debug.argtypes = [ctypes.c_int]
+    img = sim.render_egocentric(res=res, fov=bench.FOV)
+    torch.cuda.synchronize()
+    nbytes = img.numel() * img.element_size()
+    print(f'images {img.shape[0] * img.shape[1]}, output {nbytes / 1e9:.2f} GB, nonzero fraction {(img[:8] > 0).float().mean().item():.3f}')
+    del img
+    for tw in args.tw:
+        for dbg in args.debug:
+            L.tds_raster_set_strip_width(tw)
+            L.tds_raster_set_debug(dbg)
+            _ops.raster_events = []
+            for _ in range(args.iters):
+                sim.render_egocentric(res=res, fov=bench.FOV)
+            torch.cuda.synchronize()
+            ms = np.array([a.elapsed_time(b) for a, b in _ops.raster_events])
+            _ops.raster_events = None
+            print(f'tw={tw:2d} debug={dbg:2d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
+                  f'({nbytes / np.median(ms) / 1e6 / 80:.1f}% of 8 TB/s)')
+    L.tds_raster_set_strip_width(0)
+    L.tds_raster_set_debug(0)
+
+
+if __name__ == '__main__':
+    main()

@@ -308,6 +308,9 @@ def offroad(smap, state, lenwid, threshold=0.5, present=None, sc=None):
 # ---------------------------------------------------------------------------------------------------------------
 # K3 rasteriser
 # ---------------------------------------------------------------------------------------------------------------
+#: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
+raster_events = None
+
 def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None):
     """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns,
     mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2) -> (B,Nc,3,res,res) float32 [0,255] or uint8."""
@@ -325,10 +328,17 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     else:
         assert out.shape == (B, Nc, 3, res, res) and out.dtype == out_dtype and out.is_contiguous()
     p = lambda t, d, nme: nat.dev_ptr(t, d, nme) if N > 0 else None
+    ev = None
+    if raster_events is not None:          # bench.py: HIP events on the launch stream, right around the kernel
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(dev))
     nat.call('tds_raster_scene', dev, smap.handle, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
              p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
              B, Nc, N, float(2.0 / fov), int(res), nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8,
              nat.dev_ptr(out, out_dtype, 'out'), nat.stream_ptr(dev))
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(dev))
+        raster_events.append(ev)
     return out
 
 

@@ -54,6 +54,8 @@ struct CommonArgs {
     int strips;
     int64_t n_img;
     void *out;
+    int debug;                  // ablation switches for profiling (tds_raster_set_debug): 1 no static, 2 no actors, 4 no store,
+                                // 8 no outline edges, 16 no scan conversion
 };
 
 struct Camera {
@@ -240,6 +242,7 @@ struct WaveCtx {
     int qlen;           // wave-uniform
     int lane;
     int H, W, X0;
+    int debug;
 };
 
 __device__ inline void wave_sync() {
@@ -289,7 +292,7 @@ __device__ void process_batch(WaveCtx &w, int n) {
     int total = __shfl(incl, 63);
     wave_sync();
     // (face, row) items
-    for (int t0 = 0; t0 < total; t0 += 64) {
+    for (int t0 = 0; t0 < total && !(w.debug & 16); t0 += 64) {
         int t = t0 + lane;
         if (t < total) {
             int lo = 0, hi = 63;                       // smallest f with pref[f] > t
@@ -320,7 +323,7 @@ __device__ void process_batch(WaveCtx &w, int n) {
         }
     }
     // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2) before the scan conversion
-    for (int t0 = 0; t0 < 3 * n; t0 += 64) {
+    for (int t0 = 0; t0 < 3 * n && !(w.debug & 8); t0 += 64) {
         int t = t0 + lane;
         if (t < 3 * n) {
             int f = t / 3, l = t - 3 * f;
@@ -448,7 +451,7 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
     w.q = smem + TW * H + wave * WAVE_LDS_DW;
     w.par = (int *)(w.q + Q_DW);
     w.pref = w.par + NPAR * 64;
-    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.debug = c.debug;
 
     Camera cam;
     {
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
 
     const int64_t b = img / a.Nc;
     // ---- actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction)
-    if (a.N > 0) {
+    if (a.N > 0 && !(c.debug & 2)) {
         // vertex 0 of agent 0: every face of a masked agent collapses onto it (mesh.py:1083-1089 + concat offsets)
         float p0x, p0y;
         {
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
         }
     }
     // ---- static map: grid cells under this strip
-    if (a.map.nx > 0) {
+    if (a.map.nx > 0 && !(c.debug & 1)) {
         const MapView &m = a.map;
         // world-space bounding box of the strip (2 px margin: int truncation moves a vertex by < 1 px)
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
     }
     if (w.qlen > 0) process_batch<TW>(w, w.qlen);
     __syncthreads();
-    write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+    if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
 // Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
@@ -586,7 +589,7 @@ __global__ void __launch_bounds__(RBLOCK) raster_mesh_kernel(MeshArgs a, CommonA
     w.q = smem + TW * H + wave * WAVE_LDS_DW;
     w.par = (int *)(w.q + Q_DW);
     w.pref = w.par + NPAR * 64;
-    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.debug = c.debug;
     Camera cam;
     {
         float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
@@ -640,6 +643,7 @@ inline int pick_tw(int res) {
 }
 
 int g_force_tw = 0;
+int g_debug = 0;
 
 }  // namespace
 
@@ -647,6 +651,12 @@ int g_force_tw = 0;
 TDS_EXPORT int tds_raster_set_strip_width(int tw) {
     TDS_CHECK_ARG(tw == 0 || tw == 8 || tw == 16 || tw == 32 || tw == 64, "strip width must be 0, 8, 16, 32 or 64");
     g_force_tw = tw;
+    return TDS_OK;
+}
+
+// profiling hook (not part of include/tdship.h): ablation switches, see CommonArgs::debug
+TDS_EXPORT int tds_raster_set_debug(int flags) {
+    g_debug = flags;
     return TDS_OK;
 }
 
@@ -697,7 +707,7 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
     a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
     TDS_LAUNCH_RASTER(raster_scene_kernel, a);
     TDS_LAUNCH_CHECK("raster_scene_kernel");
     return TDS_OK;
@@ -721,7 +731,7 @@ TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int
     for (int i = 1; i < n_levels; ++i) TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_raster_mesh: levels must be strictly descending");
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
     TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
     TDS_LAUNCH_CHECK("raster_mesh_kernel");
     return TDS_OK;

@@ -523,11 +523,8 @@ class Simulator:
         state = self.get_state()
         if self.agent_count == 0 or self.road_mesh.faces_count == 0:
             return torch.zeros_like(state[..., 0])
-        if isinstance(self.renderer, HipRenderer):
-            maps = self._scene()['maps']                 # the raster map holds the same triangles
-        else:
-            from torchdrivesim_amd.infractions import _static_maps_for
-            maps = _static_maps_for(self.road_mesh, state.device)
+        from torchdrivesim_amd.infractions import _static_maps_for
+        maps = _static_maps_for(self.road_mesh, state.device)      # geometry-only device map(s), cached on the mesh
         size, present = self.get_agent_size(), self.get_present_mask()
         out = []
         for smap, b in maps:
