@@ -22,11 +22,13 @@ namespace {
 
 constexpr int RWAVES = 4;
 constexpr int RBLOCK = RWAVES * 64;
-constexpr int QCAP = 128;                         // per-wave face queue (entries)
-constexpr int Q_DW = 7 * QCAP;                    // key + 6 pixel coordinates
-constexpr int NPAR = 17;                          // scan-conversion record, dwords per face
-constexpr int WAVE_LDS_DW = Q_DW + NPAR * 64 + 64;   // + inclusive prefix of rows
+constexpr int QCAP = 64;                          // per-wave face queue (entries): key + 3 packed vertices
+constexpr int Q_DW = 4 * QCAP;
+constexpr int ROWS_PER_BLOCK = 8;                 // taller faces are scan-converted in blocks of this many rows
+constexpr int BLOCK_CAP = 256;                    // per-wave list of (face, block) pairs
+constexpr int WAVE_LDS_DW = Q_DW + BLOCK_CAP;
 constexpr int NO_SWITCH = 0x7fffffff;
+constexpr int COORD_LIMIT = 16000;                // |pixel coordinate| below this: int16 packing and int32 16.16 slopes are exact
 
 struct SceneArgs {
     MapView map;
@@ -129,11 +131,18 @@ __device__ inline long long div_trunc(long long n, long long d) {
 // ---------------------------------------------------------------------------------------------------------
 // OpenCV FillConvexPoly (shift 0, 8-connected) for a triangle, in closed form per row
 // ---------------------------------------------------------------------------------------------------------
-struct Chain { int xs1; long long dx1; int ysw; int xs2; long long dx2; };
+struct Chain { int xs1; int dx1; int ysw; int xs2; int dx2; };     // slopes fit int32 for |dx| < 2^15 pixels
 
-__device__ inline long long edge_dx(int xs, int xe, int dyy) {
-    long long D = ((long long)(xe - xs) << 17) + dyy;          // ((xe-xs)*2 + (ty-y)) with x in 16.16
-    return div_trunc(D, 2ll * dyy);
+// OpenCV's edge slope ((xe - xs) * 2 + dy) / (2 * dy) in 16.16 fixed point, C truncating division.
+// With N = (xe - xs) << 16 this is trunc(N / dy + 1/2); for |xe - xs| < 2^15 it needs one 32-bit unsigned division:
+//   N >= 0: a + (2 r >= dy);   N < 0: 0 if 2|N| <= dy else -(a - (2 r < dy)),   a, r = divmod(|N|, dy)
+__device__ inline int edge_dx(int xs, int xe, int dyy) {
+    int N = (xe - xs) << 16;
+    unsigned Na = (unsigned)abs(N), d = (unsigned)dyy;
+    unsigned a = Na / d, r = Na - a * d;
+    if (N >= 0) return (int)(a + ((2u * r >= d) ? 1u : 0u));
+    if (2u * Na <= d) return 0;
+    return -(int)(a - ((2u * r < d) ? 1u : 0u));
 }
 
 // chain visiting a0 -> a1 -> a2 (a0 = first top vertex)
@@ -157,12 +166,12 @@ __device__ inline Chain make_chain(const int *px, const int *py, int a0, int a1,
     return c;
 }
 
-__device__ inline long long chain_x(int xs1, long long dx1, int ysw, int xs2, long long dx2, int ymin, int y) {
+__device__ inline long long chain_x(int xs1, int dx1, int ysw, int xs2, int dx2, int ymin, int y) {
     bool second = y >= ysw;
     long long x0 = (long long)(second ? xs2 : xs1) << 16;
-    long long dx = second ? dx2 : dx1;
+    int dx = second ? dx2 : dx1;
     int y0 = second ? ysw : ymin;
-    return x0 + (long long)(y - y0) * dx;
+    return x0 + (long long)(y - y0) * (long long)dx;
 }
 
 // cv::clipLine on int64 (drawing.cpp); returns false if nothing is left
@@ -236,9 +245,8 @@ __device__ inline void draw_line(uint32_t *tile, int H, int W, int X0, int ax, i
 // ---------------------------------------------------------------------------------------------------------
 struct WaveCtx {
     uint32_t *tile;
-    uint32_t *q;        // [7][QCAP]
-    int *par;           // [NPAR][64]
-    int *pref;          // [64]
+    uint32_t *q;        // [4][QCAP]: key, then the three vertices packed as (x & 0xffff) | y << 16
+    uint32_t *blocks;   // [BLOCK_CAP]: face | block << 8
     int qlen;           // wave-uniform
     int lane;
     int H, W, X0;
@@ -250,76 +258,162 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+__device__ inline uint32_t pack_xy(int x, int y) { return ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16); }
+__device__ inline int unpack_x(uint32_t p) { return (int)(short)(p & 0xffffu); }
+__device__ inline int unpack_y(uint32_t p) { return (int)p >> 16; }
+
+// Faces whose pixel coordinates do not fit the packed fast path (|coord| >= COORD_LIMIT): the sequential OpenCV
+// algorithm executed by a single lane, painting only the strip.  Practically never taken (a vertex more than 16000
+// pixels away from the image), kept so that the result is exact for any input.
 template <int TW>
-__device__ void process_batch(WaveCtx &w, int n) {
-    const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0;
-    wave_sync();
-    int nrows = 0;
-    if (lane < n) {
-        uint32_t key = w.q[lane];
-        int px[3], py[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { px[k] = (int)w.q[(1 + 2 * k) * QCAP + lane]; py[k] = (int)w.q[(2 + 2 * k) * QCAP + lane]; }
-        int ymin = py[0], ymax = py[0], xmin = px[0], xmax = px[0], imin = 0;
-#pragma unroll
-        for (int k = 1; k < 3; ++k) {
-            if (py[k] < ymin) { ymin = py[k]; imin = k; }
-            ymax = max(ymax, py[k]); xmin = min(xmin, px[k]); xmax = max(xmax, px[k]);
-        }
-        int ystart = max(ymin, 0), yend = min(ymax - 1, H - 1);
-        bool scan = !(xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) && (xmax >= X0) && (xmin < X0 + TW);
-        nrows = scan ? max(0, yend - ystart + 1) : 0;
-        if (nrows > 0) {
-            int i1 = imin == 2 ? 0 : imin + 1, i2 = imin == 0 ? 2 : imin - 1;
-            Chain a = make_chain(px, py, imin, i1, i2);
-            Chain b = make_chain(px, py, imin, i2, i1);
-            int *p = w.par + lane;
-            p[0 * 64] = (int)key; p[1 * 64] = ymin; p[2 * 64] = ystart;
-            p[3 * 64] = a.xs1; p[4 * 64] = (int)(a.dx1 & 0xffffffffll); p[5 * 64] = (int)(a.dx1 >> 32);
-            p[6 * 64] = a.ysw; p[7 * 64] = a.xs2; p[8 * 64] = (int)(a.dx2 & 0xffffffffll); p[9 * 64] = (int)(a.dx2 >> 32);
-            p[10 * 64] = b.xs1; p[11 * 64] = (int)(b.dx1 & 0xffffffffll); p[12 * 64] = (int)(b.dx1 >> 32);
-            p[13 * 64] = b.ysw; p[14 * 64] = b.xs2; p[15 * 64] = (int)(b.dx2 & 0xffffffffll); p[16 * 64] = (int)(b.dx2 >> 32);
-        }
+__device__ __noinline__ void fill_generic(uint32_t *tile, int H, int W, int X0, int x0, int y0, int x1, int y1, int x2, int y2, uint32_t key) {
+    const int px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+    draw_line<TW>(tile, H, W, X0, px[2], py[2], px[0], py[0], key);
+    draw_line<TW>(tile, H, W, X0, px[0], py[0], px[1], py[1], key);
+    draw_line<TW>(tile, H, W, X0, px[1], py[1], px[2], py[2], key);
+    long long xmin = px[0], xmax = px[0], ymin = py[0], ymax = py[0];
+    int imin = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (py[i] < ymin) { ymin = py[i]; imin = i; }
+        if (py[i] > ymax) ymax = py[i];
+        if (px[i] > xmax) xmax = px[i];
+        if (px[i] < xmin) xmin = px[i];
     }
-    // inclusive prefix of row counts across the wave
-    int incl = nrows;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
-    w.pref[lane] = incl;
-    int total = __shfl(incl, 63);
-    wave_sync();
-    // (face, row) items
-    for (int t0 = 0; t0 < total && !(w.debug & 16); t0 += 64) {
-        int t = t0 + lane;
-        if (t < total) {
-            int lo = 0, hi = 63;                       // smallest f with pref[f] > t
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                int mid = (lo + hi) >> 1;
-                bool go = w.pref[mid] > t;
-                hi = go ? mid : hi;
-                lo = go ? lo : mid + 1;
+    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    if (ymax > H - 1) ymax = H - 1;
+    int eidx[2] = {imin, imin}, edi[2] = {1, 2}, eye[2] = {(int)ymin, (int)ymin};
+    long long ex[2] = {-65536, -65536}, edx[2] = {0, 0};
+    int edges = 3, y = (int)ymin;
+    do {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= eye[i]) {
+                int idx0 = eidx[i], idx = idx0 + edi[i];
+                if (idx >= 3) idx -= 3;
+                for (; edges-- > 0;) {
+                    int ty = py[idx];
+                    if (ty > y) {
+                        long long xs = (long long)px[idx0] << 16, xe = (long long)px[idx] << 16;
+                        eye[i] = ty;
+                        edx[i] = div_trunc((xe - xs) * 2 + (ty - y), 2ll * (ty - y));
+                        ex[i] = xs;
+                        eidx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += edi[i];
+                    if (idx >= 3) idx -= 3;
+                }
             }
-            int f = lo;
-            int excl = f > 0 ? w.pref[f - 1] : 0;
-            const int *p = w.par + f;
-            uint32_t key = (uint32_t)p[0 * 64];
-            int ymin = p[1 * 64];
-            int y = p[2 * 64] + (t - excl);
-            auto ll = [](int lo32, int hi32) { return (long long)(((unsigned long long)(unsigned)hi32 << 32) | (unsigned)lo32); };
-            long long xa = chain_x(p[3 * 64], ll(p[4 * 64], p[5 * 64]), p[6 * 64], p[7 * 64], ll(p[8 * 64], p[9 * 64]), ymin, y);
-            long long xb = chain_x(p[10 * 64], ll(p[11 * 64], p[12 * 64]), p[13 * 64], p[14 * 64], ll(p[15 * 64], p[16 * 64]), ymin, y);
-            long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            long long xl = ex[0] < ex[1] ? ex[0] : ex[1], xr = ex[0] < ex[1] ? ex[1] : ex[0];
             long long xx1 = (xl + 32768) >> 16, xx2 = (xr + 32768) >> 16;
             if (xx2 >= 0 && xx1 < W) {
                 int s0 = (int)(xx1 < 0 ? 0 : xx1), s1 = (int)(xx2 >= W ? W - 1 : xx2);
                 s0 = max(s0, X0); s1 = min(s1, X0 + TW - 1);
-                uint32_t *row = w.tile + y;
-                for (int x = s0; x <= s1; ++x) atomicMax(&row[(x - X0) * H], key);
+                for (int x = s0; x <= s1; ++x) atomicMax(&tile[(x - X0) * H + y], key);
             }
+        }
+        ex[0] += edx[0];
+        ex[1] += edx[1];
+    } while (++y <= (int)ymax);
+}
+
+// scan-convert rows [y0, y1] of one triangle into the strip (closed form of OpenCV's FillConvexPoly row loop:
+// x(y) = xs + (y - y_edge_start) * dx in 16.16, evaluated once and then stepped like OpenCV does)
+template <int TW>
+__device__ inline void paint_rows(uint32_t *tile, int H, int W, int X0, const Chain &a, const Chain &b, int ymin, int y0, int y1,
+                                  uint32_t key) {
+    long long xa = chain_x(a.xs1, a.dx1, a.ysw, a.xs2, a.dx2, ymin, y0);
+    long long xb = chain_x(b.xs1, b.dx1, b.ysw, b.xs2, b.dx2, ymin, y0);
+    int da = y0 >= a.ysw ? a.dx2 : a.dx1, db = y0 >= b.ysw ? b.dx2 : b.dx1;
+    for (int y = y0; y <= y1; ++y) {
+        long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+        int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+        if (xx2 >= 0 && xx1 < W) {
+            int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TW - 1);
+            uint32_t *p = tile + (s0 - X0) * H + y;
+            for (int x = s0; x <= s1; ++x, p += H) atomicMax(p, key);
+        }
+        xa += da; xb += db;
+        if (y + 1 == a.ysw) { xa = (long long)a.xs2 << 16; da = a.dx2; }      // the chain switches to its second edge
+        if (y + 1 == b.ysw) { xb = (long long)b.xs2 << 16; db = b.dx2; }
+    }
+}
+
+struct FaceRows { int ymin, ystart, nrows, imin; };
+
+__device__ inline FaceRows face_rows(const int *px, const int *py, int H, int W, int X0, int TW) {
+    FaceRows r;
+    int ymax = py[0], xmin = px[0], xmax = px[0];
+    r.ymin = py[0]; r.imin = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        if (py[k] < r.ymin) { r.ymin = py[k]; r.imin = k; }
+        ymax = max(ymax, py[k]); xmin = min(xmin, px[k]); xmax = max(xmax, px[k]);
+    }
+    r.ystart = max(r.ymin, 0);
+    int yend = min(ymax - 1, H - 1);              // the row of the bottom vertex is never scan-converted (edges run out)
+    bool scan = !(xmax < 0 || ymax < 0 || xmin >= W || r.ymin >= H) && (xmax >= X0) && (xmin < X0 + TW);
+    r.nrows = scan ? max(0, yend - r.ystart + 1) : 0;
+    return r;
+}
+
+// Rasterise the first n (<= 64) faces of the wave's queue.
+//   1. lane f looks at face f; faces of at most ROWS_PER_BLOCK rows are scan-converted right away by their lane
+//      (everything stays in registers; the bulk of a road map is lane-marking slivers of a few pixels);
+//   2. taller faces are cut into blocks of ROWS_PER_BLOCK rows; the blocks are numbered by a wave prefix sum, their
+//      owners write (face, block) pairs into an LDS list, and the wave paints one block per lane -- balanced whatever
+//      the face sizes; the edge set-up is recomputed per block from the packed vertices instead of being staged in LDS;
+//   3. the three outline edges of every face (Bresenham with OpenCV's clipLine), one edge per lane.
+template <int TW>
+__device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
+    const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0;
+    wave_sync();
+    int nblocks = 0;
+    if (lane < n && !(w.debug & 16)) {
+        uint32_t key = w.q[lane];
+        int px[3], py[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { uint32_t p = w.q[(1 + k) * QCAP + lane]; px[k] = unpack_x(p); py[k] = unpack_y(p); }
+        FaceRows r = face_rows(px, py, H, W, X0, TW);
+        if (r.nrows > ROWS_PER_BLOCK) {
+            nblocks = (r.nrows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+        } else if (r.nrows > 0) {
+            int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
+            Chain a = make_chain(px, py, r.imin, i1, i2), b = make_chain(px, py, r.imin, i2, i1);
+            paint_rows<TW>(w.tile, H, W, X0, a, b, r.ymin, r.ystart, r.ystart + r.nrows - 1, key);
+        }
+    }
+    if (__ballot(nblocks > 0) != 0) {
+        int incl = nblocks;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const int excl = incl - nblocks;
+        const int total = __shfl(incl, 63);
+        for (int base = 0; base < total; base += BLOCK_CAP) {
+            int lo = max(excl, base), hi = min(incl, base + BLOCK_CAP);
+            for (int idx = lo; idx < hi; ++idx) w.blocks[idx - base] = (uint32_t)lane | ((uint32_t)(idx - excl) << 8);
+            wave_sync();
+            int m = min(BLOCK_CAP, total - base);
+            for (int i = lane; i < m; i += 64) {
+                uint32_t e = w.blocks[i];
+                int f = e & 0xff, blk = e >> 8;
+                uint32_t key = w.q[f];
+                int px[3], py[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { uint32_t p = w.q[(1 + k) * QCAP + f]; px[k] = unpack_x(p); py[k] = unpack_y(p); }
+                FaceRows r = face_rows(px, py, H, W, X0, TW);
+                int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
+                Chain a = make_chain(px, py, r.imin, i1, i2), b = make_chain(px, py, r.imin, i2, i1);
+                int y0 = r.ystart + blk * ROWS_PER_BLOCK, y1 = min(y0 + ROWS_PER_BLOCK, r.ystart + r.nrows) - 1;
+                paint_rows<TW>(w.tile, H, W, X0, a, b, r.ymin, y0, y1, key);
+            }
+            wave_sync();
         }
     }
     // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2) before the scan conversion
@@ -328,55 +422,23 @@ __device__ void process_batch(WaveCtx &w, int n) {
         if (t < 3 * n) {
             int f = t / 3, l = t - 3 * f;
             int ia = l == 0 ? 2 : l - 1, ib = l;
-            uint32_t key = w.q[f];
-            int ax = (int)w.q[(1 + 2 * ia) * QCAP + f], ay = (int)w.q[(2 + 2 * ia) * QCAP + f];
-            int bx = (int)w.q[(1 + 2 * ib) * QCAP + f], by = (int)w.q[(2 + 2 * ib) * QCAP + f];
-            draw_line<TW>(w.tile, H, W, X0, ax, ay, bx, by, key);
+            uint32_t k2 = w.q[f], pa = w.q[(1 + ia) * QCAP + f], pb = w.q[(1 + ib) * QCAP + f];
+            draw_line<TW>(w.tile, H, W, X0, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb), k2);
         }
     }
     wave_sync();
-    // move the tail of the queue to the front
-    int rest = w.qlen - n;
-    uint32_t tmp[7];
-    if (lane < rest) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) tmp[k] = w.q[k * QCAP + n + lane];
-    }
-    wave_sync();
-    if (lane < rest) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) w.q[k * QCAP + lane] = tmp[k];
-    }
-    w.qlen = rest;
 }
 
-// wave-collective append of the faces flagged `accept`
-template <int TW>
-__device__ inline void enqueue(WaveCtx &w, bool accept, uint32_t key, const int *px, const int *py) {
-    unsigned long long bal = __ballot(accept);
-    int cnt = __popcll(bal);
-    if (cnt == 0) return;
-    if (accept) {
-        int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-        int slot = w.qlen + rank;
-        w.q[slot] = key;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { w.q[(1 + 2 * k) * QCAP + slot] = (uint32_t)px[k]; w.q[(2 + 2 * k) * QCAP + slot] = (uint32_t)py[k]; }
-    }
-    w.qlen += cnt;
-    if (w.qlen >= 64) process_batch<TW>(w, 64);
-}
-
-// trim (>= 1 vertex inside the 1.05x view), project, reject faces whose pixel bounding box misses the strip
+// project (fp32, reference order) -> reject faces whose pixel bounding box misses the strip -> trim test
+// (>= 1 vertex inside the 1.05x view polygon, cv2.py:32-41).  The cheap exact rejection comes first.
 __device__ inline bool trim_project(const Camera &cam, float scale, int res, int X0, int TW, const float *sx, const float *sy,
                                     int *px, int *py) {
-    bool any = inside_polygon(cam, sx[0], sy[0]) || inside_polygon(cam, sx[1], sy[1]) || inside_polygon(cam, sx[2], sy[2]);
-    if (!any) return false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) project(cam, scale, res, sx[k], sy[k], px[k], py[k]);
     int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
     int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
-    return !(xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res);
+    if (xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res) return false;
+    return inside_polygon(cam, sx[0], sy[0]) || inside_polygon(cam, sx[1], sy[1]) || inside_polygon(cam, sx[2], sy[2]);
 }
 
 template <int TW, typename OutT>
@@ -434,92 +496,84 @@ __device__ inline void block_to_image(int64_t nblk, int strips, int64_t &img, in
     strip = (int)(L - img * strips);
 }
 
-template <int TW, typename OutT>
-__global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, CommonArgs c) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int res = c.res, H = res, W = res;
-    int64_t img;
-    int strip;
-    block_to_image(c.n_img * c.strips, c.strips, img, strip);
-    const int X0 = strip * TW;
-    uint32_t *tile = smem;
-    for (int i = tid * 4; i < TW * H; i += RBLOCK * 4) *(uint4 *)(tile + i) = make_uint4(0, 0, 0, 0);
-
-    WaveCtx w;
-    w.tile = tile;
-    w.q = smem + TW * H + wave * WAVE_LDS_DW;
-    w.par = (int *)(w.q + Q_DW);
-    w.pref = w.par + NPAR * 64;
-    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.debug = c.debug;
-
-    Camera cam;
-    {
-        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
-        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
-        make_polygon(cam, c.scale, res);
+// ---------------------------------------------------------------------------------------------------------
+// kernels.  Each kernel is one loop: a producer step yields at most one candidate face per lane (already projected,
+// known to touch the strip, trimmed); `drain` appends them to the per-wave queue and rasterises a full queue on the spot.
+// There is exactly one inlined copy of process_batch per kernel; all control flow is wave-uniform.
+// ---------------------------------------------------------------------------------------------------------
+template <int TW>
+__device__ __forceinline__ void drain(WaveCtx &w, bool acc, uint32_t key, const int (&px)[3], const int (&py)[3], bool more) {
+    // faces outside the packed coordinate range take the exact sequential path, one lane each
+    bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
+    if (__builtin_expect(__ballot(big) != 0, 0)) {
+        if (big) fill_generic<TW>(w.tile, w.H, w.W, w.X0, px[0], py[0], px[1], py[1], px[2], py[2], key);
+        acc = acc && !big;
     }
+    unsigned long long pending = __ballot(acc);
+    for (;;) {
+        if (pending != 0) {
+            const int room = QCAP - w.qlen;
+            int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pending >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pending, 0));
+            bool take = acc && ((pending >> w.lane) & 1) && rank < room;
+            if (take) {
+                int slot = w.qlen + rank;
+                w.q[slot] = key;
+                w.q[1 * QCAP + slot] = pack_xy(px[0], py[0]);
+                w.q[2 * QCAP + slot] = pack_xy(px[1], py[1]);
+                w.q[3 * QCAP + slot] = pack_xy(px[2], py[2]);
+            }
+            unsigned long long taken = __ballot(take);
+            w.qlen += __popcll(taken);
+            pending &= ~taken;
+        }
+        if (w.qlen == QCAP || (!more && pending == 0 && w.qlen > 0)) {
+            process_batch<TW>(w, w.qlen);
+            w.qlen = 0;
+        }
+        if (pending == 0) break;
+    }
+}
+
+#define TDS_RASTER_PROLOGUE()                                                                                   \
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];                                             \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                              \
+    const int res = c.res, H = res, W = res;                                                                    \
+    int64_t img;                                                                                                \
+    int strip;                                                                                                  \
+    block_to_image(c.n_img * c.strips, c.strips, img, strip);                                                   \
+    const int X0 = strip * TW;                                                                                  \
+    uint32_t *tile = smem;                                                                                      \
+    for (int i = tid * 4; i < TW * H; i += RBLOCK * 4) *(uint4 *)(tile + i) = make_uint4(0, 0, 0, 0);            \
+    WaveCtx w;                                                                                                  \
+    w.tile = tile;                                                                                              \
+    w.q = smem + TW * H + wave * WAVE_LDS_DW;                                                                   \
+    w.blocks = w.q + Q_DW;                                                                                      \
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.debug = c.debug;                                  \
+    Camera cam;                                                                                                 \
+    {                                                                                                           \
+        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];                                                          \
+        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;                                               \
+        make_polygon(cam, c.scale, res);                                                                        \
+    }                                                                                                           \
     __syncthreads();
 
+template <int TW, typename OutT>
+__global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, CommonArgs c) {
+    TDS_RASTER_PROLOGUE()
     const int64_t b = img / a.Nc;
-    // ---- actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction)
-    if (a.N > 0 && !(c.debug & 2)) {
-        // vertex 0 of agent 0: every face of a masked agent collapses onto it (mesh.py:1083-1089 + concat offsets)
-        float p0x, p0y;
-        {
-            float4 s0 = a.state[b * a.N];
-            float2 sc0 = a.agent_sc[b * a.N];
-            float2 t0 = a.tmpl[b * a.N * 7];
-            float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
-            p0x = wx + (-cam.cx); p0y = wy + (-cam.cy);
-        }
-        for (int a0 = wave * 64; a0 < a.N; a0 += RBLOCK) {
-            int ag = a0 + lane;
-            bool live = ag < a.N;
-            float sx[7], sy[7];
-            bool on = false;
-            uint32_t kbody = 0, kdir = 0;
-            if (live) {
-                int64_t ia = b * a.N + ag;
-                float4 s = a.state[ia];
-                float2 sc = a.agent_sc[ia];
-                on = a.mask[img * a.N + ag] != 0;
-                kbody = a.actor_key[2 * ia]; kdir = a.actor_key[2 * ia + 1];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    float2 t = a.tmpl[ia * 7 + k];
-                    float wx = (sc.y * t.x + (-sc.x) * t.y) + s.x;      // utils.transform :82-96
-                    float wy = (sc.x * t.x + sc.y * t.y) + s.y;
-                    sx[k] = wx + (-cam.cx); sy[k] = wy + (-cam.cy);      // mesh.translate(-cameras.xy) cv2.py:29-31
-                }
-            }
-            const int fv[3][3] = {{0, 1, 3}, {1, 3, 2}, {4, 5, 6}};
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                float fx[3], fy[3];
-                int px[3], py[3];
-                uint32_t key = f == 2 ? kdir : kbody;
-                bool use = live && (on || f == 0);
-                if (on) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { fx[k] = sx[fv[f][k]]; fy[k] = sy[fv[f][k]]; }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { fx[k] = p0x; fy[k] = p0y; }
-                    key = a.actor_key[2 * b * a.N];
-                }
-                bool acc = use && trim_project(cam, c.scale, res, X0, TW, fx, fy, px, py);
-                enqueue<TW>(w, acc, key, px, py);
-            }
-        }
-    }
-    // ---- static map: grid cells under this strip
-    if (a.map.nx > 0 && !(c.debug & 1)) {
-        const MapView &m = a.map;
-        // world-space bounding box of the strip (2 px margin: int truncation moves a vertex by < 1 px)
+    const MapView m = a.map;
+    // producer state
+    int phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map, 3 done
+    int a0 = 0, f = 0;
+    bool masked_seen = false, near = false;
+    float sx0 = 0, sx1 = 0, sx2 = 0, sx3 = 0, sx4 = 0, sx5 = 0, sx6 = 0, sy0 = 0, sy1 = 0, sy2 = 0, sy3 = 0, sy4 = 0, sy5 = 0, sy6 = 0;
+    uint32_t kbody = 0, kdir = 0;
+    int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cy = 0, chunk = wave;
+    if (m.nx > 0 && !(c.debug & 1)) {
+        // world-space bounding box of the strip (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell range
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
         const float half = (float)res / 2.0f;
-        const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TW, W) + 2.0f}, pys[2] = {-2.0f, (float)H + 2.0f};
+        const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TW, res) + 2.0f}, pys[2] = {-2.0f, (float)res + 2.0f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -531,43 +585,106 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
         const float eps = 1e-3f + 1e-6f * (fabsf(cam.cx) + fabsf(cam.cy));
         float fx0 = fminf(fmaxf((wx0 - eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx), fx1 = fminf(fmaxf((wx1 + eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx);
         float fy0 = fminf(fmaxf((wy0 - eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny), fy1 = fminf(fmaxf((wy1 + eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny);
-        int sx0 = max((int)floorf(fx0), 0), sx1 = min((int)floorf(fx1), m.nx - 1);
-        int sy0 = max((int)floorf(fy0), 0), sy1 = min((int)floorf(fy1), m.ny - 1);
-        if (sx0 <= sx1 && sy0 <= sy1) {
-            int chunk = wave;       // chunks of 64 consecutive entries, dealt round-robin to the waves
-            for (int cy = sy0; cy <= sy1; ++cy) {
-                // the cells sx0..sx1 of one grid row are one contiguous range of entries
-                const int e0 = m.cell_start[cy * m.nx + sx0], e1 = m.cell_start[cy * m.nx + sx1 + 1];
-                const int first_end = m.cell_start[cy * m.nx + sx0 + 1];
+        cx0 = max((int)floorf(fx0), 0); cx1 = min((int)floorf(fx1), m.nx - 1);
+        cy0 = max((int)floorf(fy0), 0); cy1 = min((int)floorf(fy1), m.ny - 1);
+        cy = cy0;
+        if (cx0 > cx1) cy1 = cy0 - 1;
+    }
+    for (;;) {
+        bool acc = false, more = true;
+        uint32_t key = 0;
+        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+        if (phase == 0) {
+            // actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction).
+            // Agents are dealt to the 4 waves (agent = 4*lane + wave) and culled by distance before anything else is loaded.
+            if (f == 0) {
+                const float view_r = 1.05f * 1.41421356f / c.scale;            // half diagonal of the trim polygon
+                int ag = a0 + lane * RWAVES + wave;
+                near = false;
+                if (ag < a.N) {
+                    int64_t ia = b * a.N + ag;
+                    bool on = a.mask[img * a.N + ag] != 0;
+                    masked_seen = masked_seen || !on;
+                    if (on) {
+                        float4 s = a.state[ia];
+                        float2 t0 = a.tmpl[ia * 7];                          // (l/2, w/2): the farthest template vertex
+                        float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y);
+                        reach = reach * 1.01f + 0.01f;
+                        float ddx = s.x - cam.cx, ddy = s.y - cam.cy;
+                        near = !(ddx * ddx + ddy * ddy > reach * reach);     // NaNs are kept
+                        if (near) {
+                            float2 sc = a.agent_sc[ia];
+                            kbody = a.actor_key[2 * ia]; kdir = a.actor_key[2 * ia + 1];
+                            // utils.transform :82-96, then mesh.translate(-cameras.xy) cv2.py:29-31
+#define TDS_ACTOR_VERT(K)                                                                                                   \
+    { float2 t = a.tmpl[ia * 7 + K];                                                                                        \
+      sx##K = ((sc.y * t.x + (-sc.x) * t.y) + s.x) + (-cam.cx); sy##K = ((sc.x * t.x + sc.y * t.y) + s.y) + (-cam.cy); }
+                            TDS_ACTOR_VERT(0) TDS_ACTOR_VERT(1) TDS_ACTOR_VERT(2) TDS_ACTOR_VERT(3) TDS_ACTOR_VERT(4) TDS_ACTOR_VERT(5) TDS_ACTOR_VERT(6)
+#undef TDS_ACTOR_VERT
+                        }
+                    }
+                }
+                if (__ballot(near) == 0) f = 3;                              // nobody in sight: skip the three faces
+            }
+            if (f < 3) {
+                float fx[3] = {f == 0 ? sx0 : (f == 1 ? sx1 : sx4), f == 0 ? sx1 : (f == 1 ? sx3 : sx5), f == 0 ? sx3 : (f == 1 ? sx2 : sx6)};
+                float fy[3] = {f == 0 ? sy0 : (f == 1 ? sy1 : sy4), f == 0 ? sy1 : (f == 1 ? sy3 : sy5), f == 0 ? sy3 : (f == 1 ? sy2 : sy6)};
+                acc = near && trim_project(cam, c.scale, res, X0, TW, fx, fy, px, py);
+                key = f == 2 ? kdir : kbody;
+                ++f;
+            }
+            if (f >= 3) {
+                f = 0;
+                a0 += RBLOCK;
+                if (a0 >= a.N) phase = 1;
+            }
+        } else if (phase == 1) {
+            // every face of a masked agent collapses onto vertex 0 of agent 0 (faces * 0 then concat offsets,
+            // mesh.py:1083-1089): a one-pixel dot with the body colour / level of agent 0, under the same trim
+            if (__ballot(masked_seen) != 0) {
+                float4 s0 = a.state[b * a.N];
+                float2 sc0 = a.agent_sc[b * a.N];
+                float2 t0 = a.tmpl[b * a.N * 7];
+                float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
+                float fx[3] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[3] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
+                acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TW, fx, fy, px, py);
+                key = a.actor_key[2 * b * a.N];
+            }
+            phase = 2;
+        } else {
+            // static map: the cells cx0..cx1 of one grid row are ONE contiguous range of entries; chunks of 64 consecutive
+            // entries are dealt round-robin to the waves
+            more = false;
+            while (cy <= cy1) {
+                const int e0 = m.cell_start[cy * m.nx + cx0], e1 = m.cell_start[cy * m.nx + cx1 + 1];
                 const int nchunks = (e1 - e0 + 63) >> 6;
-                for (; chunk < nchunks; chunk += RWAVES) {
+                if (chunk < nchunks) {
+                    const int first_end = m.cell_start[cy * m.nx + cx0 + 1];
                     int i = e0 + chunk * 64 + lane;
-                    bool acc = false;
-                    uint32_t key = 0;
-                    int px[3], py[3];
                     if (i < e1) {
                         const uint4 *ep = (const uint4 *)(m.entries + i);
                         uint4 u0 = ep[0], u1 = ep[1];
-                        unsigned dd = u1.w;                                     // bx0 | by0 << 16 = offsets from the bbox-min cell
+                        unsigned dd = u1.w;                                     // ddx | ddy << 16: offsets from the bbox-min cell
                         // exactly one of the scanned cells owns the face: the first one its bounding box touches
-                        bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && (((dd >> 16) == 0) || (cy == sy0));
+                        bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && (((dd >> 16) == 0) || (cy == cy0));
                         if (owner) {
-                            float vx[3] = {__uint_as_float(u0.x), __uint_as_float(u0.z), __uint_as_float(u1.x)};
-                            float vy[3] = {__uint_as_float(u0.y), __uint_as_float(u0.w), __uint_as_float(u1.y)};
-                            float sxv[3], syv[3];
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) { sxv[k] = vx[k] + (-cam.cx); syv[k] = vy[k] + (-cam.cy); }
+                            float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
+                            float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
                             key = u1.z;
                             acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py);
                         }
                     }
-                    enqueue<TW>(w, acc, key, px, py);
+                    chunk += RWAVES;
+                    more = true;
+                    break;
                 }
                 chunk -= nchunks;
+                ++cy;
             }
         }
+        drain<TW>(w, acc, key, px, py, more);
+        if (!more) break;
     }
-    if (w.qlen > 0) process_batch<TW>(w, w.qlen);
     __syncthreads();
     if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
@@ -575,36 +692,16 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
 // Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
 template <int TW, typename OutT>
 __global__ void __launch_bounds__(RBLOCK) raster_mesh_kernel(MeshArgs a, CommonArgs c) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int res = c.res, H = res, W = res;
-    int64_t img;
-    int strip;
-    block_to_image(c.n_img * c.strips, c.strips, img, strip);
-    const int X0 = strip * TW;
-    uint32_t *tile = smem;
-    for (int i = tid * 4; i < TW * H; i += RBLOCK * 4) *(uint4 *)(tile + i) = make_uint4(0, 0, 0, 0);
-    WaveCtx w;
-    w.tile = tile;
-    w.q = smem + TW * H + wave * WAVE_LDS_DW;
-    w.par = (int *)(w.q + Q_DW);
-    w.pref = w.par + NPAR * 64;
-    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.debug = c.debug;
-    Camera cam;
-    {
-        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
-        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
-        make_polygon(cam, c.scale, res);
-    }
-    __syncthreads();
+    TDS_RASTER_PROLOGUE()
     const float *V = a.verts + img * a.V * 3, *A = a.attrs + img * a.V * 3;
     const int32_t *Fp = a.faces + img * a.F * 3;
-    for (int64_t f0 = (int64_t)wave * 64; f0 < a.F; f0 += RBLOCK) {
+    for (int64_t f0 = (int64_t)wave * 64;; f0 += RBLOCK) {
+        const bool more = f0 < a.F;
         int64_t f = f0 + lane;
         bool acc = false;
         uint32_t key = 0;
-        int px[3], py[3];
-        if (f < a.F) {
+        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+        if (more && f < a.F) {
             int v0 = Fp[3 * f], v1 = Fp[3 * f + 1], v2 = Fp[3 * f + 2];
             float sxv[3] = {V[3 * v0] + (-cam.cx), V[3 * v1] + (-cam.cx), V[3 * v2] + (-cam.cx)};
             float syv[3] = {V[3 * v0 + 1] + (-cam.cy), V[3 * v1 + 1] + (-cam.cy), V[3 * v2 + 1] + (-cam.cy)};
@@ -613,7 +710,7 @@ __global__ void __launch_bounds__(RBLOCK) raster_mesh_kernel(MeshArgs a, CommonA
                 float z = V[3 * v0 + 2];                                         // level of the first vertex, cv2.py:44-46
                 int rank = 0;
                 for (int l = 0; l < a.n_levels; ++l) rank += (a.levels[l] >= z) ? 1 : 0;   // 1 + index in the descending table
-                acc = rank > 0;
+                rank = max(rank, 1);
                 uint32_t rgb = 0;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {                                 // cv2.py:50
@@ -623,11 +720,11 @@ __global__ void __launch_bounds__(RBLOCK) raster_mesh_kernel(MeshArgs a, CommonA
                 key = ((uint32_t)rank << 24) | rgb;
             }
         }
-        enqueue<TW>(w, acc, key, px, py);
+        drain<TW>(w, acc, key, px, py, more);
+        if (!more) break;
     }
-    if (w.qlen > 0) process_batch<TW>(w, w.qlen);
     __syncthreads();
-    write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+    if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
 inline size_t lds_bytes(int tw, int res) { return ((size_t)tw * res + (size_t)RWAVES * WAVE_LDS_DW) * sizeof(uint32_t); }
