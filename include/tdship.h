@@ -146,10 +146,17 @@ int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, const float *l
  *   cam_xy    B x Nc x 2, cam_sc B x Nc x 2 [sin, cos]
  *   scale = 2 / fov (rendering/base.py:149), res = H = W
  *   out       B x Nc x 3 x H x W   float32 or uint8 (out_mode)
- * Equal-level faces of different colour are ordered by packed colour (documented tie-break). */
+ * Equal-level faces of different colour are ordered by packed colour (documented tie-break).
+ *
+ * workspace: optional DEVICE scratch (tds_raster_scene_workspace_bytes) for the fast path -- a first kernel scans the map grid
+ * once per camera and bins the surviving faces into per-strip lists, a second one rasterises the strips from the lists.
+ * With workspace == NULL every strip scans the grid itself (same pixels, slower).  The scratch carries no state between calls. */
 int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                      const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc,
-                     int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *stream);
+                     int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
+                     int64_t workspace_bytes, void *stream);
+/* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
+int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 
 /* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
  *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,

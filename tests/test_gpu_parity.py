@@ -274,14 +274,20 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town):
         smap = make_map(ops, *mesh, town['categories'])
         static = oracle_static(oracle, *mesh, town['categories']) if len(mesh[1]) else (np.zeros((0, 3), np.float32),) * 2 + (np.zeros((0, 3), np.int32),)
         mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
-        for tw in (0, 64, 16):
+        for tw, ws in ((0, True), (0, False), (64, True), (16, True), (16, False)):     # strip widths x {binned, fused} kernels
             from torchdrivesim_amd import _native
             _native.lib().tds_raster_set_strip_width(tw)
-            img, ref = render_both(ops, oracle, smap, static, st, sz, mask, st[..., :2].copy(), g[f'g5_{n}_cam_sc'], m['fov'], m['res'])
-            _native.lib().tds_raster_set_strip_width(0)
+            ops.use_workspace = ws
+            ops._workspaces.clear()
+            try:
+                img, ref = render_both(ops, oracle, smap, static, st, sz, mask, st[..., :2].copy(), g[f'g5_{n}_cam_sc'], m['fov'], m['res'])
+            finally:
+                _native.lib().tds_raster_set_strip_width(0)
+                ops.use_workspace = True
+                ops._workspaces.clear()
             assert img.shape == tuple(m['out_shape'])
             bad = (img != ref)
-            assert not bad.any(), f'{n} tw={tw}: {bad.sum()} of {bad.size} values differ in images {np.unique(np.nonzero(bad)[0:2], axis=1)[:, :8]}'
+            assert not bad.any(), f'{n} tw={tw} ws={ws}: {bad.sum()} of {bad.size} values differ in images {np.unique(np.nonzero(bad)[0:2], axis=1)[:, :8]}'
         assert ref.any()
 
 
@@ -314,9 +320,14 @@ def test_k3_random_town01_256_bit_exact(ops, oracle, town):
     static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
     sd = dev(state)
     cam_sc = sc_np(ops.heading_sc(sd[..., 2]))
-    img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 35.0, 256)
-    bad = img != ref
-    assert not bad.any(), f'{bad.sum()} values differ'
+    for ws in (True, False):
+        ops.use_workspace = ws
+        try:
+            img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 35.0, 256)
+        finally:
+            ops.use_workspace = True
+        bad = img != ref
+        assert not bad.any(), f'workspace={ws}: {bad.sum()} values differ'
     assert (ref > 0).mean() > 0.05
 
 

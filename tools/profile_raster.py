@@ -22,11 +22,13 @@ def main():
     ap.add_argument('--tw', type=int, nargs='*', default=[0])
     ap.add_argument('--debug', type=int, nargs='*', default=[0])
     ap.add_argument('--u8', action='store_true')
+    ap.add_argument('--no-ws', action='store_true', help='fused per-strip kernel instead of the binned persistent kernel')
     ap.add_argument('--steps-before', type=int, default=5, help='simulation steps before rendering (spreads the agents)')
     args = ap.parse_args()
     from torchdrivesim_amd import _native, _ops
     from torchdrivesim_amd.utils import Resolution
     dev = torch.device('cuda', 0)
+    _ops.use_workspace = not args.no_ws
     sim, actions, _ = bench.build_simulator(args.batch, args.agents, dev, seed=1234)
     if args.u8:
         sim.renderer.cfg.out_dtype = 'uint8'

@@ -308,6 +308,22 @@ def offroad(smap, state, lenwid, threshold=0.5, present=None, sc=None):
 # ---------------------------------------------------------------------------------------------------------------
 # K3 rasteriser
 # ---------------------------------------------------------------------------------------------------------------
+#: scratch for the binned fast path of K3, one per (device, cameras, resolution); never carries state between calls
+_workspaces = {}
+use_workspace = True
+
+
+def _raster_workspace(dev, n_img, res):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n_img, res)
+    ws = _workspaces.get(key)
+    if ws is None:
+        n = ctypes.c_int64(0)
+        nat.call('tds_raster_scene_workspace_bytes', dev, n_img, res, ctypes.byref(n))
+        ws = torch.empty(max(int(n.value), 0), dtype=torch.uint8, device=dev) if n.value > 0 else False
+        _workspaces[key] = ws
+    return ws if ws is not False else None
+
+
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
 raster_events = None
 
@@ -328,14 +344,16 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     else:
         assert out.shape == (B, Nc, 3, res, res) and out.dtype == out_dtype and out.is_contiguous()
     p = lambda t, d, nme: nat.dev_ptr(t, d, nme) if N > 0 else None
+    mode = nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8
+    ws = _raster_workspace(dev, B * Nc, int(res)) if use_workspace else None
     ev = None
     if raster_events is not None:          # bench.py: HIP events on the launch stream, right around the kernel
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(dev))
     nat.call('tds_raster_scene', dev, smap.handle, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
              p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
-             B, Nc, N, float(2.0 / fov), int(res), nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8,
-             nat.dev_ptr(out, out_dtype, 'out'), nat.stream_ptr(dev))
+             B, Nc, N, float(2.0 / fov), int(res), mode, nat.dev_ptr(out, out_dtype, 'out'),
+             None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(), nat.stream_ptr(dev))
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         raster_events.append(ev)

@@ -24,7 +24,6 @@ constexpr int RWAVES = 4;
 constexpr int RBLOCK = RWAVES * 64;
 constexpr int QCAP = 64;                          // per-wave face queue (entries): key + 3 packed vertices
 constexpr int Q_DW = 4 * QCAP;
-constexpr int ROWS_PER_BLOCK = 8;                 // taller faces are scan-converted in blocks of this many rows
 constexpr int BLOCK_CAP = 256;                    // per-wave list of (face, block) pairs
 constexpr int WAVE_LDS_DW = Q_DW + BLOCK_CAP;
 constexpr int NO_SWITCH = 0x7fffffff;
@@ -211,7 +210,10 @@ __device__ inline bool clip_line(int W, int H, long long &x1, long long &y1, lon
     return (c1 | c2) == 0;
 }
 
-// cv::Line, 8-connected, leftToRight; paints the pixels that fall into the strip [X0, X0+TW)
+// cv::Line, 8-connected, leftToRight; paints the pixels that fall into the strip [X0, X0+TW).
+// The Bresenham walk is entered in closed form at the first pixel whose x reaches the strip and left once x passes it
+// (x never decreases along the walk): after k steps the minor axis has advanced m_k = floor((2 dmin k + dmaj - 1) / (2 dmaj))
+// and the error term is e0 - 2 dmin k + 2 dmaj m_k  (checked exhaustively against the iterative form).
 template <int TW>
 __device__ inline void draw_line(uint32_t *tile, int H, int W, int X0, int ax, int ay, int bx, int by, uint32_t key) {
     long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
@@ -219,24 +221,41 @@ __device__ inline void draw_line(uint32_t *tile, int H, int W, int X0, int ax, i
         (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
         if (!clip_line(W, H, x1, y1, x2, y2)) return;
     }
-    int lo = (int)(x1 < x2 ? x1 : x2), hi = (int)(x1 < x2 ? x2 : x1);
-    if (hi < X0 || lo >= X0 + TW) return;
     int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
     int px = (int)x1, py = (int)y1;
     int step_y = 1;
     if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }
+    if (px >= X0 + TW || px + dx < X0) return;                   // the x range [px, px + dx] misses the strip
     if (dy < 0) { dy = -dy; step_y = -1; }
-    bool vert = dy > dx;
-    if (vert) { int t = dx; dx = dy; dy = t; }
-    int err = dx - (dy + dy), plus_delta = dx + dx, minus_delta = -(dy + dy);
-    int count = dx + 1;
-    for (int i = 0; i < count; ++i) {
-        unsigned lx = (unsigned)(px - X0);
-        if (lx < (unsigned)TW) atomicMax(&tile[lx * H + py], key);
+    const bool vert = dy > dx;
+    const int dmaj = vert ? dy : dx, dmin = vert ? dx : dy;
+    int err = dmaj - (dmin + dmin);
+    const int plus_delta = dmaj + dmaj, minus_delta = -(dmin + dmin);
+    int k = 0;                                                       // steps already taken
+    if (px < X0) {
+        const int t = X0 - px;                                       // columns to skip
+        if (!vert) {
+            k = t;
+            int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
+            err += k * minus_delta + m * plus_delta;
+            px += k; py += step_y * m;
+        } else {
+            // first step count with m_k >= t  (dmin > 0 here because px + dx >= X0 > px)
+            k = (int)(((unsigned)(2 * dmaj) * (unsigned)t - (unsigned)dmaj + (unsigned)(2 * dmin)) / (unsigned)(2 * dmin));
+            int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
+            err += k * minus_delta + m * plus_delta;
+            py += step_y * k; px += m;
+        }
+    }
+    uint32_t *p = tile + (px - X0) * H + py;
+    const int pstep_maj = vert ? step_y : H, pstep_min = vert ? H : step_y;
+    for (; k <= dmaj; ++k) {
+        if (px >= X0 + TW) break;
+        atomicMax(p, key);
         bool neg = err < 0;
         err += minus_delta + (neg ? plus_delta : 0);
-        if (vert) { py += step_y; px += neg ? 1 : 0; }
-        else { px += 1; py += neg ? step_y : 0; }
+        p += pstep_maj + (neg ? pstep_min : 0);
+        px += vert ? (neg ? 1 : 0) : 1;
     }
 }
 
@@ -320,30 +339,9 @@ __device__ __noinline__ void fill_generic(uint32_t *tile, int H, int W, int X0, 
     } while (++y <= (int)ymax);
 }
 
-// scan-convert rows [y0, y1] of one triangle into the strip (closed form of OpenCV's FillConvexPoly row loop:
-// x(y) = xs + (y - y_edge_start) * dx in 16.16, evaluated once and then stepped like OpenCV does)
-template <int TW>
-__device__ inline void paint_rows(uint32_t *tile, int H, int W, int X0, const Chain &a, const Chain &b, int ymin, int y0, int y1,
-                                  uint32_t key) {
-    long long xa = chain_x(a.xs1, a.dx1, a.ysw, a.xs2, a.dx2, ymin, y0);
-    long long xb = chain_x(b.xs1, b.dx1, b.ysw, b.xs2, b.dx2, ymin, y0);
-    int da = y0 >= a.ysw ? a.dx2 : a.dx1, db = y0 >= b.ysw ? b.dx2 : b.dx1;
-    for (int y = y0; y <= y1; ++y) {
-        long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
-        int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
-        if (xx2 >= 0 && xx1 < W) {
-            int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TW - 1);
-            uint32_t *p = tile + (s0 - X0) * H + y;
-            for (int x = s0; x <= s1; ++x, p += H) atomicMax(p, key);
-        }
-        xa += da; xb += db;
-        if (y + 1 == a.ysw) { xa = (long long)a.xs2 << 16; da = a.dx2; }      // the chain switches to its second edge
-        if (y + 1 == b.ysw) { xb = (long long)b.xs2 << 16; db = b.dx2; }
-    }
-}
+struct FaceRows { int ymin, ystart, nrows, imin, xlo, xhi; };
 
-struct FaceRows { int ymin, ystart, nrows, imin; };
-
+// rows that OpenCV's scan conversion paints for this triangle, and the pixel columns of the strip it can touch
 __device__ inline FaceRows face_rows(const int *px, const int *py, int H, int W, int X0, int TW) {
     FaceRows r;
     int ymax = py[0], xmin = px[0], xmax = px[0];
@@ -355,75 +353,105 @@ __device__ inline FaceRows face_rows(const int *px, const int *py, int H, int W,
     }
     r.ystart = max(r.ymin, 0);
     int yend = min(ymax - 1, H - 1);              // the row of the bottom vertex is never scan-converted (edges run out)
-    bool scan = !(xmax < 0 || ymax < 0 || xmin >= W || r.ymin >= H) && (xmax >= X0) && (xmin < X0 + TW);
+    r.xlo = max(max(xmin, 0), X0);
+    r.xhi = min(min(xmax, W - 1), X0 + TW - 1);
+    bool scan = !(xmax < 0 || ymax < 0 || xmin >= W || r.ymin >= H) && (r.xlo <= r.xhi);
     r.nrows = scan ? max(0, yend - r.ystart + 1) : 0;
     return r;
 }
 
+constexpr int TILE = 8;          // scan conversion work unit: TILE rows x TILE columns of a face's bounding box
+
 // Rasterise the first n (<= 64) faces of the wave's queue.
-//   1. lane f looks at face f; faces of at most ROWS_PER_BLOCK rows are scan-converted right away by their lane
-//      (everything stays in registers; the bulk of a road map is lane-marking slivers of a few pixels);
-//   2. taller faces are cut into blocks of ROWS_PER_BLOCK rows; the blocks are numbered by a wave prefix sum, their
-//      owners write (face, block) pairs into an LDS list, and the wave paints one block per lane -- balanced whatever
-//      the face sizes; the edge set-up is recomputed per block from the packed vertices instead of being staged in LDS;
-//   3. the three outline edges of every face (Bresenham with OpenCV's clipLine), one edge per lane.
+//   1. lane f sets up face f: rows to paint and the two edge chains of OpenCV's scan conversion (start x, 16.16 slope,
+//      switch row) -- one 32-bit division per edge;
+//   2. the part of each face's bounding box inside the strip is cut into TILE x TILE tiles; tiles are numbered by a wave
+//      prefix sum, their owners write (face, tile) pairs into an LDS list, and the wave paints one tile per lane: the edge
+//      data comes from the owner lane by ds_bpermute, rows are stepped like OpenCV does, every span is cut to the tile.
+//      Work per lane is bounded by TILE x TILE whatever the face sizes, so slivers and big road triangles mix well;
+//   3. the outline edges (Bresenham + OpenCV's clipLine) in segments of SEG pixels, one segment per lane, each segment
+//      entered in closed form.
 template <int TW>
 __device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
     const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0;
     wave_sync();
-    int nblocks = 0;
-    if (lane < n && !(w.debug & 16)) {
-        uint32_t key = w.q[lane];
-        int px[3], py[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { uint32_t p = w.q[(1 + k) * QCAP + lane]; px[k] = unpack_x(p); py[k] = unpack_y(p); }
-        FaceRows r = face_rows(px, py, H, W, X0, TW);
-        if (r.nrows > ROWS_PER_BLOCK) {
-            nblocks = (r.nrows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-        } else if (r.nrows > 0) {
+    // ---- per-face set-up (lane = face)
+    uint32_t key = 0, v0 = 0, v1 = 0, v2 = 0;
+    int ntiles = 0, ntx = 1;
+    FaceRows r = {0, 0, 0, 0, 0, 0};
+    Chain a = {0, 0, NO_SWITCH, 0, 0}, b = {0, 0, NO_SWITCH, 0, 0};
+    if (lane < n) {
+        key = w.q[lane]; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
+        const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
+        r = face_rows(px, py, H, W, X0, TW);
+        if (r.nrows > 0 && !(w.debug & 16)) {
             int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
-            Chain a = make_chain(px, py, r.imin, i1, i2), b = make_chain(px, py, r.imin, i2, i1);
-            paint_rows<TW>(w.tile, H, W, X0, a, b, r.ymin, r.ystart, r.ystart + r.nrows - 1, key);
+            a = make_chain(px, py, r.imin, i1, i2);
+            b = make_chain(px, py, r.imin, i2, i1);
+            ntx = (r.xhi - r.xlo) / TILE + 1;
+            ntiles = ntx * ((r.nrows + TILE - 1) / TILE);
         }
     }
-    if (__ballot(nblocks > 0) != 0) {
-        int incl = nblocks;
+    // ---- scan conversion, one tile per lane
+    if (__ballot(ntiles > 0) != 0) {
+        int incl = ntiles;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             int v = __shfl_up(incl, d);
             if (lane >= d) incl += v;
         }
-        const int excl = incl - nblocks;
+        const int excl = incl - ntiles;
         const int total = __shfl(incl, 63);
+        // what a tile needs from its face, packed for the cross-lane fetch
+        const int sh_a = (a.xs1 & 0xffff) | (a.xs2 << 16), sh_b = (b.xs1 & 0xffff) | (b.xs2 << 16);
+        const int sh_sw = (min(a.ysw, 0x7fff) & 0xffff) | (min(b.ysw, 0x7fff) << 16);
+        const int sh_y = (r.ymin & 0xffff) | (r.ystart << 16), sh_n = r.nrows | (ntx << 16), sh_x = r.xlo | (r.xhi << 16);
         for (int base = 0; base < total; base += BLOCK_CAP) {
             int lo = max(excl, base), hi = min(incl, base + BLOCK_CAP);
             for (int idx = lo; idx < hi; ++idx) w.blocks[idx - base] = (uint32_t)lane | ((uint32_t)(idx - excl) << 8);
             wave_sync();
-            int m = min(BLOCK_CAP, total - base);
-            for (int i = lane; i < m; i += 64) {
-                uint32_t e = w.blocks[i];
-                int f = e & 0xff, blk = e >> 8;
-                uint32_t key = w.q[f];
-                int px[3], py[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { uint32_t p = w.q[(1 + k) * QCAP + f]; px[k] = unpack_x(p); py[k] = unpack_y(p); }
-                FaceRows r = face_rows(px, py, H, W, X0, TW);
-                int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
-                Chain a = make_chain(px, py, r.imin, i1, i2), b = make_chain(px, py, r.imin, i2, i1);
-                int y0 = r.ystart + blk * ROWS_PER_BLOCK, y1 = min(y0 + ROWS_PER_BLOCK, r.ystart + r.nrows) - 1;
-                paint_rows<TW>(w.tile, H, W, X0, a, b, r.ymin, y0, y1, key);
+            const int m = min(BLOCK_CAP, total - base);
+            for (int i0 = 0; i0 < m; i0 += 64) {
+                const int i = i0 + lane;
+                const bool live = i < m;
+                const uint32_t e = live ? w.blocks[i] : 0u;
+                const int f = e & 0xff, t = (int)(e >> 8);
+                // all lanes take part in the shuffles
+                const int ga = __shfl(sh_a, f), gb = __shfl(sh_b, f), gsw = __shfl(sh_sw, f), gy = __shfl(sh_y, f), gn = __shfl(sh_n, f);
+                const int gx = __shfl(sh_x, f), adx1 = __shfl(a.dx1, f), adx2 = __shfl(a.dx2, f), bdx1 = __shfl(b.dx1, f), bdx2 = __shfl(b.dx2, f);
+                const uint32_t k2 = (uint32_t)__shfl((int)key, f);
+                if (live) {
+                    const int ymin = (int)(short)(gy & 0xffff), ystart = gy >> 16, nrows = gn & 0xffff, tnx = gn >> 16;
+                    const int ty = t / tnx, tx = t - ty * tnx;
+                    const int y0 = ystart + ty * TILE, y1 = min(y0 + TILE, ystart + nrows) - 1;
+                    const int c0 = (gx & 0xffff) + tx * TILE, c1 = min(c0 + TILE - 1, gx >> 16);
+                    const int aysw = (int)(short)(gsw & 0xffff), bysw = gsw >> 16;           // 0x7fff = no second edge
+                    const int axs1 = (int)(short)(ga & 0xffff), axs2 = ga >> 16, bxs1 = (int)(short)(gb & 0xffff), bxs2 = gb >> 16;
+                    long long xa = chain_x(axs1, adx1, aysw, axs2, adx2, ymin, y0);
+                    long long xb = chain_x(bxs1, bdx1, bysw, bxs2, bdx2, ymin, y0);
+                    int da = y0 >= aysw ? adx2 : adx1, db = y0 >= bysw ? bdx2 : bdx1;
+                    for (int y = y0; y <= y1; ++y) {
+                        long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+                        int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+                        // OpenCV draws [xx1, xx2] clamped to the image when it is not entirely outside; here cut to the tile
+                        int s0 = max(xx1, c0), s1 = min(xx2, c1);
+                        uint32_t *p = w.tile + (s0 - X0) * H + y;
+                        for (int x = s0; x <= s1; ++x, p += H) atomicMax(p, k2);
+                        xa += da; xb += db;
+                        if (y + 1 == aysw) { xa = (long long)axs2 << 16; da = adx2; }
+                        if (y + 1 == bysw) { xb = (long long)bxs2 << 16; db = bdx2; }
+                    }
+                }
             }
             wave_sync();
         }
     }
-    // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2) before the scan conversion
-    for (int t0 = 0; t0 < 3 * n && !(w.debug & 8); t0 += 64) {
-        int t = t0 + lane;
-        if (t < 3 * n) {
-            int f = t / 3, l = t - 3 * f;
-            int ia = l == 0 ? 2 : l - 1, ib = l;
-            uint32_t k2 = w.q[f], pa = w.q[(1 + ia) * QCAP + f], pb = w.q[(1 + ib) * QCAP + f];
-            draw_line<TW>(w.tile, H, W, X0, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb), k2);
+    // ---- outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2) before the scan conversion
+    if (!(w.debug & 8)) {
+#pragma unroll 1
+        for (int l = 0; l < 3; ++l) {
+            const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
+            if (lane < n) draw_line<TW>(w.tile, H, W, X0, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb), key);
         }
     }
     wave_sync();
@@ -557,23 +585,30 @@ __device__ __forceinline__ void drain(WaveCtx &w, bool acc, uint32_t key, const 
     }                                                                                                           \
     __syncthreads();
 
-template <int TW, typename OutT>
-__global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, CommonArgs c) {
-    TDS_RASTER_PROLOGUE()
-    const int64_t b = img / a.Nc;
-    const MapView m = a.map;
-    // producer state
-    int phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map, 3 done
-    int a0 = 0, f = 0;
-    bool masked_seen = false, near = false;
-    float sx0 = 0, sx1 = 0, sx2 = 0, sx3 = 0, sx4 = 0, sx5 = 0, sx6 = 0, sy0 = 0, sy1 = 0, sy2 = 0, sy3 = 0, sy4 = 0, sy5 = 0, sy6 = 0;
-    uint32_t kbody = 0, kdir = 0;
-    int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cy = 0, chunk = wave;
+// ---- scene producer: actors, then the masked-agent dot, then the static map cells under a pixel window --------------
+struct ScanState {
+    int phase, a0, f;
+    bool masked_seen, near;
+    float sx0, sx1, sx2, sx3, sx4, sx5, sx6, sy0, sy1, sy2, sy3, sy4, sy5, sy6;
+    uint32_t kbody, kdir;
+    int cx0, cx1, cy0, cy1, cy, chunk;
+};
+
+// window = pixel columns [X0, X0 + TWw) of the image (the whole image when binning)
+__device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int wave, int X0, int TWw) {   // wave = index among the cooperating waves
+    const MapView &m = a.map;
+    const int res = c.res;
+    st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map
+    st.a0 = 0; st.f = 0; st.masked_seen = false; st.near = false;
+    st.sx0 = st.sx1 = st.sx2 = st.sx3 = st.sx4 = st.sx5 = st.sx6 = 0.0f;
+    st.sy0 = st.sy1 = st.sy2 = st.sy3 = st.sy4 = st.sy5 = st.sy6 = 0.0f;
+    st.kbody = st.kdir = 0;
+    st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.cy1 = -1; st.cy = 0; st.chunk = wave;
     if (m.nx > 0 && !(c.debug & 1)) {
-        // world-space bounding box of the strip (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell range
+        // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell range
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
         const float half = (float)res / 2.0f;
-        const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TW, res) + 2.0f}, pys[2] = {-2.0f, (float)res + 2.0f};
+        const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TWw, res) + 2.0f}, pys[2] = {-2.0f, (float)res + 2.0f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -585,103 +620,126 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
         const float eps = 1e-3f + 1e-6f * (fabsf(cam.cx) + fabsf(cam.cy));
         float fx0 = fminf(fmaxf((wx0 - eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx), fx1 = fminf(fmaxf((wx1 + eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx);
         float fy0 = fminf(fmaxf((wy0 - eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny), fy1 = fminf(fmaxf((wy1 + eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny);
-        cx0 = max((int)floorf(fx0), 0); cx1 = min((int)floorf(fx1), m.nx - 1);
-        cy0 = max((int)floorf(fy0), 0); cy1 = min((int)floorf(fy1), m.ny - 1);
-        cy = cy0;
-        if (cx0 > cx1) cy1 = cy0 - 1;
+        st.cx0 = max((int)floorf(fx0), 0); st.cx1 = min((int)floorf(fx1), m.nx - 1);
+        st.cy0 = max((int)floorf(fy0), 0); st.cy1 = min((int)floorf(fy1), m.ny - 1);
+        st.cy = st.cy0;
+        if (st.cx0 > st.cx1) st.cy1 = st.cy0 - 1;
     }
-    for (;;) {
-        bool acc = false, more = true;
-        uint32_t key = 0;
-        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-        if (phase == 0) {
-            // actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction).
-            // Agents are dealt to the 4 waves (agent = 4*lane + wave) and culled by distance before anything else is loaded.
-            if (f == 0) {
-                const float view_r = 1.05f * 1.41421356f / c.scale;            // half diagonal of the trim polygon
-                int ag = a0 + lane * RWAVES + wave;
-                near = false;
-                if (ag < a.N) {
-                    int64_t ia = b * a.N + ag;
-                    bool on = a.mask[img * a.N + ag] != 0;
-                    masked_seen = masked_seen || !on;
-                    if (on) {
-                        float4 s = a.state[ia];
-                        float2 t0 = a.tmpl[ia * 7];                          // (l/2, w/2): the farthest template vertex
-                        float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y);
-                        reach = reach * 1.01f + 0.01f;
-                        float ddx = s.x - cam.cx, ddy = s.y - cam.cy;
-                        near = !(ddx * ddx + ddy * ddy > reach * reach);     // NaNs are kept
-                        if (near) {
-                            float2 sc = a.agent_sc[ia];
-                            kbody = a.actor_key[2 * ia]; kdir = a.actor_key[2 * ia + 1];
-                            // utils.transform :82-96, then mesh.translate(-cameras.xy) cv2.py:29-31
-#define TDS_ACTOR_VERT(K)                                                                                                   \
-    { float2 t = a.tmpl[ia * 7 + K];                                                                                        \
-      sx##K = ((sc.y * t.x + (-sc.x) * t.y) + s.x) + (-cam.cx); sy##K = ((sc.x * t.x + sc.y * t.y) + s.y) + (-cam.cy); }
-                            TDS_ACTOR_VERT(0) TDS_ACTOR_VERT(1) TDS_ACTOR_VERT(2) TDS_ACTOR_VERT(3) TDS_ACTOR_VERT(4) TDS_ACTOR_VERT(5) TDS_ACTOR_VERT(6)
+}
+
+// one producer step: at most one candidate face per lane; returns false when the producer is exhausted
+template <int NW = RWAVES>
+__device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane,
+                                          int wave, int X0, int TWw, bool &acc, uint32_t &key, int (&px)[3], int (&py)[3]) {
+    const MapView &m = a.map;
+    const int res = c.res;
+    const int64_t b = img / a.Nc;
+    acc = false;
+    key = 0;
+    if (st.phase == 0) {
+        // actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction).
+        // Agents are dealt to the 4 waves (agent = 4*lane + wave) and culled by distance before anything else is loaded.
+        if (st.f == 0) {
+            const float view_r = 1.05f * 1.41421356f / c.scale;            // half diagonal of the trim polygon
+            int ag = st.a0 + lane * NW + wave;
+            st.near = false;
+            if (ag < a.N) {
+                int64_t ia = b * a.N + ag;
+                bool on = a.mask[img * a.N + ag] != 0;
+                st.masked_seen = st.masked_seen || !on;
+                if (on) {
+                    float4 s = a.state[ia];
+                    float2 t0 = a.tmpl[ia * 7];                          // (l/2, w/2): the farthest template vertex
+                    float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y);
+                    reach = reach * 1.01f + 0.01f;
+                    float ddx = s.x - cam.cx, ddy = s.y - cam.cy;
+                    st.near = !(ddx * ddx + ddy * ddy > reach * reach);  // NaNs are kept
+                    if (st.near) {
+                        float2 sc = a.agent_sc[ia];
+                        st.kbody = a.actor_key[2 * ia]; st.kdir = a.actor_key[2 * ia + 1];
+                        // utils.transform :82-96, then mesh.translate(-cameras.xy) cv2.py:29-31
+#define TDS_ACTOR_VERT(K)                                                                                                          \
+    { float2 t = a.tmpl[ia * 7 + K];                                                                                               \
+      st.sx##K = ((sc.y * t.x + (-sc.x) * t.y) + s.x) + (-cam.cx); st.sy##K = ((sc.x * t.x + sc.y * t.y) + s.y) + (-cam.cy); }
+                        TDS_ACTOR_VERT(0) TDS_ACTOR_VERT(1) TDS_ACTOR_VERT(2) TDS_ACTOR_VERT(3) TDS_ACTOR_VERT(4) TDS_ACTOR_VERT(5) TDS_ACTOR_VERT(6)
 #undef TDS_ACTOR_VERT
-                        }
                     }
                 }
-                if (__ballot(near) == 0) f = 3;                              // nobody in sight: skip the three faces
             }
-            if (f < 3) {
-                float fx[3] = {f == 0 ? sx0 : (f == 1 ? sx1 : sx4), f == 0 ? sx1 : (f == 1 ? sx3 : sx5), f == 0 ? sx3 : (f == 1 ? sx2 : sx6)};
-                float fy[3] = {f == 0 ? sy0 : (f == 1 ? sy1 : sy4), f == 0 ? sy1 : (f == 1 ? sy3 : sy5), f == 0 ? sy3 : (f == 1 ? sy2 : sy6)};
-                acc = near && trim_project(cam, c.scale, res, X0, TW, fx, fy, px, py);
-                key = f == 2 ? kdir : kbody;
-                ++f;
-            }
-            if (f >= 3) {
-                f = 0;
-                a0 += RBLOCK;
-                if (a0 >= a.N) phase = 1;
-            }
-        } else if (phase == 1) {
-            // every face of a masked agent collapses onto vertex 0 of agent 0 (faces * 0 then concat offsets,
-            // mesh.py:1083-1089): a one-pixel dot with the body colour / level of agent 0, under the same trim
-            if (__ballot(masked_seen) != 0) {
-                float4 s0 = a.state[b * a.N];
-                float2 sc0 = a.agent_sc[b * a.N];
-                float2 t0 = a.tmpl[b * a.N * 7];
-                float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
-                float fx[3] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[3] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
-                acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TW, fx, fy, px, py);
-                key = a.actor_key[2 * b * a.N];
-            }
-            phase = 2;
-        } else {
-            // static map: the cells cx0..cx1 of one grid row are ONE contiguous range of entries; chunks of 64 consecutive
-            // entries are dealt round-robin to the waves
-            more = false;
-            while (cy <= cy1) {
-                const int e0 = m.cell_start[cy * m.nx + cx0], e1 = m.cell_start[cy * m.nx + cx1 + 1];
-                const int nchunks = (e1 - e0 + 63) >> 6;
-                if (chunk < nchunks) {
-                    const int first_end = m.cell_start[cy * m.nx + cx0 + 1];
-                    int i = e0 + chunk * 64 + lane;
-                    if (i < e1) {
-                        const uint4 *ep = (const uint4 *)(m.entries + i);
-                        uint4 u0 = ep[0], u1 = ep[1];
-                        unsigned dd = u1.w;                                     // ddx | ddy << 16: offsets from the bbox-min cell
-                        // exactly one of the scanned cells owns the face: the first one its bounding box touches
-                        bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && (((dd >> 16) == 0) || (cy == cy0));
-                        if (owner) {
-                            float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
-                            float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
-                            key = u1.z;
-                            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py);
-                        }
-                    }
-                    chunk += RWAVES;
-                    more = true;
-                    break;
-                }
-                chunk -= nchunks;
-                ++cy;
-            }
+            if (__ballot(st.near) == 0) st.f = 3;                        // nobody in sight: skip the three faces
         }
+        if (st.f < 3) {
+            const int f = st.f;
+            float fx[3] = {f == 0 ? st.sx0 : (f == 1 ? st.sx1 : st.sx4), f == 0 ? st.sx1 : (f == 1 ? st.sx3 : st.sx5), f == 0 ? st.sx3 : (f == 1 ? st.sx2 : st.sx6)};
+            float fy[3] = {f == 0 ? st.sy0 : (f == 1 ? st.sy1 : st.sy4), f == 0 ? st.sy1 : (f == 1 ? st.sy3 : st.sy5), f == 0 ? st.sy3 : (f == 1 ? st.sy2 : st.sy6)};
+            acc = st.near && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py);
+            key = f == 2 ? st.kdir : st.kbody;
+            ++st.f;
+        }
+        if (st.f >= 3) {
+            st.f = 0;
+            st.a0 += 64 * NW;
+            if (st.a0 >= a.N) st.phase = 1;
+        }
+        return true;
+    }
+    if (st.phase == 1) {
+        // every face of a masked agent collapses onto vertex 0 of agent 0 (faces * 0 then concat offsets,
+        // mesh.py:1083-1089): a one-pixel dot with the body colour / level of agent 0, under the same trim
+        if (__ballot(st.masked_seen) != 0) {
+            float4 s0 = a.state[b * a.N];
+            float2 sc0 = a.agent_sc[b * a.N];
+            float2 t0 = a.tmpl[b * a.N * 7];
+            float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
+            float fx[3] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[3] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
+            acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py);
+            key = a.actor_key[2 * b * a.N];
+        }
+        st.phase = 2;
+        return true;
+    }
+    // static map: the cells cx0..cx1 of one grid row are ONE contiguous range of entries; chunks of 64 consecutive
+    // entries are dealt round-robin to the waves
+    while (st.cy <= st.cy1) {
+        const int e0 = m.cell_start[st.cy * m.nx + st.cx0], e1 = m.cell_start[st.cy * m.nx + st.cx1 + 1];
+        const int nchunks = (e1 - e0 + 63) >> 6;
+        if (st.chunk < nchunks) {
+            const int first_end = m.cell_start[st.cy * m.nx + st.cx0 + 1];
+            int i = e0 + st.chunk * 64 + lane;
+            if (i < e1) {
+                const uint4 *ep = (const uint4 *)(m.entries + i);
+                uint4 u0 = ep[0], u1 = ep[1];
+                unsigned dd = u1.w;                                     // ddx | ddy << 16: offsets from the bbox-min cell
+                // exactly one of the scanned cells owns the face: the first one its bounding box touches
+                bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && (((dd >> 16) == 0) || (st.cy == st.cy0));
+                if (owner) {
+                    float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
+                    float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
+                    key = u1.z;
+                    acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py);
+                }
+            }
+            st.chunk += NW;
+            return true;
+        }
+        st.chunk -= nchunks;
+        ++st.cy;
+    }
+    return false;
+}
+
+// Fused single-pass kernel: one workgroup per (camera, strip); every strip scans the grid itself.  Used when the caller
+// gives no workspace; also the semantics reference for the binned kernel below.
+template <int TW, typename OutT>
+__global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgs a, CommonArgs c) {
+    TDS_RASTER_PROLOGUE()
+    ScanState st;
+    scan_init(st, a, c, cam, wave, X0, TW);
+    for (;;) {
+        bool acc;
+        uint32_t key;
+        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+        const bool more = scan_step(st, a, c, cam, img, lane, wave, X0, TW, acc, key, px, py);
         drain<TW>(w, acc, key, px, py, more);
         if (!more) break;
     }
@@ -689,9 +747,91 @@ __global__ void __launch_bounds__(RBLOCK) raster_scene_kernel(SceneArgs a, Commo
     if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
+// ---- fast path: two kernels ---------------------------------------------------------------------------------
+// K3a bin_faces_kernel: ONE WAVE per camera scans the grid once for the whole image (trim, projection) and appends every
+// surviving face (16 B: key + three packed vertices) to the list of each strip it touches; no workgroup barriers.
+// K3b raster_scene_list_kernel: one workgroup per (camera, strip) rasterises that strip's list.
+// Scratch layout: counts[n_img * strips] (uint32) followed by lists[n_img * strips * caps] (uint4).
+// A strip whose list overflowed, or that met a face outside the packed coordinate range, is poisoned (count > caps) and
+// scans the grid for itself in K3b, so the result never depends on the capacity.
+constexpr int BIN_WAVES = 4;          // cameras per workgroup of K3a
+constexpr int MAX_STRIPS = 128;
+
+__global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgs a, CommonArgs c, int tw, uint32_t *__restrict__ counts,
+                                                                     uint4 *__restrict__ lists, int caps) {
+    __shared__ uint32_t cnt_s[BIN_WAVES][MAX_STRIPS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t img = (int64_t)blockIdx.x * BIN_WAVES + wv;
+    if (img >= c.n_img) return;                                        // wave-uniform; no barriers in this kernel
+    const int res = c.res, W = res, strips = c.strips;
+    uint32_t *cnt = cnt_s[wv];
+    for (int i = lane; i < strips; i += 64) cnt[i] = 0;
+    Camera cam;
+    {
+        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
+        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
+        make_polygon(cam, c.scale, res);
+    }
+    wave_sync();
+    uint4 *mine = lists + (size_t)img * strips * caps;
+    ScanState st;
+    scan_init(st, a, c, cam, 0, 0, W);
+    for (;;) {
+        bool acc;
+        uint32_t key;
+        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+        const bool more = scan_step<1>(st, a, c, cam, img, lane, 0, 0, W, acc, key, px, py);
+        if (acc) {
+            int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
+            bool big = max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT;
+            int s0 = max(xmin, 0) / tw, s1 = min(xmax, W - 1) / tw;
+            uint4 e = make_uint4(key, pack_xy(px[0], py[0]), pack_xy(px[1], py[1]), pack_xy(px[2], py[2]));
+            for (int s = s0; s <= s1; ++s) {
+                if (big) { atomicAdd(&cnt[s], 0x40000000u); continue; }      // poison: this strip scans for itself
+                uint32_t slot = atomicAdd(&cnt[s], 1u);
+                if (slot < (uint32_t)caps) mine[(size_t)s * caps + slot] = e;
+            }
+        }
+        if (!more) break;
+    }
+    wave_sync();
+    for (int i = lane; i < strips; i += 64) counts[img * strips + i] = cnt[i];
+}
+
+template <int TW, typename OutT>
+__global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs a, CommonArgs c, const uint32_t *__restrict__ counts,
+                                                                       const uint4 *__restrict__ lists, int caps) {
+    TDS_RASTER_PROLOGUE()
+    const uint32_t n = counts[img * c.strips + strip];
+    if (n <= (uint32_t)caps) {
+        const uint4 *lst = lists + ((size_t)img * c.strips + strip) * caps;
+        for (uint32_t i0 = wave * 64;; i0 += RBLOCK) {
+            const bool more = i0 < n;
+            bool acc = more && (i0 + lane < n);
+            uint4 e = acc ? lst[i0 + lane] : make_uint4(0, 0, 0, 0);
+            int px[3] = {unpack_x(e.y), unpack_x(e.z), unpack_x(e.w)}, py[3] = {unpack_y(e.y), unpack_y(e.z), unpack_y(e.w)};
+            drain<TW>(w, acc, e.x, px, py, more);
+            if (!more) break;
+        }
+    } else {
+        ScanState st;
+        scan_init(st, a, c, cam, wave, X0, TW);
+        for (;;) {
+            bool acc;
+            uint32_t key;
+            int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+            const bool more = scan_step(st, a, c, cam, img, lane, wave, X0, TW, acc, key, px, py);
+            drain<TW>(w, acc, key, px, py, more);
+            if (!more) break;
+        }
+    }
+    __syncthreads();
+    if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+}
+
 // Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
 template <int TW, typename OutT>
-__global__ void __launch_bounds__(RBLOCK) raster_mesh_kernel(MeshArgs a, CommonArgs c) {
+__global__ void __launch_bounds__(RBLOCK, 4) raster_mesh_kernel(MeshArgs a, CommonArgs c) {
     TDS_RASTER_PROLOGUE()
     const float *V = a.verts + img * a.V * 3, *A = a.attrs + img * a.V * 3;
     const int32_t *Fp = a.faces + img * a.F * 3;
@@ -785,9 +925,27 @@ static int common_checks(const char *fn, int64_t n_img, int res, int out_mode, c
     return TDS_OK;
 }
 
+namespace {
+constexpr int DEFAULT_CAPS = 512;         // faces per strip list that the recommended workspace provides
+inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
+    return n_img * strips * ((int64_t)caps * (int64_t)sizeof(uint4) + (int64_t)sizeof(uint32_t));
+}
+}  // namespace
+
+TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes) {
+    TDS_CHECK_ARG(bytes, "tds_raster_scene_workspace_bytes: null output");
+    TDS_CHECK_ARG(res > 0 && res <= 4096 && n_img >= 0, "tds_raster_scene_workspace_bytes: bad arguments");
+    int tw = g_force_tw ? g_force_tw : pick_tw(res);
+    *bytes = 0;
+    if (tw == 0 || (res + tw - 1) / tw > MAX_STRIPS) return TDS_OK;
+    *bytes = ws_bytes_for(n_img, (res + tw - 1) / tw, DEFAULT_CAPS);
+    return TDS_OK;
+}
+
 TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                                 const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
-                                int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *stream) {
+                                int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
+                                int64_t workspace_bytes, void *stream) {
     TDS_CHECK_ARG(map, "tds_raster_scene: null map");
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
     TDS_CHECK_ARG(map->n_levels > 0 || map->view.nx == 0, "tds_raster_scene: the map was created without rendering data");
@@ -799,12 +957,42 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
     TDS_CHECK_ARG(cam_xy && cam_sc, "tds_raster_scene: null camera arrays");
     TDS_CHECK_ARG(N == 0 || (state && agent_sc && tmpl && actor_key && mask), "tds_raster_scene: null agent arrays");
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene: scale must be positive");
+    TDS_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "tds_raster_scene: bad workspace");
     SceneArgs a;
     a.map = map->view; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
     a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
+    // fast path: bin once per camera (K3a), then rasterise per strip from the lists (K3b)
+    if (workspace && !(g_debug & 32) && cm.strips <= MAX_STRIPS) {
+        int64_t caps = (workspace_bytes / (n_img * cm.strips) - (int64_t)sizeof(uint32_t)) / (int64_t)sizeof(uint4);
+        if (caps > 4096) caps = 4096;
+        if (caps >= 64) {
+            uint32_t *counts = (uint32_t *)workspace;
+            size_t off = ((size_t)n_img * cm.strips * sizeof(uint32_t) + 255) & ~(size_t)255;
+            if ((int64_t)(off + (size_t)n_img * cm.strips * caps * sizeof(uint4)) > workspace_bytes) --caps;
+            uint4 *lists = (uint4 *)((char *)workspace + off);
+            hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)((n_img + BIN_WAVES - 1) / BIN_WAVES)), dim3(BIN_WAVES * 64), 0,
+                               (hipStream_t)stream, a, cm, tw, counts, lists, (int)caps);
+            TDS_LAUNCH_CHECK("bin_faces_kernel");
+            size_t lds = lds_bytes(tw, res);
+            dim3 grid((unsigned)(n_img * cm.strips));
+            auto launch = [&](auto kern) {
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, grid, dim3(RBLOCK), lds, (hipStream_t)stream, a, cm, (const uint32_t *)counts, (const uint4 *)lists, (int)caps);
+            };
+            if (out_mode == TDS_OUT_F32) {
+                if (tw == 64) launch(raster_scene_list_kernel<64, float>); else if (tw == 32) launch(raster_scene_list_kernel<32, float>);
+                else if (tw == 16) launch(raster_scene_list_kernel<16, float>); else launch(raster_scene_list_kernel<8, float>);
+            } else {
+                if (tw == 64) launch(raster_scene_list_kernel<64, uint8_t>); else if (tw == 32) launch(raster_scene_list_kernel<32, uint8_t>);
+                else if (tw == 16) launch(raster_scene_list_kernel<16, uint8_t>); else launch(raster_scene_list_kernel<8, uint8_t>);
+            }
+            TDS_LAUNCH_CHECK("raster_scene_list_kernel");
+            return TDS_OK;
+        }
+    }
     TDS_LAUNCH_RASTER(raster_scene_kernel, a);
     TDS_LAUNCH_CHECK("raster_scene_kernel");
     return TDS_OK;
