@@ -274,20 +274,21 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town):
         smap = make_map(ops, *mesh, town['categories'])
         static = oracle_static(oracle, *mesh, town['categories']) if len(mesh[1]) else (np.zeros((0, 3), np.float32),) * 2 + (np.zeros((0, 3), np.int32),)
         mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
-        for tw, ws in ((0, True), (0, False), (64, True), (16, True), (16, False)):     # strip widths x {binned, fused} kernels
+        # {bit-plane kernel} + strip widths x {binned, fused} packed-key kernels
+        for tw, ws, bits in ((0, True, True), (0, True, False), (0, False, False), (64, True, False), (16, True, False), (16, False, False)):
             from torchdrivesim_amd import _native
             _native.lib().tds_raster_set_strip_width(tw)
-            ops.use_workspace = ws
+            ops.use_workspace, ops.use_bitplanes = ws, bits
             ops._workspaces.clear()
             try:
                 img, ref = render_both(ops, oracle, smap, static, st, sz, mask, st[..., :2].copy(), g[f'g5_{n}_cam_sc'], m['fov'], m['res'])
             finally:
                 _native.lib().tds_raster_set_strip_width(0)
-                ops.use_workspace = True
+                ops.use_workspace, ops.use_bitplanes = True, True
                 ops._workspaces.clear()
             assert img.shape == tuple(m['out_shape'])
             bad = (img != ref)
-            assert not bad.any(), f'{n} tw={tw} ws={ws}: {bad.sum()} of {bad.size} values differ in images {np.unique(np.nonzero(bad)[0:2], axis=1)[:, :8]}'
+            assert not bad.any(), f'{n} tw={tw} ws={ws} bits={bits}: {bad.sum()} of {bad.size} values differ in images {np.unique(np.nonzero(bad)[0:2], axis=1)[:, :8]}'
         assert ref.any()
 
 
@@ -320,14 +321,14 @@ def test_k3_random_town01_256_bit_exact(ops, oracle, town):
     static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
     sd = dev(state)
     cam_sc = sc_np(ops.heading_sc(sd[..., 2]))
-    for ws in (True, False):
-        ops.use_workspace = ws
+    for ws, bits in ((True, True), (True, False), (False, False)):
+        ops.use_workspace, ops.use_bitplanes = ws, bits
         try:
             img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 35.0, 256)
         finally:
-            ops.use_workspace = True
+            ops.use_workspace, ops.use_bitplanes = True, True
         bad = img != ref
-        assert not bad.any(), f'workspace={ws}: {bad.sum()} values differ'
+        assert not bad.any(), f'workspace={ws} bitplanes={bits}: {bad.sum()} values differ'
     assert (ref > 0).mean() > 0.05
 
 

@@ -12,6 +12,6 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-include-regex raster --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-include-regex "raster|bin_faces" --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py "$@" > $OUT/p$i.log 2>&1
 done
-python3 $R/tools/pmc_summary.py $OUT raster > $OUT/summary.json; rm -rf $OUT/p[0-9]; cat $OUT/summary.json
+python3 $R/tools/pmc_summary.py $OUT "raster|bin_faces" > $OUT/summary.json; rm -rf $OUT/p[0-9]; cat $OUT/summary.json

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--tw', type=int, nargs='*', default=[0])
     ap.add_argument('--debug', type=int, nargs='*', default=[0])
     ap.add_argument('--u8', action='store_true')
+    ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
     ap.add_argument('--no-ws', action='store_true', help='fused per-strip kernel instead of the binned persistent kernel')
     ap.add_argument('--steps-before', type=int, default=5, help='simulation steps before rendering (spreads the agents)')
     args = ap.parse_args()
@@ -29,6 +30,7 @@ def main():
     from torchdrivesim_amd.utils import Resolution
     dev = torch.device('cuda', 0)
     _ops.use_workspace = not args.no_ws
+    _ops.use_bitplanes = not args.no_bits
     sim, actions, _ = bench.build_simulator(args.batch, args.agents, dev, seed=1234)
     if args.u8:
         sim.renderer.cfg.out_dtype = 'uint8'

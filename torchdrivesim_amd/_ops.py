@@ -311,6 +311,7 @@ def offroad(smap, state, lenwid, threshold=0.5, present=None, sc=None):
 #: scratch for the binned fast path of K3, one per (device, cameras, resolution); never carries state between calls
 _workspaces = {}
 use_workspace = True
+use_bitplanes = True      # test hook: False forces the packed-key kernels
 
 
 def _raster_workspace(dev, n_img, res):
@@ -327,7 +328,7 @@ def _raster_workspace(dev, n_img, res):
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
 raster_events = None
 
-def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None):
+def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None):
     """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns,
     mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2) -> (B,Nc,3,res,res) float32 [0,255] or uint8."""
     B, Nc = cam_xy.shape[:2]
@@ -345,6 +346,14 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
         assert out.shape == (B, Nc, 3, res, res) and out.dtype == out_dtype and out.is_contiguous()
     p = lambda t, d, nme: nat.dev_ptr(t, d, nme) if N > 0 else None
     mode = nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8
+    # distinct actor keys (host side): enables the bit-plane kernel.  Callers that know them (Simulator) pass `key_table`;
+    # otherwise they are read back from the device tensor (a synchronisation -- fine for tests and one-off calls)
+    if key_table is None and N > 0 and use_bitplanes:
+        key_table = torch.unique(actor_key).cpu().tolist()
+    kt = None
+    if key_table is not None and use_bitplanes:
+        vals = [int(v) & 0xffffffff for v in key_table]
+        kt = (ctypes.c_uint32 * max(len(vals), 1))(*vals)
     ws = _raster_workspace(dev, B * Nc, int(res)) if use_workspace else None
     ev = None
     if raster_events is not None:          # bench.py: HIP events on the launch stream, right around the kernel
@@ -353,7 +362,8 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     nat.call('tds_raster_scene', dev, smap.handle, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
              p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
              B, Nc, N, float(2.0 / fov), int(res), mode, nat.dev_ptr(out, out_dtype, 'out'),
-             None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(), nat.stream_ptr(dev))
+             None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(),
+             None if kt is None else ctypes.cast(kt, ctypes.c_void_p), 0 if kt is None else len(key_table), nat.stream_ptr(dev))
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         raster_events.append(ev)

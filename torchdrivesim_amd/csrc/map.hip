@@ -119,6 +119,14 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         delete m;
         return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
     }
+    m->n_uniq = 0;
+    for (const GridEntry &ge : entries) {
+        bool seen = false;
+        for (int i = 0; i < m->n_uniq && !seen; ++i) seen = m->uniq_keys[i] == ge.key;
+        if (seen) continue;
+        if (m->n_uniq == 64) { m->n_uniq = -1; break; }
+        m->uniq_keys[m->n_uniq++] = ge.key;
+    }
     m->bytes = (int64_t)(be + bc);
     m->view.entries = (const GridEntry *)m->d_entries;
     m->view.cell_start = (const int32_t *)m->d_cell_start;

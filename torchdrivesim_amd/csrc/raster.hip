@@ -829,6 +829,396 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
     if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
+// =========================================================================================================
+// Bit-plane fast path.  A scene uses only a handful of distinct keys (rank + colour: road, lane kinds, vehicle, direction
+// ...).  Instead of one u32 per pixel, the workgroup keeps ONE BIT per pixel and key: plane[k][y][x / 32].  Painting a
+// span is then one or two ds_or_b32 whatever its length (bits run along OpenCV's x, the span direction), a whole 256x256
+// image fits in 8 KiB per key so a single workgroup renders the entire camera (no strips, every face is set up once), and
+// the final pass resolves, per pixel, the highest key whose bit is set.  Equal keys paint the same bit, so -- exactly as
+// with ds_max on packed keys -- the result does not depend on the order in which faces are processed.
+// =========================================================================================================
+constexpr int BWAVES = 8;
+constexpr int BBLOCK = BWAVES * 64;
+constexpr int MAX_KEYS = 16;
+constexpr int ROWS_PER_ITEM = 8;
+
+struct KeyTable { uint32_t key[MAX_KEYS]; int n; };      // ascending = painter order (later wins)
+
+struct BitCtx {
+    uint32_t *planes;   // [K][H][wpr]
+    uint32_t *q;        // [4][QCAP]: plane index, then the three packed vertices
+    uint32_t *blocks;   // [BLOCK_CAP]
+    int qlen, lane, H, W, X0, TWp, wpr, debug;
+};
+
+// bits [s0, s1] (strip-local columns) of one row of one plane
+__device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int s0, int s1) {
+    const int w0 = s0 >> 5, w1 = s1 >> 5;
+    const uint32_t m0 = 0xffffffffu << (s0 & 31), m1 = 0xffffffffu >> (31 - (s1 & 31));
+    if (w0 == w1) {
+        atomicOr(rowp + w0, m0 & m1);
+    } else {
+        atomicOr(rowp + w0, m0);
+        for (int wd = w0 + 1; wd < w1; ++wd) atomicOr(rowp + wd, 0xffffffffu);
+        atomicOr(rowp + w1, m1);
+    }
+}
+
+// cv::Line into a bit plane (same walk as draw_line; consecutive pixels that share a word are merged into one ds_or)
+__device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int TWp, int wpr, int ax, int ay, int bx, int by) {
+    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+    if ((unsigned long long)x1 >= (unsigned long long)W || (unsigned long long)x2 >= (unsigned long long)W ||
+        (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
+        if (!clip_line(W, H, x1, y1, x2, y2)) return;
+    }
+    int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+    int px = (int)x1, py = (int)y1;
+    int step_y = 1;
+    if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }
+    if (px >= X0 + TWp || px + dx < X0) return;
+    if (dy < 0) { dy = -dy; step_y = -1; }
+    const bool vert = dy > dx;
+    const int dmaj = vert ? dy : dx, dmin = vert ? dx : dy;
+    int err = dmaj - (dmin + dmin);
+    const int plus_delta = dmaj + dmaj, minus_delta = -(dmin + dmin);
+    int k = 0;
+    if (px < X0) {
+        const int t = X0 - px;
+        if (!vert) {
+            k = t;
+            int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
+            err += k * minus_delta + m * plus_delta;
+            px += k; py += step_y * m;
+        } else {
+            k = (int)(((unsigned)(2 * dmaj) * (unsigned)t - (unsigned)dmaj + (unsigned)(2 * dmin)) / (unsigned)(2 * dmin));
+            int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
+            err += k * minus_delta + m * plus_delta;
+            py += step_y * k; px += m;
+        }
+    }
+    const int lim = X0 + TWp;
+    if (vert) {
+        // y-major: one pixel per row, every step lands in another word
+        uint32_t *rowp = plane + py * wpr;
+        const int rstep = step_y * wpr;
+        for (; k <= dmaj && px < lim; ++k) {
+            const int lx = px - X0;
+            atomicOr(rowp + (lx >> 5), 1u << (lx & 31));
+            const bool neg = err < 0;
+            err += minus_delta + (neg ? plus_delta : 0);
+            rowp += rstep;
+            px += neg ? 1 : 0;
+        }
+    } else {
+        // x-major: consecutive pixels of a row that share a word are merged into one ds_or
+        int cur = -1;
+        uint32_t mask = 0;
+        int rowoff = py * wpr;
+        const int rstep = step_y * wpr;
+        for (; k <= dmaj && px < lim; ++k) {
+            const int lx = px - X0;
+            const int addr = rowoff + (lx >> 5);
+            const uint32_t bit = 1u << (lx & 31);
+            if (addr != cur) {
+                if (mask) atomicOr(plane + cur, mask);
+                cur = addr; mask = bit;
+            } else {
+                mask |= bit;
+            }
+            const bool neg = err < 0;
+            err += minus_delta + (neg ? plus_delta : 0);
+            px += 1;
+            rowoff += neg ? rstep : 0;
+        }
+        if (mask) atomicOr(plane + cur, mask);
+    }
+}
+
+// exact sequential path for faces outside the packed coordinate range (see fill_generic)
+__device__ __noinline__ void fill_generic_bits(uint32_t *plane, int H, int W, int X0, int TWp, int wpr, int x0, int y0, int x1, int y1, int x2,
+                                               int y2) {
+    const int px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+    draw_line_bits(plane, H, W, X0, TWp, wpr, px[2], py[2], px[0], py[0]);
+    draw_line_bits(plane, H, W, X0, TWp, wpr, px[0], py[0], px[1], py[1]);
+    draw_line_bits(plane, H, W, X0, TWp, wpr, px[1], py[1], px[2], py[2]);
+    long long xmin = px[0], xmax = px[0], ymin = py[0], ymax = py[0];
+    int imin = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (py[i] < ymin) { ymin = py[i]; imin = i; }
+        if (py[i] > ymax) ymax = py[i];
+        if (px[i] > xmax) xmax = px[i];
+        if (px[i] < xmin) xmin = px[i];
+    }
+    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    if (ymax > H - 1) ymax = H - 1;
+    int eidx[2] = {imin, imin}, edi[2] = {1, 2}, eye[2] = {(int)ymin, (int)ymin};
+    long long ex[2] = {-65536, -65536}, edx[2] = {0, 0};
+    int edges = 3, y = (int)ymin;
+    do {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= eye[i]) {
+                int idx0 = eidx[i], idx = idx0 + edi[i];
+                if (idx >= 3) idx -= 3;
+                for (; edges-- > 0;) {
+                    int ty = py[idx];
+                    if (ty > y) {
+                        long long xs = (long long)px[idx0] << 16, xe = (long long)px[idx] << 16;
+                        eye[i] = ty;
+                        edx[i] = div_trunc((xe - xs) * 2 + (ty - y), 2ll * (ty - y));
+                        ex[i] = xs;
+                        eidx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += edi[i];
+                    if (idx >= 3) idx -= 3;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            long long xl = ex[0] < ex[1] ? ex[0] : ex[1], xr = ex[0] < ex[1] ? ex[1] : ex[0];
+            long long xx1 = (xl + 32768) >> 16, xx2 = (xr + 32768) >> 16;
+            if (xx2 >= 0 && xx1 < W) {
+                int s0 = (int)(xx1 < 0 ? 0 : xx1), s1 = (int)(xx2 >= W ? W - 1 : xx2);
+                s0 = max(s0, X0); s1 = min(s1, X0 + TWp - 1);
+                if (s0 <= s1) paint_span_bits(plane + y * wpr, s0 - X0, s1 - X0);
+            }
+        }
+        ex[0] += edx[0];
+        ex[1] += edx[1];
+    } while (++y <= (int)ymax);
+}
+
+// Rasterise the first n (<= 64) faces of the wave's queue into the bit planes.
+//   1. lane f sets up face f (rows to paint, the two edge chains);
+//   2. faces are cut into items of ROWS_PER_ITEM rows, numbered by a wave prefix sum; the wave processes one item per lane:
+//      the edge data comes from the owner lane by ds_bpermute, each row costs one span evaluation and one or two ds_or --
+//      no per-pixel loop, so slivers and big road triangles cost the same per row;
+//   3. the three outline edges, one face per lane.
+__device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
+    const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0, TWp = w.TWp, wpr = w.wpr;
+    wave_sync();
+    uint32_t kidx = 0, v0 = 0, v1 = 0, v2 = 0;
+    int nitems = 0;
+    FaceRows r = {0, 0, 0, 0, 0, 0};
+    Chain a = {0, 0, NO_SWITCH, 0, 0}, b = {0, 0, NO_SWITCH, 0, 0};
+    if (lane < n) {
+        kidx = w.q[lane]; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
+        const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
+        r = face_rows(px, py, H, W, X0, TWp);
+        if (r.nrows > 0 && !(w.debug & 16)) {
+            int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
+            a = make_chain(px, py, r.imin, i1, i2);
+            b = make_chain(px, py, r.imin, i2, i1);
+            nitems = (r.nrows + ROWS_PER_ITEM - 1) / ROWS_PER_ITEM;
+        }
+    }
+    if (__ballot(nitems > 0) != 0) {
+        int incl = nitems;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const int excl = incl - nitems;
+        const int total = __shfl(incl, 63);
+        const int sh_a = (a.xs1 & 0xffff) | (a.xs2 << 16), sh_b = (b.xs1 & 0xffff) | (b.xs2 << 16);
+        const int sh_sw = (min(a.ysw, 0x7fff) & 0xffff) | (min(b.ysw, 0x7fff) << 16);
+        const int sh_y = (r.ymin & 0xffff) | (r.ystart << 16), sh_n = r.nrows | ((int)kidx << 16);
+        for (int base = 0; base < total; base += BLOCK_CAP) {
+            int lo = max(excl, base), hi = min(incl, base + BLOCK_CAP);
+            for (int idx = lo; idx < hi; ++idx) w.blocks[idx - base] = (uint32_t)lane | ((uint32_t)(idx - excl) << 8);
+            wave_sync();
+            const int m = min(BLOCK_CAP, total - base);
+            for (int i0 = 0; i0 < m; i0 += 64) {
+                const int i = i0 + lane;
+                const bool live = i < m;
+                const uint32_t e = live ? w.blocks[i] : 0u;
+                const int f = e & 0xff, t = (int)(e >> 8);
+                const int ga = __shfl(sh_a, f), gb = __shfl(sh_b, f), gsw = __shfl(sh_sw, f), gy = __shfl(sh_y, f), gn = __shfl(sh_n, f);
+                const int adx1 = __shfl(a.dx1, f), adx2 = __shfl(a.dx2, f), bdx1 = __shfl(b.dx1, f), bdx2 = __shfl(b.dx2, f);
+                if (live) {
+                    const int ymin = (int)(short)(gy & 0xffff), ystart = gy >> 16, nrows = gn & 0xffff, k = gn >> 16;
+                    const int y0 = ystart + t * ROWS_PER_ITEM, y1 = min(y0 + ROWS_PER_ITEM, ystart + nrows) - 1;
+                    const int aysw = (int)(short)(gsw & 0xffff), bysw = gsw >> 16;           // 0x7fff = no second edge
+                    const int axs1 = (int)(short)(ga & 0xffff), axs2 = ga >> 16, bxs1 = (int)(short)(gb & 0xffff), bxs2 = gb >> 16;
+                    long long xa = chain_x(axs1, adx1, aysw, axs2, adx2, ymin, y0);
+                    long long xb = chain_x(bxs1, bdx1, bysw, bxs2, bdx2, ymin, y0);
+                    int da = y0 >= aysw ? adx2 : adx1, db = y0 >= bysw ? bdx2 : bdx1;
+                    uint32_t *rowp = w.planes + ((size_t)k * H + y0) * wpr;
+                    for (int y = y0; y <= y1; ++y, rowp += wpr) {
+                        long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+                        int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+                        // OpenCV draws [xx1, xx2] clamped to the image unless it lies entirely outside
+                        int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TWp - 1);
+                        if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
+                        xa += da; xb += db;
+                        if (y + 1 == aysw) { xa = (long long)axs2 << 16; da = adx2; }
+                        if (y + 1 == bysw) { xb = (long long)bxs2 << 16; db = bdx2; }
+                    }
+                }
+            }
+            wave_sync();
+        }
+    }
+    // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2); one edge per lane over the 3n edges of the batch
+    for (int t0 = 0; t0 < 3 * n && !(w.debug & 8); t0 += 64) {
+        const int t = t0 + lane;
+        if (t < 3 * n) {
+            const int f = t / 3, l = t - 3 * f;
+            const int ia = l == 0 ? 2 : l - 1, ib = l;
+            const uint32_t k2 = w.q[f], pa = w.q[(1 + ia) * QCAP + f], pb = w.q[(1 + ib) * QCAP + f];
+            draw_line_bits(w.planes + (size_t)k2 * H * wpr, H, W, X0, TWp, wpr, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb));
+        }
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool acc, uint32_t key, const int (&px)[3], const int (&py)[3], bool more) {
+    // plane of the key = its position in the ascending table
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < MAX_KEYS; ++i) k += (i < kt.n && kt.key[i] < key) ? 1 : 0;
+    bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
+    if (__builtin_expect(__ballot(big) != 0, 0)) {
+        if (big) fill_generic_bits(w.planes + (size_t)k * w.H * w.wpr, w.H, w.W, w.X0, w.TWp, w.wpr, px[0], py[0], px[1], py[1], px[2], py[2]);
+        acc = acc && !big;
+    }
+    unsigned long long pending = __ballot(acc);
+    for (;;) {
+        if (pending != 0) {
+            const int room = QCAP - w.qlen;
+            int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pending >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pending, 0));
+            bool take = acc && ((pending >> w.lane) & 1) && rank < room;
+            if (take) {
+                int slot = w.qlen + rank;
+                w.q[slot] = (uint32_t)k;
+                w.q[1 * QCAP + slot] = pack_xy(px[0], py[0]);
+                w.q[2 * QCAP + slot] = pack_xy(px[1], py[1]);
+                w.q[3 * QCAP + slot] = pack_xy(px[2], py[2]);
+            }
+            unsigned long long taken = __ballot(take);
+            w.qlen += __popcll(taken);
+            pending &= ~taken;
+        }
+        if (w.qlen == QCAP || (!more && pending == 0 && w.qlen > 0)) {
+            process_batch_bits(w, w.qlen);
+            w.qlen = 0;
+        }
+        if (pending == 0) break;
+    }
+}
+
+// resolve the planes (highest key wins) and stream the strip out; one item = 4 consecutive rows x 32 columns
+template <typename OutT>
+__device__ inline void write_out_bits(const uint32_t *planes, const float4 *ftab, int K, OutT *out, int64_t img, int res, int X0, int TWp,
+                                      int wpr, int tid) {
+    const int H = res, W = res;
+    const int64_t plane_px = (int64_t)W * H;
+    OutT *o = out + img * 3 * plane_px;
+    const int cols = min(TWp, W - X0);
+    if ((H & 3) == 0) {
+        const int quads = H >> 2;
+        for (int item = tid; item < quads * wpr; item += BBLOCK) {
+            const int rq = item % quads, xw = item / quads, y0 = rq * 4;
+            if (xw * 32 >= cols) continue;
+            uint32_t s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0}, cov[4] = {0, 0, 0, 0};
+            for (int k = K - 1; k >= 0; --k) {                       // wave-uniform
+                const int idx = k + 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t wd = planes[((size_t)k * H + y0 + j) * wpr + xw];
+                    uint32_t s = wd & ~cov[j];
+                    cov[j] |= wd;
+                    s0[j] |= (idx & 1) ? s : 0u; s1[j] |= (idx & 2) ? s : 0u; s2[j] |= (idx & 4) ? s : 0u; s3[j] |= (idx & 8) ? s : 0u;
+                }
+            }
+            const int nb = min(32, cols - xw * 32);
+            for (int bpos = 0; bpos < nb; ++bpos) {
+                float4 c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int idx = ((s0[j] >> bpos) & 1) | (((s1[j] >> bpos) & 1) << 1) | (((s2[j] >> bpos) & 1) << 2) | (((s3[j] >> bpos) & 1) << 3);
+                    c[j] = ftab[idx];
+                }
+                const int64_t off = (int64_t)(X0 + xw * 32 + bpos) * H + y0;
+                if constexpr (sizeof(OutT) == 4) {
+                    *(float4 *)(o + off) = make_float4(c[0].x, c[1].x, c[2].x, c[3].x);
+                    *(float4 *)(o + plane_px + off) = make_float4(c[0].y, c[1].y, c[2].y, c[3].y);
+                    *(float4 *)(o + 2 * plane_px + off) = make_float4(c[0].z, c[1].z, c[2].z, c[3].z);
+                } else {
+                    auto pk = [](float a0, float a1, float a2, float a3) {
+                        return (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
+                    };
+                    *(uint32_t *)(o + off) = pk(c[0].x, c[1].x, c[2].x, c[3].x);
+                    *(uint32_t *)(o + plane_px + off) = pk(c[0].y, c[1].y, c[2].y, c[3].y);
+                    *(uint32_t *)(o + 2 * plane_px + off) = pk(c[0].z, c[1].z, c[2].z, c[3].z);
+                }
+            }
+        }
+        return;
+    }
+    for (int i = tid; i < H * cols; i += BBLOCK) {                   // odd resolutions: one pixel per thread
+        const int lx = i / H, y = i - lx * H;
+        int idx = 0;
+        for (int k = K - 1; k >= 0 && idx == 0; --k)
+            if ((planes[((size_t)k * H + y) * wpr + (lx >> 5)] >> (lx & 31)) & 1) idx = k + 1;
+        const float4 cc = ftab[idx];
+        const int64_t off = (int64_t)(X0 + lx) * H + y;
+        o[off] = (OutT)cc.x; o[plane_px + off] = (OutT)cc.y; o[2 * plane_px + off] = (OutT)cc.z;
+    }
+}
+
+// one workgroup (8 waves) per (camera, strip); for the usual resolutions one strip is the whole image
+template <typename OutT>
+__global__ void __launch_bounds__(BBLOCK, 2) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
+    int64_t img;
+    int strip;
+    block_to_image(c.n_img * c.strips, c.strips, img, strip);
+    const int X0 = strip * TWp;
+    const int plane_dw = K * H * wpr;
+    uint32_t *planes = smem;
+    float4 *ftab = (float4 *)(smem + ((plane_dw + 3) & ~3));          // [K + 1] colours as floats, entry 0 = background
+    for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
+    if (tid <= K) {
+        uint32_t key = tid == 0 ? 0u : kt.key[tid - 1];
+        ftab[tid] = make_float4((float)((key >> 16) & 255), (float)((key >> 8) & 255), (float)(key & 255), 0.0f);
+    }
+    BitCtx w;
+    w.planes = planes;
+    w.q = (uint32_t *)(ftab + MAX_KEYS + 1) + wave * WAVE_LDS_DW;
+    w.blocks = w.q + Q_DW;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug;
+    Camera cam;
+    {
+        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
+        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
+        make_polygon(cam, c.scale, res);
+    }
+    __syncthreads();
+    ScanState st;
+    scan_init(st, a, c, cam, wave, X0, TWp);
+    for (;;) {
+        bool acc;
+        uint32_t key;
+        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+        const bool more = scan_step<BWAVES>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py);
+        drain_bits(w, kt, acc, key, px, py, more);
+        if (!more) break;
+    }
+    __syncthreads();
+    if (!(c.debug & 4)) write_out_bits<OutT>(planes, ftab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
+}
+
+inline size_t bits_lds_bytes(int K, int res, int twp) {
+    size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
+    return plane_dw * 4 + (MAX_KEYS + 1) * sizeof(float4) + (size_t)BWAVES * WAVE_LDS_DW * 4;
+}
+
 // Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
 template <int TW, typename OutT>
 __global__ void __launch_bounds__(RBLOCK, 4) raster_mesh_kernel(MeshArgs a, CommonArgs c) {
@@ -945,7 +1335,7 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
 TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                                 const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                 int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                                int64_t workspace_bytes, void *stream) {
+                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, void *stream) {
     TDS_CHECK_ARG(map, "tds_raster_scene: null map");
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
     TDS_CHECK_ARG(map->n_levels > 0 || map->view.nx == 0, "tds_raster_scene: the map was created without rendering data");
@@ -964,7 +1354,41 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
-    // fast path: bin once per camera (K3a), then rasterise per strip from the lists (K3b)
+    // fastest path: bit planes, when the scene uses at most MAX_KEYS distinct keys and the caller listed the actors' keys
+    if ((N == 0 || (actor_keys && n_actor_keys > 0)) && map->n_uniq >= 0 && !(g_debug & 64)) {
+        KeyTable kt;
+        kt.n = 0;
+        bool ok = true;
+        auto add = [&](uint32_t key) {
+            for (int i = 0; i < kt.n; ++i) if (kt.key[i] == key) return;
+            if (kt.n == MAX_KEYS) { ok = false; return; }
+            kt.key[kt.n++] = key;
+        };
+        for (int i = 0; i < map->n_uniq; ++i) add(map->uniq_keys[i]);
+        for (int i = 0; i < (N > 0 ? n_actor_keys : 0); ++i) add(actor_keys[i]);
+        for (int i = kt.n; i < MAX_KEYS; ++i) kt.key[i] = 0xffffffffu;
+        if (ok && kt.n > 0) {
+            for (int i = 1; i < kt.n; ++i)                                   // ascending (insertion sort)
+                for (int j = i; j > 0 && kt.key[j - 1] > kt.key[j]; --j) { uint32_t t = kt.key[j]; kt.key[j] = kt.key[j - 1]; kt.key[j - 1] = t; }
+            // strip width: the whole (32-padded) image if the planes fit 64 KiB, else the widest multiple of 32 that does
+            int twp = (res + 31) & ~31;
+            while (twp > 32 && (size_t)kt.n * res * (twp / 8) > 64 * 1024) twp -= 32;
+            size_t lds = bits_lds_bytes(kt.n, res, twp);
+            if (lds <= 150 * 1024) {
+                CommonArgs cb = cm;
+                cb.strips = (res + twp - 1) / twp;
+                dim3 grid((unsigned)(n_img * cb.strips));
+                auto launch = [&](auto kern) {
+                    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(BBLOCK), lds, (hipStream_t)stream, a, cb, kt, twp);
+                };
+                if (out_mode == TDS_OUT_F32) launch(raster_scene_bits_kernel<float>); else launch(raster_scene_bits_kernel<uint8_t>);
+                TDS_LAUNCH_CHECK("raster_scene_bits_kernel");
+                return TDS_OK;
+            }
+        }
+    }
+    // general path: bin once per camera (K3a), then rasterise per strip from the lists (K3b)
     if (workspace && !(g_debug & 32) && cm.strips <= MAX_STRIPS) {
         int64_t caps = (workspace_bytes / (n_img * cm.strips) - (int64_t)sizeof(uint32_t)) / (int64_t)sizeof(uint4);
         if (caps > 4096) caps = 4096;

@@ -72,4 +72,6 @@ struct tds_map {
     int device;
     int64_t V, F, n_entries, bytes;
     int n_levels;
+    uint32_t uniq_keys[64];     // distinct face keys of the map (bit-plane fast path of K3)
+    int n_uniq;                 // -1: more than 64
 };

@@ -69,10 +69,12 @@ class HipRenderer(BirdviewRenderer):
         return _ops.StaticMap(verts[:, :2], faces, face_z, face_rgb, levels, device=device or rgb_mesh.device)
 
     def render_scene(self, static_map: _ops.StaticMap, state: Tensor, agent_sc: Tensor, tmpl: Tensor, actor_key: Tensor, mask: Tensor,
-                     camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None) -> Tensor:
+                     camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None,
+                     key_table=None) -> Tensor:
         """-> B x Nc x 3 x H x W"""
         res = self.res if res is None else res
         if res.width != res.height:
             raise RuntimeError('only square resolutions are supported')
         fov = fov if fov is not None else 2.0 / self.scale
-        return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype)
+        return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype,
+                                 key_table=key_table)

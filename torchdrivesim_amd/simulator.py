@@ -456,14 +456,15 @@ class Simulator:
         else:
             maps = [(self.renderer.make_static_map(bg[b:b + 1], actor_levels, device=dev), b) for b in range(B)]
         tmpl = actor_template(sizes).contiguous()                   # B x N x 7 x 2
-        keys = []
+        keys, key_tables = [], []
         for smap, _ in maps:
             body = torch.tensor([(smap.rank_of(lv[n]) << 24) | int(_ops.quantise_colors(torch.tensor(cm[n], dtype=torch.float32) / 255.0)) for n in names],
                                 dtype=torch.int64, device=dev)
             dkey = (smap.rank_of(lv['direction']) << 24) | int(_ops.quantise_colors(torch.tensor(cm['direction'], dtype=torch.float32) / 255.0))
             k = torch.stack([body[types.long()], torch.full_like(types.long(), dkey)], dim=-1)
             keys.append(k.to(torch.int32).contiguous())             # bit pattern of the uint32 key
-        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys)
+            key_tables.append(sorted(set(body.tolist()) | {dkey}))   # distinct actor keys, known on the host (bit-plane kernel)
+        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables)
         return self._scene_cache
 
     # ------------------------------------------------------------------------------------------------- rendering
@@ -486,13 +487,13 @@ class Simulator:
             state = self.get_all_agent_state().detach()
             agent_sc = _ops.heading_sc(state[..., 2])
             out = []
-            for (smap, b), keys in zip(scene['maps'], scene['keys']):
+            for (smap, b), keys, ktab in zip(scene['maps'], scene['keys'], scene['key_tables']):
                 sl = slice(None) if b is None else slice(b, b + 1)
                 k = keys[sl]
                 if custom_agent_colors is not None:
                     raise NotImplementedError('custom_agent_colors: per-camera colours are not wired into the fused path yet')
                 out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], scene['tmpl'][sl], k, mask[sl].contiguous(),
-                                                      camera_xy[sl].detach(), camera_sc[sl].detach(), res=res, fov=fov))
+                                                      camera_xy[sl].detach(), camera_sc[sl].detach(), res=res, fov=fov, key_table=ktab))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
         # any other BirdviewRenderer: the reference's generic dataflow (explicit per-camera mesh)
         rgb_mesh = self.birdview_mesh_generator.generate(n_cam, agent_state=self.get_all_agent_state()[:, None].expand(-1, n_cam, -1, -1),
