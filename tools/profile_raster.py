@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--tw', type=int, nargs='*', default=[0])
     ap.add_argument('--debug', type=int, nargs='*', default=[0])
     ap.add_argument('--u8', action='store_true')
+    ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
     ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
     ap.add_argument('--no-ws', action='store_true', help='fused per-strip kernel instead of the binned persistent kernel')
     ap.add_argument('--steps-before', type=int, default=5, help='simulation steps before rendering (spreads the agents)')
@@ -44,7 +45,9 @@ def main():
     nbytes = img.numel() * img.element_size()
     print(f'images {img.shape[0] * img.shape[1]}, output {nbytes / 1e9:.2f} GB, nonzero fraction {(img[:8] > 0).float().mean().item():.3f}')
     del img
-    for tw in args.tw:
+    L.tds_raster_set_bits_waves.argtypes = [ctypes.c_int]
+    for tw, bw in [(t, b) for t in args.tw for b in args.bits_waves]:
+        L.tds_raster_set_bits_waves(bw)
         for dbg in args.debug:
             L.tds_raster_set_strip_width(tw)
             L.tds_raster_set_debug(dbg)
@@ -54,7 +57,7 @@ def main():
             torch.cuda.synchronize()
             ms = np.array([a.elapsed_time(b) for a, b in _ops.raster_events])
             _ops.raster_events = None
-            print(f'tw={tw:2d} debug={dbg:2d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
+            print(f'tw={tw:3d} waves={bw} debug={dbg:2d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
                   f'({nbytes / np.median(ms) / 1e6 / 80:.1f}% of 8 TB/s)')
     L.tds_raster_set_strip_width(0)
     L.tds_raster_set_debug(0)

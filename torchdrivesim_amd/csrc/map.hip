@@ -4,6 +4,8 @@
 // (B*A*4, F, 3, 3) tensor; here each corner walks grid rings outwards until the best distance is proven minimal.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "tds_common.h"
@@ -40,6 +42,35 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
             if (!any) { minx = maxx = x; miny = maxy = y; any = true; }
             minx = std::min(minx, x); maxx = std::max(maxx, x); miny = std::min(miny, y); maxy = std::max(maxy, y);
         }
+    // Outline edges shared by faces of the same key: Line(p, q) and Line(q, p) paint the same pixels (OpenCV walks left to
+    // right), so when two faces with the same key share an edge only one of them has to draw it.  dup[f] bit l marks edge l of
+    // face f as a repeat of an edge of an EARLIER face; the rasteriser skips it only when one of the edge's end points passes
+    // the trim test, which guarantees that the earlier face is drawn too (it shares both end points).
+    std::vector<uint8_t> dup((size_t)F, 0);
+    if (face_z) {
+        struct EdgeKey { uint32_t a[4]; uint32_t key; bool operator==(const EdgeKey &o) const { return memcmp(this, &o, sizeof(EdgeKey)) == 0; } };
+        struct EdgeHash { size_t operator()(const EdgeKey &k) const { size_t h = 1469598103934665603ull; for (int i = 0; i < 4; ++i) h = (h ^ k.a[i]) * 1099511628211ull; return (h ^ k.key) * 1099511628211ull; } };
+        std::unordered_map<EdgeKey, int64_t, EdgeHash> seen;
+        seen.reserve((size_t)F * 3);
+        for (int64_t f = 0; f < F; ++f) {
+            int rank = -1;
+            for (int l = 0; l < n_levels; ++l) if (levels[l] == face_z[f]) { rank = l + 1; break; }
+            if (rank < 0) continue;
+            uint32_t key = ((uint32_t)rank << 24) | (face_rgb[f] & 0xFFFFFFu);
+            const int ea[3] = {2, 0, 1}, eb[3] = {0, 1, 2};
+            for (int l = 0; l < 3; ++l) {
+                float p[2] = {verts[2 * faces[3 * f + ea[l]]], verts[2 * faces[3 * f + ea[l]] + 1]};
+                float q[2] = {verts[2 * faces[3 * f + eb[l]]], verts[2 * faces[3 * f + eb[l]] + 1]};
+                if (p[0] > q[0] || (p[0] == q[0] && p[1] > q[1])) { std::swap(p[0], q[0]); std::swap(p[1], q[1]); }
+                EdgeKey ek;
+                memcpy(&ek.a[0], &p[0], 4); memcpy(&ek.a[1], &p[1], 4); memcpy(&ek.a[2], &q[0], 4); memcpy(&ek.a[3], &q[1], 4);
+                ek.key = key;
+                auto it = seen.find(ek);
+                if (it == seen.end()) seen.emplace(ek, f);
+                else if (it->second != f) dup[(size_t)f] |= (uint8_t)(1u << l);
+            }
+        }
+    }
     std::vector<int32_t> cell_start;
     std::vector<GridEntry> entries;
     int nx = 0, ny = 0;
@@ -48,7 +79,7 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         inv = 1.0f / cell;
         nx = tds::cell_coord(maxx, ox, inv) + 1;
         ny = tds::cell_coord(maxy, oy, inv) + 1;
-        bool too_big = nx > 32767 || ny > 32767 || (int64_t)nx * ny > (int64_t)(1 << 26);
+        bool too_big = nx > 8191 || ny > 8191 || (int64_t)nx * ny > (int64_t)(1 << 26);
         int64_t total = 0;
         if (!too_big) {
             cell_start.assign((size_t)nx * ny + 1, 0);
@@ -94,7 +125,7 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
             int cy0 = tds::cell_coord(fy0, oy, inv), cy1 = tds::cell_coord(fy1, oy, inv);
             for (int cy = cy0; cy <= cy1; ++cy)
                 for (int cx = cx0; cx <= cx1; ++cx) {
-                    e.ddx = (uint16_t)(cx - cx0); e.ddy = (uint16_t)(cy - cy0);
+                    e.ddx = (uint16_t)(cx - cx0); e.ddy = (uint16_t)((cy - cy0) | ((int)dup[(size_t)f] << 13));
                     entries[(size_t)cursor[(size_t)cy * nx + cx]++] = e;
                 }
         }

@@ -459,14 +459,24 @@ __device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
 
 // project (fp32, reference order) -> reject faces whose pixel bounding box misses the strip -> trim test
 // (>= 1 vertex inside the 1.05x view polygon, cv2.py:32-41).  The cheap exact rejection comes first.
+// `ins` receives one bit per vertex that passed the trim test.
 __device__ inline bool trim_project(const Camera &cam, float scale, int res, int X0, int TW, const float *sx, const float *sy,
-                                    int *px, int *py) {
+                                    int *px, int *py, unsigned &ins) {
+    ins = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) project(cam, scale, res, sx[k], sy[k], px[k], py[k]);
     int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
     int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
     if (xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res) return false;
-    return inside_polygon(cam, sx[0], sy[0]) || inside_polygon(cam, sx[1], sy[1]) || inside_polygon(cam, sx[2], sy[2]);
+    ins = (inside_polygon(cam, sx[0], sy[0]) ? 1u : 0u) | (inside_polygon(cam, sx[1], sy[1]) ? 2u : 0u) | (inside_polygon(cam, sx[2], sy[2]) ? 4u : 0u);
+    return ins != 0;
+}
+
+// Which of the three outline edges (l = 0: v2-v0, 1: v0-v1, 2: v1-v2) must be drawn: an edge flagged as the repeat of an
+// earlier same-key face's edge is skipped when one of its end points passed the trim test (then that face is drawn as well)
+__device__ inline unsigned edge_mask(unsigned dup, unsigned ins) {
+    const unsigned e0 = (ins & 5u) ? 1u : 0u, e1 = (ins & 3u) ? 2u : 0u, e2 = (ins & 6u) ? 4u : 0u;    // end points of edge l inside?
+    return 7u & ~(dup & (e0 | e1 | e2));
 }
 
 template <int TW, typename OutT>
@@ -630,8 +640,10 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, con
 // one producer step: at most one candidate face per lane; returns false when the producer is exhausted
 template <int NW = RWAVES>
 __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane,
-                                          int wave, int X0, int TWw, bool &acc, uint32_t &key, int (&px)[3], int (&py)[3]) {
+                                          int wave, int X0, int TWw, bool &acc, uint32_t &key, int (&px)[3], int (&py)[3], unsigned &edges) {
     const MapView &m = a.map;
+    unsigned ins = 0;
+    edges = 7u;
     const int res = c.res;
     const int64_t b = img / a.Nc;
     acc = false;
@@ -672,8 +684,9 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
             const int f = st.f;
             float fx[3] = {f == 0 ? st.sx0 : (f == 1 ? st.sx1 : st.sx4), f == 0 ? st.sx1 : (f == 1 ? st.sx3 : st.sx5), f == 0 ? st.sx3 : (f == 1 ? st.sx2 : st.sx6)};
             float fy[3] = {f == 0 ? st.sy0 : (f == 1 ? st.sy1 : st.sy4), f == 0 ? st.sy1 : (f == 1 ? st.sy3 : st.sy5), f == 0 ? st.sy3 : (f == 1 ? st.sy2 : st.sy6)};
-            acc = st.near && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py);
+            acc = st.near && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
             key = f == 2 ? st.kdir : st.kbody;
+            edges = edge_mask(f == 1 ? 2u : 0u, ins);      // body faces [0,1,3] and [1,3,2] share the edge 1-3 (edge 1 of the second)
             ++st.f;
         }
         if (st.f >= 3) {
@@ -692,7 +705,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
             float2 t0 = a.tmpl[b * a.N * 7];
             float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
             float fx[3] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[3] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
-            acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py);
+            acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
             key = a.actor_key[2 * b * a.N];
         }
         st.phase = 2;
@@ -709,14 +722,15 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
             if (i < e1) {
                 const uint4 *ep = (const uint4 *)(m.entries + i);
                 uint4 u0 = ep[0], u1 = ep[1];
-                unsigned dd = u1.w;                                     // ddx | ddy << 16: offsets from the bbox-min cell
+                unsigned dd = u1.w;                                     // ddx | ddy << 16 (offsets from the bbox-min cell) | repeated-edge bits << 29
                 // exactly one of the scanned cells owns the face: the first one its bounding box touches
-                bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && (((dd >> 16) == 0) || (st.cy == st.cy0));
+                bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && ((((dd >> 16) & 0x1fffu) == 0) || (st.cy == st.cy0));
                 if (owner) {
                     float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
                     float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
                     key = u1.z;
-                    acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py);
+                    acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins);
+                    edges = edge_mask(dd >> 29, ins);
                 }
             }
             st.chunk += NW;
@@ -739,7 +753,8 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgs a, Co
         bool acc;
         uint32_t key;
         int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-        const bool more = scan_step(st, a, c, cam, img, lane, wave, X0, TW, acc, key, px, py);
+        unsigned edges;
+        const bool more = scan_step(st, a, c, cam, img, lane, wave, X0, TW, acc, key, px, py, edges);
         drain<TW>(w, acc, key, px, py, more);
         if (!more) break;
     }
@@ -780,7 +795,8 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgs a, 
         bool acc;
         uint32_t key;
         int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-        const bool more = scan_step<1>(st, a, c, cam, img, lane, 0, 0, W, acc, key, px, py);
+        unsigned edges;
+        const bool more = scan_step<1>(st, a, c, cam, img, lane, 0, 0, W, acc, key, px, py, edges);
         if (acc) {
             int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
             bool big = max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT;
@@ -820,7 +836,8 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
             bool acc;
             uint32_t key;
             int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-            const bool more = scan_step(st, a, c, cam, img, lane, wave, X0, TW, acc, key, px, py);
+            unsigned edges;
+        const bool more = scan_step(st, a, c, cam, img, lane, wave, X0, TW, acc, key, px, py, edges);
             drain<TW>(w, acc, key, px, py, more);
             if (!more) break;
         }
@@ -837,10 +854,9 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
 // the final pass resolves, per pixel, the highest key whose bit is set.  Equal keys paint the same bit, so -- exactly as
 // with ds_max on packed keys -- the result does not depend on the order in which faces are processed.
 // =========================================================================================================
-constexpr int BWAVES = 8;
-constexpr int BBLOCK = BWAVES * 64;
 constexpr int MAX_KEYS = 16;
 constexpr int ROWS_PER_ITEM = 8;
+constexpr int SEG = 16;                 // steps of an outline edge handled by one lane
 
 struct KeyTable { uint32_t key[MAX_KEYS]; int n; };      // ascending = painter order (later wins)
 
@@ -865,7 +881,9 @@ __device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int s0, int s1) 
 }
 
 // cv::Line into a bit plane (same walk as draw_line; consecutive pixels that share a word are merged into one ds_or)
-__device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int TWp, int wpr, int ax, int ay, int bx, int by) {
+// Only the steps kb..ke of the walk are painted (a line is cut into segments that are spread over the lanes).
+__device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int TWp, int wpr, int ax, int ay, int bx, int by, int kb = 0,
+                                      int ke = 0x7fffffff) {
     long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
     if ((unsigned long long)x1 >= (unsigned long long)W || (unsigned long long)x2 >= (unsigned long long)W ||
         (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
@@ -881,27 +899,26 @@ __device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int
     const int dmaj = vert ? dy : dx, dmin = vert ? dx : dy;
     int err = dmaj - (dmin + dmin);
     const int plus_delta = dmaj + dmaj, minus_delta = -(dmin + dmin);
-    int k = 0;
-    if (px < X0) {
+    if (kb > dmaj) return;
+    int k = kb;
+    if (px < X0) {                                                   // first step whose x reaches the strip
         const int t = X0 - px;
-        if (!vert) {
-            k = t;
-            int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
-            err += k * minus_delta + m * plus_delta;
-            px += k; py += step_y * m;
-        } else {
-            k = (int)(((unsigned)(2 * dmaj) * (unsigned)t - (unsigned)dmaj + (unsigned)(2 * dmin)) / (unsigned)(2 * dmin));
-            int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
-            err += k * minus_delta + m * plus_delta;
-            py += step_y * k; px += m;
-        }
+        const int ks = !vert ? t : (int)(((unsigned)(2 * dmaj) * (unsigned)t - (unsigned)dmaj + (unsigned)(2 * dmin)) / (unsigned)(2 * dmin));
+        k = max(k, ks);
     }
+    if (k > 0) {                                                     // enter the walk at step k in closed form
+        int m = (int)(((unsigned)(2 * dmin) * (unsigned)k + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj));
+        err += k * minus_delta + m * plus_delta;
+        if (!vert) { px += k; py += step_y * m; }
+        else { py += step_y * k; px += m; }
+    }
+    const int kend = min(ke, dmaj);
     const int lim = X0 + TWp;
     if (vert) {
         // y-major: one pixel per row, every step lands in another word
         uint32_t *rowp = plane + py * wpr;
         const int rstep = step_y * wpr;
-        for (; k <= dmaj && px < lim; ++k) {
+        for (; k <= kend && px < lim; ++k) {
             const int lx = px - X0;
             atomicOr(rowp + (lx >> 5), 1u << (lx & 31));
             const bool neg = err < 0;
@@ -915,7 +932,7 @@ __device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int
         uint32_t mask = 0;
         int rowoff = py * wpr;
         const int rstep = step_y * wpr;
-        for (; k <= dmaj && px < lim; ++k) {
+        for (; k <= kend && px < lim; ++k) {
             const int lx = px - X0;
             const int addr = rowoff + (lx >> 5);
             const uint32_t bit = 1u << (lx & 31);
@@ -1004,7 +1021,7 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
     FaceRows r = {0, 0, 0, 0, 0, 0};
     Chain a = {0, 0, NO_SWITCH, 0, 0}, b = {0, 0, NO_SWITCH, 0, 0};
     if (lane < n) {
-        kidx = w.q[lane]; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
+        kidx = w.q[lane] & 15u; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
         const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
         r = face_rows(px, py, H, W, X0, TWp);
         if (r.nrows > 0 && !(w.debug & 16)) {
@@ -1062,20 +1079,55 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
             wave_sync();
         }
     }
-    // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2); one edge per lane over the 3n edges of the batch
-    for (int t0 = 0; t0 < 3 * n && !(w.debug & 8); t0 += 64) {
-        const int t = t0 + lane;
-        if (t < 3 * n) {
-            const int f = t / 3, l = t - 3 * f;
-            const int ia = l == 0 ? 2 : l - 1, ib = l;
-            const uint32_t k2 = w.q[f], pa = w.q[(1 + ia) * QCAP + f], pb = w.q[(1 + ib) * QCAP + f];
-            draw_line_bits(w.planes + (size_t)k2 * H * wpr, H, W, X0, TWp, wpr, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb));
+    // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2).  Every edge that has to be drawn is cut into segments of
+    // SEG steps (of the unclipped major length; steps that clipping removes are simply empty); the segments are numbered by a
+    // wave prefix sum, listed in LDS by their owners and walked one per lane, each entered in closed form.
+    if (!(w.debug & 8)) {
+        int nseg[3] = {0, 0, 0};
+        if (lane < n) {
+            const unsigned em = (w.q[lane] >> 4) & 7u;
+            const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int ia = l == 0 ? 2 : l - 1, ib = l;
+                const int len = max(abs(px[ia] - px[ib]), abs(py[ia] - py[ib])) + 1;
+                nseg[l] = ((em >> l) & 1u) ? (len + SEG - 1) / SEG : 0;
+            }
+        }
+        const int mine = nseg[0] + nseg[1] + nseg[2];
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const int excl = incl - mine;
+        const int total = __shfl(incl, 63);
+        for (int base = 0; base < total; base += BLOCK_CAP) {
+            int lo = max(excl, base), hi = min(incl, base + BLOCK_CAP);
+            for (int idx = lo; idx < hi; ++idx) {
+                int j = idx - excl, l = 0;
+                if (j >= nseg[0]) { j -= nseg[0]; l = 1; if (j >= nseg[1]) { j -= nseg[1]; l = 2; } }
+                w.blocks[idx - base] = (uint32_t)lane | ((uint32_t)l << 6) | ((uint32_t)j << 8);
+            }
+            wave_sync();
+            const int m = min(BLOCK_CAP, total - base);
+            for (int i = lane; i < m; i += 64) {
+                const uint32_t e = w.blocks[i];
+                const int f = e & 63, l = (e >> 6) & 3, j = (int)(e >> 8);
+                const int ia = l == 0 ? 2 : l - 1, ib = l;
+                const uint32_t q0 = w.q[f], pa = w.q[(1 + ia) * QCAP + f], pb = w.q[(1 + ib) * QCAP + f];
+                draw_line_bits(w.planes + (size_t)(q0 & 15u) * H * wpr, H, W, X0, TWp, wpr, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb),
+                               j * SEG, j * SEG + SEG - 1);
+            }
+            wave_sync();
         }
     }
     wave_sync();
 }
 
-__device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool acc, uint32_t key, const int (&px)[3], const int (&py)[3], bool more) {
+__device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool acc, uint32_t key, unsigned edges, const int (&px)[3],
+                                           const int (&py)[3], bool more) {
     // plane of the key = its position in the ascending table
     int k = 0;
 #pragma unroll
@@ -1093,7 +1145,7 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool a
             bool take = acc && ((pending >> w.lane) & 1) && rank < room;
             if (take) {
                 int slot = w.qlen + rank;
-                w.q[slot] = (uint32_t)k;
+                w.q[slot] = (uint32_t)k | (edges << 4);           // plane index | outline edges to draw
                 w.q[1 * QCAP + slot] = pack_xy(px[0], py[0]);
                 w.q[2 * QCAP + slot] = pack_xy(px[1], py[1]);
                 w.q[3 * QCAP + slot] = pack_xy(px[2], py[2]);
@@ -1111,7 +1163,7 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool a
 }
 
 // resolve the planes (highest key wins) and stream the strip out; one item = 4 consecutive rows x 32 columns
-template <typename OutT>
+template <int BBLOCK, typename OutT>
 __device__ inline void write_out_bits(const uint32_t *planes, const float4 *ftab, int K, OutT *out, int64_t img, int res, int X0, int TWp,
                                       int wpr, int tid) {
     const int H = res, W = res;
@@ -1171,8 +1223,9 @@ __device__ inline void write_out_bits(const uint32_t *planes, const float4 *ftab
 }
 
 // one workgroup (8 waves) per (camera, strip); for the usual resolutions one strip is the whole image
-template <typename OutT>
-__global__ void __launch_bounds__(BBLOCK, 2) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
+template <int BWAVES, typename OutT>
+__global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
+    constexpr int BBLOCK = BWAVES * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
@@ -1206,18 +1259,20 @@ __global__ void __launch_bounds__(BBLOCK, 2) raster_scene_bits_kernel(SceneArgs 
         bool acc;
         uint32_t key;
         int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-        const bool more = scan_step<BWAVES>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py);
-        drain_bits(w, kt, acc, key, px, py, more);
+        unsigned edges;
+        const bool more = scan_step<BWAVES>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
+        drain_bits(w, kt, acc, key, edges, px, py, more);
         if (!more) break;
     }
     __syncthreads();
-    if (!(c.debug & 4)) write_out_bits<OutT>(planes, ftab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
+    if (!(c.debug & 4)) write_out_bits<BBLOCK, OutT>(planes, ftab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
 }
 
-inline size_t bits_lds_bytes(int K, int res, int twp) {
+inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves) {
     size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
-    return plane_dw * 4 + (MAX_KEYS + 1) * sizeof(float4) + (size_t)BWAVES * WAVE_LDS_DW * 4;
+    return plane_dw * 4 + (MAX_KEYS + 1) * sizeof(float4) + (size_t)nwaves * WAVE_LDS_DW * 4;
 }
+int g_bits_waves = 4;
 
 // Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
 template <int TW, typename OutT>
@@ -1235,7 +1290,8 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_mesh_kernel(MeshArgs a, Comm
             int v0 = Fp[3 * f], v1 = Fp[3 * f + 1], v2 = Fp[3 * f + 2];
             float sxv[3] = {V[3 * v0] + (-cam.cx), V[3 * v1] + (-cam.cx), V[3 * v2] + (-cam.cx)};
             float syv[3] = {V[3 * v0 + 1] + (-cam.cy), V[3 * v1 + 1] + (-cam.cy), V[3 * v2 + 1] + (-cam.cy)};
-            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py);
+            unsigned ins;
+            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py, ins);
             if (acc) {
                 float z = V[3 * v0 + 2];                                         // level of the first vertex, cv2.py:44-46
                 int rank = 0;
@@ -1276,8 +1332,15 @@ int g_debug = 0;
 
 // test/benchmark hook: force the strip width (0 = automatic)
 TDS_EXPORT int tds_raster_set_strip_width(int tw) {
-    TDS_CHECK_ARG(tw == 0 || tw == 8 || tw == 16 || tw == 32 || tw == 64, "strip width must be 0, 8, 16, 32 or 64");
+    TDS_CHECK_ARG(tw == 0 || tw == 8 || tw == 16 || tw == 32 || tw == 64 || tw == 96 || tw == 128, "strip width must be 0, 8, 16, 32, 64, 96 or 128");
     g_force_tw = tw;
+    return TDS_OK;
+}
+
+// tuning hook (not part of include/tdship.h): waves per workgroup of the bit-plane kernel (4 or 8)
+TDS_EXPORT int tds_raster_set_bits_waves(int n) {
+    TDS_CHECK_ARG(n == 4 || n == 8, "waves per workgroup must be 4 or 8");
+    g_bits_waves = n;
     return TDS_OK;
 }
 
@@ -1309,7 +1372,7 @@ static int common_checks(const char *fn, int64_t n_img, int res, int out_mode, c
     TDS_CHECK_ARG(res > 0 && res <= 4096, "%s: resolution %d out of range (1..4096)", fn, res);
     TDS_CHECK_ARG(out_mode == TDS_OUT_F32 || out_mode == TDS_OUT_U8, "%s: unknown output mode %d", fn, out_mode);
     TDS_CHECK_ARG(out || n_img == 0, "%s: null output", fn);
-    tw = g_force_tw ? g_force_tw : pick_tw(res);
+    tw = (g_force_tw && g_force_tw <= 64) ? g_force_tw : pick_tw(res);
     if (tw == 0 || lds_bytes(tw, res) > 160 * 1024) { tds::set_error("%s: resolution %d does not fit the LDS tile", fn, res); return TDS_ELIMIT; }
     TDS_CHECK_ARG(n_img * ((res + tw - 1) / tw) < ((int64_t)1 << 31), "%s: too many strips", fn);
     return TDS_OK;
@@ -1325,7 +1388,7 @@ inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
 TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes) {
     TDS_CHECK_ARG(bytes, "tds_raster_scene_workspace_bytes: null output");
     TDS_CHECK_ARG(res > 0 && res <= 4096 && n_img >= 0, "tds_raster_scene_workspace_bytes: bad arguments");
-    int tw = g_force_tw ? g_force_tw : pick_tw(res);
+    int tw = (g_force_tw && g_force_tw <= 64) ? g_force_tw : pick_tw(res);
     *bytes = 0;
     if (tw == 0 || (res + tw - 1) / tw > MAX_STRIPS) return TDS_OK;
     *bytes = ws_bytes_for(n_img, (res + tw - 1) / tw, DEFAULT_CAPS);
@@ -1373,16 +1436,19 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
             // strip width: the whole (32-padded) image if the planes fit 64 KiB, else the widest multiple of 32 that does
             int twp = (res + 31) & ~31;
             while (twp > 32 && (size_t)kt.n * res * (twp / 8) > 64 * 1024) twp -= 32;
-            size_t lds = bits_lds_bytes(kt.n, res, twp);
+            if (g_force_tw >= 32 && g_force_tw < twp) twp = g_force_tw;     // tuning hook
+            const int nwv = g_bits_waves;
+            size_t lds = bits_lds_bytes(kt.n, res, twp, nwv);
             if (lds <= 150 * 1024) {
                 CommonArgs cb = cm;
                 cb.strips = (res + twp - 1) / twp;
                 dim3 grid((unsigned)(n_img * cb.strips));
                 auto launch = [&](auto kern) {
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(BBLOCK), lds, (hipStream_t)stream, a, cb, kt, twp);
+                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp);
                 };
-                if (out_mode == TDS_OUT_F32) launch(raster_scene_bits_kernel<float>); else launch(raster_scene_bits_kernel<uint8_t>);
+                if (out_mode == TDS_OUT_F32) { if (nwv == 4) launch(raster_scene_bits_kernel<4, float>); else launch(raster_scene_bits_kernel<8, float>); }
+                else { if (nwv == 4) launch(raster_scene_bits_kernel<4, uint8_t>); else launch(raster_scene_bits_kernel<8, uint8_t>); }
                 TDS_LAUNCH_CHECK("raster_scene_bits_kernel");
                 return TDS_OK;
             }
