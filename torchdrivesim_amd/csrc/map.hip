@@ -230,21 +230,29 @@ __device__ __forceinline__ float tri_d2(float px, float py, const GridEntry &e) 
     return inside ? 0.0f : dist;
 }
 
+// min over all faces of tri_d2, found by walking grid rings outwards from the point's cell.  A face is listed in every
+// cell its bounding box touches, so its closest point lies in a listed cell whose box is at least as close as the face:
+// cells whose box is not closer than the best distance so far can be skipped, and the walk stops once a whole ring is.
 __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, float py) {
     float best = __builtin_inff();
     if (m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return best;
     // unclamped cell of the point (float -> int conversion saturates, keep it in a sane range first)
     float fx = fminf(fmaxf((px - m.ox) * m.inv_cell, -1.0e6f), 1.0e6f), fy = fminf(fmaxf((py - m.oy) * m.inv_cell, -1.0e6f), 1.0e6f);
     int cx = (int)floorf(fx), cy = (int)floorf(fy);
-    int k = max(max(0, max(-cx, cx - (m.nx - 1))), max(-cy, cy - (m.ny - 1)));
     auto visit = [&](int x, int y) {
+        // squared distance from the point to the cell's box, shrunk a little so that rounding can only make us visit more
+        float bx0 = m.ox + (float)x * m.cell, by0 = m.oy + (float)y * m.cell;
+        float ddx = fmaxf(fmaxf(bx0 - px, px - (bx0 + m.cell)), 0.0f), ddy = fmaxf(fmaxf(by0 - py, py - (by0 + m.cell)), 0.0f);
+        float cd = (ddx * ddx + ddy * ddy) * 0.998f - 1e-3f;
+        if (cd >= best) return;
         int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
-        for (int i = s; i < e; ++i) {
+        for (int i = s; i < e && best > 0.0f; ++i) {
             GridEntry ge = m.entries[i];
             float d = tri_d2(px, py, ge);
             best = (d < best) ? d : best;
         }
     };
+    int k = max(max(0, max(-cx, cx - (m.nx - 1))), max(-cy, cy - (m.ny - 1)));
     for (;; ++k) {
         // cells at Chebyshev distance exactly k from (cx, cy), clipped to the grid
         int y0 = max(cy - k, 0), y1 = min(cy + k, m.ny - 1);

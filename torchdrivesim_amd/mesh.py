@@ -432,13 +432,33 @@ class BirdviewRGBMeshGenerator:
     def initialize_background_mesh(self, background_mesh, world_center: Optional[Tensor] = None):
         if world_center is None:
             if getattr(background_mesh, 'categories', None) and 'road' in background_mesh.categories:
-                world_center = background_mesh.separate_by_category()['road'].center
+                world_center = self._category_center(background_mesh, 'road')
             else:
                 world_center = background_mesh.center
         self.world_center = world_center.to(background_mesh.device)
         if isinstance(background_mesh, BirdviewMesh):
             background_mesh = set_colors_with_defaults(background_mesh.clone(), color_map=self.color_map, rendering_levels=self.rendering_levels)
         self.background_mesh = background_mesh
+
+    @staticmethod
+    def _category_center(mesh: BirdviewMesh, category: str) -> Tensor:
+        """Centre of the bounding box of the vertices used by the faces of one category -- what
+        `mesh.separate_by_category()[category].center` gives (mesh.py:860-866), without the per-scene Python loop."""
+        idx = mesh.categories.index(category)
+        faces = mesh.faces.long()
+        if faces.shape[1] == 0:
+            return torch.zeros((mesh.batch_size, 2), dtype=mesh.verts.dtype, device=mesh.device)
+        is_cat = mesh.vert_category == idx                                         # B x V
+        keep_face = torch.gather(is_cat.unsqueeze(1).expand(-1, faces.shape[1], -1), 2, faces).any(-1)      # B x F
+        used = torch.zeros_like(is_cat, dtype=torch.int32).scatter_add_(1, faces.flatten(1), keep_face.unsqueeze(-1).expand(-1, -1, 3).flatten(1).int()) > 0
+        big = torch.finfo(mesh.verts.dtype).max
+        v = mesh.verts[..., :2]
+        lo = torch.where(used.unsqueeze(-1), v, torch.full_like(v, big)).min(dim=1).values
+        hi = torch.where(used.unsqueeze(-1), v, torch.full_like(v, -big)).max(dim=1).values
+        # unused batch elements (no such face): padded vertex 0 semantics of the reference -> centre of vertex 0
+        none = ~used.any(dim=1)
+        center = (hi + lo) / 2
+        return torch.where(none.unsqueeze(-1), v[:, 0] if v.shape[1] else torch.zeros_like(center), center)
 
     def add_static_meshes(self, meshes: List[BirdviewMesh]) -> None:
         self.add_static_rgb_meshes([set_colors_with_defaults(m.clone(), color_map=self.color_map, rendering_levels=self.rendering_levels) for m in meshes])
