@@ -248,6 +248,11 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
         int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
         for (int i = s; i < e && best > 0.0f; ++i) {
             GridEntry ge = m.entries[i];
+            // the face cannot beat `best` if even its bounding box is farther (same safety shrink as for the cell)
+            float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
+            float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
+            float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
+            if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) continue;
             float d = tri_d2(px, py, ge);
             best = (d < best) ? d : best;
         }
