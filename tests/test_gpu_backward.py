@@ -1,0 +1,88 @@
+"""Gradients of the HIP backward kernels (BASELINE config 5) against the reference's torch-autograd gradients captured in
+fixture G7 (tools/gen_golden.py: loss = sum(compute_collision) + sum(compute_offroad) after one KinematicBicycle step)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def make_sim(g, metric, state, action=None):
+    from torchdrivesim_amd.kinematic import KinematicBicycle
+    from torchdrivesim_amd.mesh import BaseMesh
+    from torchdrivesim_amd.rendering import HipRendererConfig
+    from torchdrivesim_amd.simulator import Simulator, TorchDriveConfig, CollisionMetric
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    B = state.shape[0]
+    road = BaseMesh(verts=d(g['road_verts'])[None].expand(B, -1, -1).contiguous(), faces=d(g['road_faces'].astype(np.int64))[None].expand(B, -1, -1).contiguous())
+    km = KinematicBicycle()
+    km.set_params(lr=d(g['lr']))
+    km.set_state(state)
+    cfg = TorchDriveConfig(collision_metric=CollisionMetric(metric), renderer=HipRendererConfig())
+    return Simulator(road, km, d(g['size']), d(g['present']), cfg)
+
+
+@pytest.mark.parametrize('metric', ['iou', 'discs'])
+def test_collision_and_offroad_gradients_wrt_state(metric):
+    g = load_golden('g7_grads.npz')
+    s1 = torch.from_numpy(g[f'{metric}_state1']).to(DEV).requires_grad_(True)
+    sim = make_sim(g, metric, s1)
+    coll = sim.compute_collision()
+    np.testing.assert_allclose(coll.detach().cpu().numpy(), g[f'{metric}_coll'], atol=2e-6)
+    gc, = torch.autograd.grad(coll.sum(), s1)
+    ref = g[f'{metric}_grad_coll_wrt_state1']
+    np.testing.assert_allclose(gc.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref).max()))
+    assert np.abs(ref).max() > 0
+    off = sim.compute_offroad()
+    np.testing.assert_allclose(off.detach().cpu().numpy(), g[f'{metric}_off'], rtol=1e-5, atol=1e-5)
+    go, = torch.autograd.grad(off.sum(), s1)
+    ref = g[f'{metric}_grad_off_wrt_state1']
+    np.testing.assert_allclose(go.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref).max()))
+    assert np.abs(ref).max() > 0
+
+
+@pytest.mark.parametrize('metric', ['iou', 'discs'])
+def test_full_step_gradients_match_reference(metric):
+    """state0, action -> step (K1) -> collision (K2a) + offroad (K2b) -> backward through all three kernels."""
+    g = load_golden('g7_grads.npz')
+    s0 = torch.from_numpy(g['state0']).to(DEV).requires_grad_(True)
+    act = torch.from_numpy(g['action']).to(DEV).requires_grad_(True)
+    sim = make_sim(g, metric, s0)
+    sim.step(act)
+    np.testing.assert_allclose(sim.get_state().detach().cpu().numpy(), g[f'{metric}_state1'], rtol=1e-5, atol=1e-5)
+    loss = sim.compute_collision().sum() + sim.compute_offroad().sum()
+    loss.backward()
+    for got, key in ((s0.grad, f'{metric}_grad_state'), (act.grad, f'{metric}_grad_action')):
+        ref = g[key]
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=3e-3, atol=3e-4 * max(1.0, np.abs(ref).max()))
+
+
+def test_collision_gradient_finite_differences():
+    """independent check of the analytic IoU / discs gradients: central differences of the forward kernel in float64-ish steps"""
+    from torchdrivesim_amd import _ops
+    gen = torch.Generator().manual_seed(3)
+    B, N = 2, 5
+    xy = (torch.rand(B, N, 2, generator=gen) - 0.5) * 5
+    boxes = torch.cat([xy, 4 + torch.rand(B, N, 1, generator=gen), 1.8 + 0.4 * torch.rand(B, N, 1, generator=gen),
+                       (torch.rand(B, N, 1, generator=gen) - 0.5) * 6], -1).to(DEV)
+    present = torch.ones(B, N, dtype=torch.bool, device=DEV)
+    wgt = torch.rand(B, N, generator=gen).to(DEV)
+    for metric in ('iou', 'discs'):
+        b = boxes.clone().requires_grad_(True)
+        (_ops.collision(b, present, metric=metric) * wgt).sum().backward()
+        an = b.grad.cpu().numpy()
+        num = np.zeros_like(an)
+        eps = 2e-3
+        for bi in range(B):
+            for ni in range(N):
+                for k in range(5):
+                    bp, bm = boxes.clone(), boxes.clone()
+                    bp[bi, ni, k] += eps
+                    bm[bi, ni, k] -= eps
+                    fp = (_ops.collision(bp, present, metric=metric) * wgt).sum().item()
+                    fm = (_ops.collision(bm, present, metric=metric) * wgt).sum().item()
+                    num[bi, ni, k] = (fp - fm) / (2 * eps)
+        np.testing.assert_allclose(an, num, rtol=0.05, atol=0.02 * max(1.0, np.abs(num).max()))
