@@ -139,10 +139,10 @@ def main():
         sink['col'] = sim.compute_collision()
         sink['off'] = sim.compute_offroad()
 
+    from torchdrivesim_amd import parallel
+
     def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+        parallel.barrier(device)            # dist.barrier() when there is a process group, then torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -152,11 +152,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)        # slowest rank
     raster_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else float('nan')
     _ops.raster_events = None
 
