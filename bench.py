@@ -173,7 +173,7 @@ def main():
                                  f'fp32 fov {FOV:g} m + compute_collision(iou) + compute_offroad', global_batch=world * B, agents=A, res=RES,
                         parallelism=f'scene-batch sharding x{world}, no collectives'),
             roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                          kernel='raster_scene_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE))
+                          kernel='raster_scene_bits_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(host, min(args.cpu_scenes, B), A)
         print(json.dumps(line))
