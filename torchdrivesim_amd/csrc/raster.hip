@@ -854,11 +854,11 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
 // the final pass resolves, per pixel, the highest key whose bit is set.  Equal keys paint the same bit, so -- exactly as
 // with ds_max on packed keys -- the result does not depend on the order in which faces are processed.
 // =========================================================================================================
-constexpr int MAX_KEYS = 16;
+constexpr int MAX_KEYS = 15;              // key indices 1..15 fit 4 bits (0 = background)
 constexpr int ROWS_PER_ITEM = 8;
 constexpr int SEG = 16;                 // steps of an outline edge handled by one lane
 
-struct KeyTable { uint32_t key[MAX_KEYS]; int n; };      // ascending = painter order (later wins)
+struct KeyTable { uint32_t key[16]; int n; };      // ascending = painter order (later wins)
 
 struct BitCtx {
     uint32_t *planes;   // [K][H][wpr]
@@ -1162,10 +1162,22 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool a
     }
 }
 
-// resolve the planes (highest key wins) and stream the strip out; one item = 4 consecutive rows x 32 columns
-template <int BBLOCK, typename OutT>
-__device__ inline void write_out_bits(const uint32_t *planes, const float4 *ftab, int K, OutT *out, int64_t img, int res, int X0, int TWp,
-                                      int wpr, int tid) {
+// Resolve the planes (highest key wins) and stream the strip out; one item = 4 consecutive rows x 32 columns.
+// The K planes of a row are first reduced to NB bit-slices of the winning key's index (0 = background).  Pixels leave in PAIRS of
+// vertically adjacent rows: the 2*NB index bits of a pair address a table of ready-made output values (two floats per channel), so
+// that a pixel costs no arithmetic after its index has been extracted.  Extraction: slice i rotated left by i, masked to every 8th
+// column and OR-ed together puts the complete pair index of 4 columns (phase, phase+8, ...) into one word.
+template <int NB, typename OutT> struct PairTab;
+template <int NB> struct PairTab<NB, float> { using E = float2; };
+template <int NB> struct PairTab<NB, uint8_t> { using E = uint32_t; };        // low 16 bits: the two bytes of a pair
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return __builtin_rotateleft32(v, (unsigned)n & 31u); }
+
+template <int BBLOCK, int NB, typename OutT>
+__device__ inline void write_out_bits(const uint32_t *planes, const typename PairTab<NB, OutT>::E *tab, int K, OutT *out, int64_t img, int res,
+                                      int X0, int TWp, int wpr, int tid) {
+    using E = typename PairTab<NB, OutT>::E;
+    constexpr int P = 1 << (2 * NB);
     const int H = res, W = res;
     const int64_t plane_px = (int64_t)W * H;
     OutT *o = out + img * 3 * plane_px;
@@ -1175,37 +1187,53 @@ __device__ inline void write_out_bits(const uint32_t *planes, const float4 *ftab
         for (int item = tid; item < quads * wpr; item += BBLOCK) {
             const int rq = item % quads, xw = item / quads, y0 = rq * 4;
             if (xw * 32 >= cols) continue;
-            uint32_t s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0}, cov[4] = {0, 0, 0, 0};
+            uint32_t s[NB][4], cov[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[b][j] = 0;
             for (int k = K - 1; k >= 0; --k) {                       // wave-uniform
                 const int idx = k + 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t wd = planes[((size_t)k * H + y0 + j) * wpr + xw];
-                    uint32_t s = wd & ~cov[j];
+                    uint32_t sn = wd & ~cov[j];
                     cov[j] |= wd;
-                    s0[j] |= (idx & 1) ? s : 0u; s1[j] |= (idx & 2) ? s : 0u; s2[j] |= (idx & 4) ? s : 0u; s3[j] |= (idx & 8) ? s : 0u;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) s[b][j] |= ((idx >> b) & 1) ? sn : 0u;
                 }
             }
-            const int nb = min(32, cols - xw * 32);
-            for (int bpos = 0; bpos < nb; ++bpos) {
-                float4 c[4];
+            uint32_t R0[2 * NB], R1[2 * NB];                         // pair (rows 0,1) and pair (rows 2,3)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int idx = ((s0[j] >> bpos) & 1) | (((s1[j] >> bpos) & 1) << 1) | (((s2[j] >> bpos) & 1) << 2) | (((s3[j] >> bpos) & 1) << 3);
-                    c[j] = ftab[idx];
+            for (int i = 0; i < 2 * NB; ++i) {
+                R0[i] = rotl32(i < NB ? s[i % NB][0] : s[i % NB][1], i);
+                R1[i] = rotl32(i < NB ? s[i % NB][2] : s[i % NB][3], i);
+            }
+            const int ncol = min(32, cols - xw * 32);
+            OutT *ob = o + (int64_t)(X0 + xw * 32) * H + y0;
+#pragma unroll
+            for (int ph = 0; ph < 8; ++ph) {
+                uint32_t A0 = 0, A1 = 0;
+#pragma unroll
+                for (int i = 0; i < 2 * NB; ++i) {
+                    const uint32_t Mx = 0x01010101u << ((ph + i) & 7);      // every 8th column, bit i of its pair index
+                    A0 |= R0[i] & Mx;
+                    A1 |= R1[i] & Mx;
                 }
-                const int64_t off = (int64_t)(X0 + xw * 32 + bpos) * H + y0;
-                if constexpr (sizeof(OutT) == 4) {
-                    *(float4 *)(o + off) = make_float4(c[0].x, c[1].x, c[2].x, c[3].x);
-                    *(float4 *)(o + plane_px + off) = make_float4(c[0].y, c[1].y, c[2].y, c[3].y);
-                    *(float4 *)(o + 2 * plane_px + off) = make_float4(c[0].z, c[1].z, c[2].z, c[3].z);
-                } else {
-                    auto pk = [](float a0, float a1, float a2, float a3) {
-                        return (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
-                    };
-                    *(uint32_t *)(o + off) = pk(c[0].x, c[1].x, c[2].x, c[3].x);
-                    *(uint32_t *)(o + plane_px + off) = pk(c[0].y, c[1].y, c[2].y, c[3].y);
-                    *(uint32_t *)(o + 2 * plane_px + off) = pk(c[0].z, c[1].z, c[2].z, c[3].z);
+                A0 = rotl32(A0, 32 - ph);
+                A1 = rotl32(A1, 32 - ph);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int p = ph + 8 * m;
+                    if (p >= ncol) continue;
+                    const uint32_t i01 = (A0 >> (8 * m)) & (uint32_t)(P - 1), i23 = (A1 >> (8 * m)) & (uint32_t)(P - 1);
+                    OutT *op = ob + (int64_t)p * H;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const E lo = tab[ch * P + i01], hi = tab[ch * P + i23];
+                        if constexpr (sizeof(OutT) == 4) *(float4 *)(op + ch * plane_px) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                        else *(uint32_t *)(op + ch * plane_px) = lo | (hi << 16);
+                    }
                 }
             }
         }
@@ -1216,16 +1244,24 @@ __device__ inline void write_out_bits(const uint32_t *planes, const float4 *ftab
         int idx = 0;
         for (int k = K - 1; k >= 0 && idx == 0; --k)
             if ((planes[((size_t)k * H + y) * wpr + (lx >> 5)] >> (lx & 31)) & 1) idx = k + 1;
-        const float4 cc = ftab[idx];
         const int64_t off = (int64_t)(X0 + lx) * H + y;
-        o[off] = (OutT)cc.x; o[plane_px + off] = (OutT)cc.y; o[2 * plane_px + off] = (OutT)cc.z;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const E e = tab[ch * P + idx];
+            if constexpr (sizeof(OutT) == 4) o[ch * plane_px + off] = e.x;
+            else o[ch * plane_px + off] = (OutT)(e & 255u);
+        }
     }
 }
 
-// one workgroup (8 waves) per (camera, strip); for the usual resolutions one strip is the whole image
-template <int BWAVES, typename OutT>
+template <int NB, typename OutT>
+constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename PairTab<NB, OutT>::E) / 4; }
+
+// one workgroup per (camera, strip); for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
+template <int BWAVES, int NB, typename OutT>
 __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
-    constexpr int BBLOCK = BWAVES * 64;
+    using E = typename PairTab<NB, OutT>::E;
+    constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
@@ -1235,15 +1271,24 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
     const int X0 = strip * TWp;
     const int plane_dw = K * H * wpr;
     uint32_t *planes = smem;
-    float4 *ftab = (float4 *)(smem + ((plane_dw + 3) & ~3));          // [K + 1] colours as floats, entry 0 = background
+    E *tab = (E *)(smem + ((plane_dw + 3) & ~3));                     // [3][P] output values of an index pair
     for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
-    if (tid <= K) {
-        uint32_t key = tid == 0 ? 0u : kt.key[tid - 1];
-        ftab[tid] = make_float4((float)((key >> 16) & 255), (float)((key >> 8) & 255), (float)(key & 255), 0.0f);
+    for (int e = tid; e < 3 * P; e += BBLOCK) {
+        const int ch = e / P, pr = e - ch * P, ilo = pr & ((1 << NB) - 1), ihi = pr >> NB;
+        uint32_t klo = 0, khi = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_KEYS; ++i) {                         // kt lives in SGPRs: no dynamic indexing
+            klo = (i < K && ilo == i + 1) ? kt.key[i] : klo;
+            khi = (i < K && ihi == i + 1) ? kt.key[i] : khi;
+        }
+        const int sh = 16 - 8 * ch;
+        const uint32_t vlo = (klo >> sh) & 255u, vhi = (khi >> sh) & 255u;
+        if constexpr (sizeof(OutT) == 4) tab[e] = make_float2((float)vlo, (float)vhi);
+        else tab[e] = vlo | (vhi << 8);
     }
     BitCtx w;
     w.planes = planes;
-    w.q = (uint32_t *)(ftab + MAX_KEYS + 1) + wave * WAVE_LDS_DW;
+    w.q = (uint32_t *)tab + pair_tab_dw<NB, OutT>() + wave * WAVE_LDS_DW;
     w.blocks = w.q + Q_DW;
     w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug;
     Camera cam;
@@ -1265,12 +1310,15 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
         if (!more) break;
     }
     __syncthreads();
-    if (!(c.debug & 4)) write_out_bits<BBLOCK, OutT>(planes, ftab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
+    if (!(c.debug & 4)) write_out_bits<BBLOCK, NB, OutT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
 }
 
-inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves) {
+inline int bits_index_bits(int K) { return K <= 3 ? 2 : (K <= 7 ? 3 : 4); }
+inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) {
     size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
-    return plane_dw * 4 + (MAX_KEYS + 1) * sizeof(float4) + (size_t)nwaves * WAVE_LDS_DW * 4;
+    size_t P = (size_t)1 << (2 * bits_index_bits(K));
+    size_t tab_dw = 3 * P * (out_mode == TDS_OUT_F32 ? 2 : 1);
+    return (plane_dw + tab_dw + (size_t)nwaves * WAVE_LDS_DW) * 4;
 }
 int g_bits_waves = 4;
 
@@ -1429,7 +1477,7 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
         };
         for (int i = 0; i < map->n_uniq; ++i) add(map->uniq_keys[i]);
         for (int i = 0; i < (N > 0 ? n_actor_keys : 0); ++i) add(actor_keys[i]);
-        for (int i = kt.n; i < MAX_KEYS; ++i) kt.key[i] = 0xffffffffu;
+        for (int i = kt.n; i < 16; ++i) kt.key[i] = 0xffffffffu;
         if (ok && kt.n > 0) {
             for (int i = 1; i < kt.n; ++i)                                   // ascending (insertion sort)
                 for (int j = i; j > 0 && kt.key[j - 1] > kt.key[j]; --j) { uint32_t t = kt.key[j]; kt.key[j] = kt.key[j - 1]; kt.key[j - 1] = t; }
@@ -1438,7 +1486,7 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
             while (twp > 32 && (size_t)kt.n * res * (twp / 8) > 64 * 1024) twp -= 32;
             if (g_force_tw >= 32 && g_force_tw < twp) twp = g_force_tw;     // tuning hook
             const int nwv = g_bits_waves;
-            size_t lds = bits_lds_bytes(kt.n, res, twp, nwv);
+            size_t lds = bits_lds_bytes(kt.n, res, twp, nwv, out_mode);
             if (lds <= 150 * 1024) {
                 CommonArgs cb = cm;
                 cb.strips = (res + twp - 1) / twp;
@@ -1447,8 +1495,14 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp);
                 };
-                if (out_mode == TDS_OUT_F32) { if (nwv == 4) launch(raster_scene_bits_kernel<4, float>); else launch(raster_scene_bits_kernel<8, float>); }
-                else { if (nwv == 4) launch(raster_scene_bits_kernel<4, uint8_t>); else launch(raster_scene_bits_kernel<8, uint8_t>); }
+                const int nb = bits_index_bits(kt.n);
+#define TDS_BITS_DISPATCH(T)                                                                                                   \
+    do {                                                                                                                       \
+        if (nwv == 4) { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, T>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, T>); else launch(raster_scene_bits_kernel<4, 4, T>); } \
+        else { if (nb == 2) launch(raster_scene_bits_kernel<8, 2, T>); else if (nb == 3) launch(raster_scene_bits_kernel<8, 3, T>); else launch(raster_scene_bits_kernel<8, 4, T>); } \
+    } while (0)
+                if (out_mode == TDS_OUT_F32) TDS_BITS_DISPATCH(float); else TDS_BITS_DISPATCH(uint8_t);
+#undef TDS_BITS_DISPATCH
                 TDS_LAUNCH_CHECK("raster_scene_bits_kernel");
                 return TDS_OK;
             }
