@@ -79,3 +79,54 @@ def test_live_opencv_cross_check(oracle):
         ref = np.zeros((64, 64, 3), np.float32)
         ref = cv2.fillConvexPoly(img=ref, points=pts, color=[7, 8, 9], shift=0, lineType=cv2.LINE_AA)
         np.testing.assert_array_equal(fill(oracle, pts, res=64, color=(7, 8, 9)), ref)
+
+
+def _walk(dx, dy):
+    """cv::LineIterator (8-connected, after the left-to-right swap: dx >= 0) from (0, 0): the visited pixels"""
+    ady, sy = abs(dy), (1 if dy >= 0 else -1)
+    vert = ady > dx
+    dmaj, dmin = (ady, dx) if vert else (dx, ady)
+    err, plus, minus = dmaj - 2 * dmin, 2 * dmaj, -2 * dmin
+    x = y = 0
+    out = []
+    for _ in range(dmaj + 1):
+        out.append((x, y))
+        neg = err < 0
+        err += minus + (plus if neg else 0)
+        if vert:
+            y += sy
+            x += 1 if neg else 0
+        else:
+            x += 1
+            y += sy if neg else 0
+    return out
+
+
+def test_line_rows_closed_form():
+    """The per-row closed form of the Bresenham walk used by the K3 bit-plane kernel (raster.hip: process_batch_bits):
+    seen from the top end point, row tau of an edge is one run of pixels given by floor divisions."""
+    for dx in range(0, 34):
+        for dy in range(-34, 35):
+            pix = _walk(dx, dy)
+            ady, up = abs(dy), dy < 0
+            ytop = -ady if up else 0
+            x0 = dx if up else 0
+            rows = {}
+            for (x, y) in pix:
+                rows.setdefault(y - ytop, []).append(x)
+            assert sorted(rows) == list(range(ady + 1))
+            vert = ady > dx
+            if not vert and ady > 0:
+                qa, qb = divmod(2 * dx, 2 * ady)
+            for tau in range(ady + 1):
+                if vert:
+                    lo = hi = (2 * dx * tau + ady - (0 if up else 1)) // (2 * ady)
+                elif ady == 0:
+                    lo, hi = 0, dx
+                else:
+                    nn = 2 * dx * (tau + 1) + 2 * ady - dx - (1 if up else 0)
+                    q2, r2 = divmod(nn, 2 * ady)
+                    lo = 0 if tau == 0 else q2 - qa - (1 if r2 < qb else 0)
+                    hi = min(q2 - 1, dx)
+                xs, xe = (x0 - hi, x0 - lo) if up else (x0 + lo, x0 + hi)
+                assert sorted(rows[tau]) == list(range(xs, xe + 1)), (dx, dy, tau)

@@ -856,15 +856,15 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
 // =========================================================================================================
 constexpr int MAX_KEYS = 15;              // key indices 1..15 fit 4 bits (0 = background)
 constexpr int ROWS_PER_ITEM = 8;
-constexpr int SEG = 16;                 // steps of an outline edge handled by one lane
+constexpr int BITS_WAVE_LDS_DW = Q_DW + 64;   // per wave: face queue + owner markers
 
 struct KeyTable { uint32_t key[16]; int n; };      // ascending = painter order (later wins)
 
 struct BitCtx {
     uint32_t *planes;   // [K][H][wpr]
     uint32_t *q;        // [4][QCAP]: plane index, then the three packed vertices
-    uint32_t *blocks;   // [BLOCK_CAP]
-    int qlen, lane, H, W, X0, TWp, wpr, debug;
+    uint32_t *slots;    // [64] owner markers of wave_owner()
+    int qlen, lane, H, W, X0, TWp, wpr, debug, gen;
 };
 
 // bits [s0, s1] (strip-local columns) of one row of one plane
@@ -1007,120 +1007,253 @@ __device__ __noinline__ void fill_generic_bits(uint32_t *plane, int H, int W, in
     } while (++y <= (int)ymax);
 }
 
-// Rasterise the first n (<= 64) faces of the wave's queue into the bit planes.
-//   1. lane f sets up face f (rows to paint, the two edge chains);
-//   2. faces are cut into items of ROWS_PER_ITEM rows, numbered by a wave prefix sum; the wave processes one item per lane:
-//      the edge data comes from the owner lane by ds_bpermute, each row costs one span evaluation and one or two ds_or --
-//      no per-pixel loop, so slivers and big road triangles cost the same per row;
-//   3. the three outline edges, one face per lane.
+// ---- wave-level helpers of the bit-plane path ----------------------------------------------------------------------
+// Inclusive scans over the 64 lanes on DPP (row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31); all lanes active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_from(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp_from<0x111, 0xf>(v); v += dpp_from<0x112, 0xf>(v); v += dpp_from<0x114, 0xf>(v); v += dpp_from<0x118, 0xf>(v);
+    v += dpp_from<0x142, 0xa>(v); v += dpp_from<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {           // values >= 0
+    v = max(v, dpp_from<0x111, 0xf>(v)); v = max(v, dpp_from<0x112, 0xf>(v)); v = max(v, dpp_from<0x114, 0xf>(v));
+    v = max(v, dpp_from<0x118, 0xf>(v)); v = max(v, dpp_from<0x142, 0xa>(v)); v = max(v, dpp_from<0x143, 0xc>(v));
+    return v;
+}
+
+// Work items are numbered by a prefix sum over their owners (lane j owns the items [excl_j, incl_j)).  For the window of 64
+// items starting at `base`, returns in lane i the owner of item base + i: every owner whose first item falls into the window
+// drops a marker (generation tag | lane) at that position of a 64-entry LDS array, the owner of the window's first item is
+// found with a ballot, and a max-scan spreads the markers (stale markers carry an older tag and lose).
+__device__ __forceinline__ int wave_owner(uint32_t *slots, int &gen, int lane, bool has, int excl, int incl, int base) {
+    ++gen;
+    const int tag = gen << 6;
+    const int rel = excl - base;
+    if (has && (unsigned)rel < 64u) slots[rel] = (uint32_t)(tag | lane);
+    const unsigned long long cm = __ballot(has && excl <= base && base < incl);
+    const int carry = cm ? (int)__ffsll((long long)cm) - 1 : 0;
+    wave_sync();
+    int m = (int)slots[lane];
+    if (lane == 0) m = max(m, tag | carry);
+    m = wave_scan_max(m);
+    return m & 63;
+}
+
+// n / d for n < 2^30, d >= 1 and a quotient below 2^16: the fp32 estimate is within 0.01 of the exact quotient, one correction
+// step in integers makes it exact
+__device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned d) {
+    unsigned q = (unsigned)((float)n * __builtin_amdgcn_rcpf((float)d));
+    int r = (int)(n - __umul24(q, d));
+    if (r < 0) --q;
+    else if (r >= (int)d) ++q;
+    return q;
+}
+
+// trunc((double)u * (double)v / (double)d) of cv::clipLine for |u v| < 2^30, 0 < |u| <= |d| < 2^16 (exact: see div_trunc)
+__device__ __forceinline__ int clip_quot(int u, int v, int d) {
+    const int n = __mul24(u, v);
+    const unsigned q = udiv_small((unsigned)abs(n), (unsigned)abs(d));
+    return ((n < 0) != (d < 0)) ? -(int)q : (int)q;
+}
+
+// cv::clipLine for end points within the packed coordinate range (|coordinate| < COORD_LIMIT); same steps as clip_line above
+__device__ inline bool clip_line_small(int W, int H, int &x1, int &y1, int &x2, int &y2) {
+    const int right = W - 1, bottom = H - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        int a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += clip_quot(a - y1, x2 - x1, y2 - y1);
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += clip_quot(a - y2, x2 - x1, y2 - y1);
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += clip_quot(a - x1, y2 - y1, x2 - x1);
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += clip_quot(a - x2, y2 - y1, x2 - x1);
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+__device__ __forceinline__ int chain_x32(int xs1, int dx1, int ysw, int xs2, int dx2, int ymin, int y) {
+    const bool second = y >= ysw;
+    return ((second ? xs2 : xs1) << 16) + (y - (second ? ysw : ymin)) * (second ? dx2 : dx1);
+}
+
+// Rasterise the first n (<= 64) faces of the wave's queue into the bit planes.  Work is cut into items of CHUNK consecutive rows,
+// numbered by wave prefix sums and mapped back to their owners by wave_owner(); a lane enters its item in closed form and then
+// advances incrementally, one span (one or two ds_or) per row:
+//   1. lane f sets up face f (rows of OpenCV's scan conversion, the two edge chains: one 32-bit division per edge);
+//   2. items of CHUNK scan-converted rows: the two chain positions in 16.16 (32-bit);
+//   3. the outline edges that have to be drawn (OpenCV: Line(v2,v0), Line(v0,v1), Line(v1,v2); edges shared with an earlier
+//      same-key face are skipped) are set up one per lane: clipLine, left-to-right order, then rewritten top-down so that the
+//      pixels of row tau of the walk are a closed form of tau (below);
+//   4. items of CHUNK rows of an edge: the pixels of cv::Line in one row are one run, painted like a span.
+// Bresenham in closed form.  After the left-to-right swap the walk starts at (px, py), dx >= 0, and after k steps the minor axis has
+// advanced m_k = floor((2 dmin k + dmaj - 1) / (2 dmaj)) (see draw_line).  Seen from the TOP end point (x0, ytop), rows tau = 0..|dy|,
+// x moving by sgn = +1 (walk goes down) or -1 (walk goes up):
+//   y-major: the pixel of row tau is x0 + sgn floor((2 dx tau + c) / (2 |dy|)),  c = |dy| - 1 (sgn > 0) or |dy| (sgn < 0);
+//   x-major: row tau holds the offsets G_tau .. min(G_{tau+1} - 1, dx),  G_0 = 0,  G_tau = floor((2 dx tau + c2) / (2 |dy|)),
+//            c2 = 2 |dy| - dx - (sgn < 0).
+// Both are floor((N0 + tau * 2 dx) / D): stepping tau adds divmod(2 dx, D) = (ia, ib) to (quotient, remainder) with one carry.
+// (checked exhaustively against the iterative walk in tests/test_oracle_fill.py::test_line_rows_closed_form)
+constexpr int CHUNK = 4;
+
 __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
     const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0, TWp = w.TWp, wpr = w.wpr;
     wave_sync();
-    uint32_t kidx = 0, v0 = 0, v1 = 0, v2 = 0;
-    int nitems = 0;
+    uint32_t kidx = 0, em = 0, v0 = 0, v1 = 0, v2 = 0;
     FaceRows r = {0, 0, 0, 0, 0, 0};
     Chain a = {0, 0, NO_SWITCH, 0, 0}, b = {0, 0, NO_SWITCH, 0, 0};
     if (lane < n) {
-        kidx = w.q[lane] & 15u; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
+        const uint32_t q0 = w.q[lane];
+        kidx = q0 & 15u; em = (q0 >> 4) & 7u; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
         const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
         r = face_rows(px, py, H, W, X0, TWp);
-        if (r.nrows > 0 && !(w.debug & 16)) {
+        if (r.nrows > 0) {
             int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
             a = make_chain(px, py, r.imin, i1, i2);
             b = make_chain(px, py, r.imin, i2, i1);
-            nitems = (r.nrows + ROWS_PER_ITEM - 1) / ROWS_PER_ITEM;
         }
     }
-    if (__ballot(nitems > 0) != 0) {
-        int incl = nitems;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        const int excl = incl - nitems;
-        const int total = __shfl(incl, 63);
+    // ---- scan-converted rows ----
+    if (!(w.debug & 16)) {
+        const int nch = (r.nrows + CHUNK - 1) / CHUNK;
+        const int incl = wave_scan_add(nch), excl = incl - nch;
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         const int sh_a = (a.xs1 & 0xffff) | (a.xs2 << 16), sh_b = (b.xs1 & 0xffff) | (b.xs2 << 16);
         const int sh_sw = (min(a.ysw, 0x7fff) & 0xffff) | (min(b.ysw, 0x7fff) << 16);
         const int sh_y = (r.ymin & 0xffff) | (r.ystart << 16), sh_n = r.nrows | ((int)kidx << 16);
-        for (int base = 0; base < total; base += BLOCK_CAP) {
-            int lo = max(excl, base), hi = min(incl, base + BLOCK_CAP);
-            for (int idx = lo; idx < hi; ++idx) w.blocks[idx - base] = (uint32_t)lane | ((uint32_t)(idx - excl) << 8);
-            wave_sync();
-            const int m = min(BLOCK_CAP, total - base);
-            for (int i0 = 0; i0 < m; i0 += 64) {
-                const int i = i0 + lane;
-                const bool live = i < m;
-                const uint32_t e = live ? w.blocks[i] : 0u;
-                const int f = e & 0xff, t = (int)(e >> 8);
-                const int ga = __shfl(sh_a, f), gb = __shfl(sh_b, f), gsw = __shfl(sh_sw, f), gy = __shfl(sh_y, f), gn = __shfl(sh_n, f);
-                const int adx1 = __shfl(a.dx1, f), adx2 = __shfl(a.dx2, f), bdx1 = __shfl(b.dx1, f), bdx2 = __shfl(b.dx2, f);
-                if (live) {
-                    const int ymin = (int)(short)(gy & 0xffff), ystart = gy >> 16, nrows = gn & 0xffff, k = gn >> 16;
-                    const int y0 = ystart + t * ROWS_PER_ITEM, y1 = min(y0 + ROWS_PER_ITEM, ystart + nrows) - 1;
-                    const int aysw = (int)(short)(gsw & 0xffff), bysw = gsw >> 16;           // 0x7fff = no second edge
-                    const int axs1 = (int)(short)(ga & 0xffff), axs2 = ga >> 16, bxs1 = (int)(short)(gb & 0xffff), bxs2 = gb >> 16;
-                    long long xa = chain_x(axs1, adx1, aysw, axs2, adx2, ymin, y0);
-                    long long xb = chain_x(bxs1, bdx1, bysw, bxs2, bdx2, ymin, y0);
-                    int da = y0 >= aysw ? adx2 : adx1, db = y0 >= bysw ? bdx2 : bdx1;
-                    uint32_t *rowp = w.planes + ((size_t)k * H + y0) * wpr;
-                    for (int y = y0; y <= y1; ++y, rowp += wpr) {
-                        long long xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
-                        int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+        for (int base = 0; base < total; base += 64) {
+            const int f = wave_owner(w.slots, w.gen, lane, nch > 0, excl, incl, base);
+            const int ga = __shfl(sh_a, f), gb = __shfl(sh_b, f), gsw = __shfl(sh_sw, f), gy = __shfl(sh_y, f), gn = __shfl(sh_n, f);
+            const int adx1 = __shfl(a.dx1, f), adx2 = __shfl(a.dx2, f), bdx1 = __shfl(b.dx1, f), bdx2 = __shfl(b.dx2, f);
+            const int ex = __shfl(excl, f);
+            if (base + lane < total) {
+                const int ymin = (int)(short)(gy & 0xffff), ystart = gy >> 16, nrows = gn & 0xffff;
+                const int y0 = ystart + CHUNK * (base + lane - ex), y1 = min(y0 + CHUNK, ystart + nrows) - 1;
+                const int aysw = (int)(short)(gsw & 0xffff), bysw = gsw >> 16;               // 0x7fff = no second edge
+                const int axs2 = ga >> 16, bxs2 = gb >> 16;
+                int xa = chain_x32((int)(short)(ga & 0xffff), adx1, aysw, axs2, adx2, ymin, y0);
+                int xb = chain_x32((int)(short)(gb & 0xffff), bdx1, bysw, bxs2, bdx2, ymin, y0);
+                int da = y0 >= aysw ? adx2 : adx1, db = y0 >= bysw ? bdx2 : bdx1;
+                uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(gn >> 16), (unsigned)H) + (unsigned)y0, (unsigned)wpr);
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    const int y = y0 + i;
+                    if (y <= y1) {
+                        const int xx1 = (min(xa, xb) + 32768) >> 16, xx2 = (max(xa, xb) + 32768) >> 16;
                         // OpenCV draws [xx1, xx2] clamped to the image unless it lies entirely outside
-                        int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TWp - 1);
+                        const int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TWp - 1);
                         if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
-                        xa += da; xb += db;
-                        if (y + 1 == aysw) { xa = (long long)axs2 << 16; da = adx2; }
-                        if (y + 1 == bysw) { xb = (long long)bxs2 << 16; db = bdx2; }
+                    }
+                    xa += da; xb += db;
+                    if (y + 1 == aysw) { xa = axs2 << 16; da = adx2; }
+                    if (y + 1 == bysw) { xb = bxs2 << 16; db = bdx2; }
+                    rowp += wpr;
+                }
+            }
+        }
+    }
+    // ---- outline edges ----
+    if (!(w.debug & 8)) {
+        const int cnt = lane < n ? __popc(em) : 0;
+        const int eincl = wave_scan_add(cnt), eexcl = eincl - cnt;
+        const int etotal = __builtin_amdgcn_readlane(eincl, 63);
+        for (int ebase = 0; ebase < etotal; ebase += 64) {
+            // lane -> (face, edge): the j-th edge of the face's mask
+            const int f = wave_owner(w.slots, w.gen, lane, cnt > 0, eexcl, eincl, ebase);
+            const int emf = __shfl((int)em, f), j = ebase + lane - __shfl(eexcl, f);
+            const bool valid = ebase + lane < etotal;
+            const int first = (emf & 1) ? 0 : ((emf & 2) ? 1 : 2), second = ((emf & 3) == 3) ? 1 : 2;
+            const int l = j == 0 ? first : (j == 1 ? second : 2);
+            const int fa = valid ? f : 0;
+            const uint32_t pa = w.q[(l == 0 ? 3 : l) * QCAP + fa], pb = w.q[(1 + l) * QCAP + fa];   // vertex (l == 0 ? 2 : l - 1), vertex l
+            const int ek = (int)(w.q[fa] & 15u);
+            int x1 = unpack_x(pa), y1 = unpack_y(pa), x2 = unpack_x(pb), y2 = unpack_y(pb);
+            bool ok = valid;
+            const bool outside = (unsigned)x1 >= (unsigned)W || (unsigned)x2 >= (unsigned)W || (unsigned)y1 >= (unsigned)H || (unsigned)y2 >= (unsigned)H;
+            if (__ballot(ok && outside) != 0) {
+                if (ok && outside) ok = clip_line_small(W, H, x1, y1, x2, y2);
+            }
+            int dx = x2 - x1, dy = y2 - y1, sx = x1, sy = y1;
+            if (dx < 0) { dx = -dx; dy = -dy; sx = x2; sy = y2; }
+            ok = ok && !(sx >= X0 + TWp || sx + dx < X0);                    // the x range misses the strip
+            const int ady = abs(dy);
+            const bool up = dy < 0, vert = ady > dx;
+            const int x0 = up ? sx + dx : sx, ytop = up ? sy - ady : sy;
+            // per-row increment of (quotient, remainder): divmod(2 dx, 2 |dy|); y-major: (0, 2 dx)
+            int ia = 0, ib = 2 * dx;
+            if (!vert && ady > 0) { ia = (int)udiv_small((unsigned)dx, (unsigned)ady); ib = 2 * (dx - __mul24(ia, ady)); }
+            const int nch = ok ? (ady + CHUNK) / CHUNK : 0;
+            const int rincl = wave_scan_add(nch), rexcl = rincl - nch;
+            const int rtotal = __builtin_amdgcn_readlane(rincl, 63);
+            const int e1 = (ytop & 0xffff) | (x0 << 16), e2 = dx | (ady << 16), e3 = ia | (ib << 16);
+            const int e4 = ek | (up ? 16 : 0) | (vert ? 32 : 0);
+            for (int rbase = 0; rbase < rtotal; rbase += 64) {
+                const int e = wave_owner(w.slots, w.gen, lane, nch > 0, rexcl, rincl, rbase);
+                const int g1 = __shfl(e1, e), g2 = __shfl(e2, e), g3 = __shfl(e3, e), g4 = __shfl(e4, e), gx = __shfl(rexcl, e);
+                if (rbase + lane < rtotal) {
+                    const int tau0 = CHUNK * (rbase + lane - gx);
+                    const int gdx = g2 & 0xffff, gady = g2 >> 16, D = 2 * gady;
+                    const int gia = g3 & 0xffff, gib = (int)((unsigned)g3 >> 16);
+                    const bool gup = (g4 & 16) != 0, gvert = (g4 & 32) != 0;
+                    // state: q = floor(N / D), rem = N - q D for the row's N; x-major rows run from `lo` (the previous q) to q - 1
+                    int q, rem, lo = 0;
+                    if (gady == 0) {                                         // horizontal: one row, offsets 0..dx
+                        q = gdx + 1; rem = 0;
+                    } else {
+                        const int c = gvert ? gady - (gup ? 0 : 1) : 2 * gdx + D - gdx - (gup ? 1 : 0);
+                        if (tau0 == 0) {
+                            // N = c < 2 D:  y-major c < D;  x-major c = dx + D - s in [D - 1, ...): one division all the same
+                            q = (int)udiv_small((unsigned)c, (unsigned)D);
+                            rem = c - __mul24(q, D);
+                        } else {
+                            const unsigned N = (unsigned)(__mul24(2 * gdx, tau0) + c);
+                            q = (int)udiv_small(N, (unsigned)D);
+                            rem = (int)N - __mul24(q, D);
+                            if (!gvert) lo = q - gia - (rem < gib ? 1 : 0);
+                        }
+                    }
+                    const int gx0 = g1 >> 16, ytop_e = (int)(short)(g1 & 0xffff);
+                    const int taue = min(tau0 + CHUNK - 1, gady);
+                    uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H) + (unsigned)(ytop_e + tau0), (unsigned)wpr);
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i) {
+                        if (tau0 + i <= taue) {
+                            const int l0 = gvert ? q : lo, h0 = gvert ? q : min(q - 1, gdx);
+                            const int xs = gup ? gx0 - h0 : gx0 + l0, xe = gup ? gx0 - l0 : gx0 + h0;
+                            const int s0 = max(xs, X0), s1 = min(xe, X0 + TWp - 1);
+                            if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
+                        }
+                        lo = q;
+                        rem += gib;
+                        const bool carry = rem >= D;
+                        rem -= carry ? D : 0;
+                        q += gia + (carry ? 1 : 0);
+                        rowp += wpr;
                     }
                 }
             }
-            wave_sync();
-        }
-    }
-    // outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2).  Every edge that has to be drawn is cut into segments of
-    // SEG steps (of the unclipped major length; steps that clipping removes are simply empty); the segments are numbered by a
-    // wave prefix sum, listed in LDS by their owners and walked one per lane, each entered in closed form.
-    if (!(w.debug & 8)) {
-        int nseg[3] = {0, 0, 0};
-        if (lane < n) {
-            const unsigned em = (w.q[lane] >> 4) & 7u;
-            const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                const int ia = l == 0 ? 2 : l - 1, ib = l;
-                const int len = max(abs(px[ia] - px[ib]), abs(py[ia] - py[ib])) + 1;
-                nseg[l] = ((em >> l) & 1u) ? (len + SEG - 1) / SEG : 0;
-            }
-        }
-        const int mine = nseg[0] + nseg[1] + nseg[2];
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        const int excl = incl - mine;
-        const int total = __shfl(incl, 63);
-        for (int base = 0; base < total; base += BLOCK_CAP) {
-            int lo = max(excl, base), hi = min(incl, base + BLOCK_CAP);
-            for (int idx = lo; idx < hi; ++idx) {
-                int j = idx - excl, l = 0;
-                if (j >= nseg[0]) { j -= nseg[0]; l = 1; if (j >= nseg[1]) { j -= nseg[1]; l = 2; } }
-                w.blocks[idx - base] = (uint32_t)lane | ((uint32_t)l << 6) | ((uint32_t)j << 8);
-            }
-            wave_sync();
-            const int m = min(BLOCK_CAP, total - base);
-            for (int i = lane; i < m; i += 64) {
-                const uint32_t e = w.blocks[i];
-                const int f = e & 63, l = (e >> 6) & 3, j = (int)(e >> 8);
-                const int ia = l == 0 ? 2 : l - 1, ib = l;
-                const uint32_t q0 = w.q[f], pa = w.q[(1 + ia) * QCAP + f], pb = w.q[(1 + ib) * QCAP + f];
-                draw_line_bits(w.planes + (size_t)(q0 & 15u) * H * wpr, H, W, X0, TWp, wpr, unpack_x(pa), unpack_y(pa), unpack_x(pb), unpack_y(pb),
-                               j * SEG, j * SEG + SEG - 1);
-            }
-            wave_sync();
         }
     }
     wave_sync();
@@ -1288,9 +1421,10 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
     }
     BitCtx w;
     w.planes = planes;
-    w.q = (uint32_t *)tab + pair_tab_dw<NB, OutT>() + wave * WAVE_LDS_DW;
-    w.blocks = w.q + Q_DW;
-    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug;
+    w.q = (uint32_t *)tab + pair_tab_dw<NB, OutT>() + wave * BITS_WAVE_LDS_DW;
+    w.slots = w.q + Q_DW;
+    w.slots[lane] = 0;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug; w.gen = 0;
     Camera cam;
     {
         float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
@@ -1318,7 +1452,7 @@ inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) 
     size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
     size_t P = (size_t)1 << (2 * bits_index_bits(K));
     size_t tab_dw = 3 * P * (out_mode == TDS_OUT_F32 ? 2 : 1);
-    return (plane_dw + tab_dw + (size_t)nwaves * WAVE_LDS_DW) * 4;
+    return (plane_dw + tab_dw + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
 }
 int g_bits_waves = 4;
 
