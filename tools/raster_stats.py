@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Work counters of the K3 bit-plane kernel on the bench workload (debug flag 128): per wave and image."""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from torchdrivesim_amd import _native
+from torchdrivesim_amd.utils import Resolution
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dev = torch.device('cuda', 0)
+sim, actions, _ = bench.build_simulator(B, 64, dev, seed=1234)
+for i in range(5):
+    sim.step(actions[i % 8])
+L = _native.lib()
+L.tds_raster_set_debug.argtypes = [ctypes.c_int]
+L.tds_raster_get_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+buf = (ctypes.c_ulonglong * 16)()
+sim.render_egocentric(res=Resolution(256, 256), fov=35.0); torch.cuda.synchronize()
+L.tds_raster_get_stats(buf)
+L.tds_raster_set_debug(128)
+sim.render_egocentric(res=Resolution(256, 256), fov=35.0); torch.cuda.synchronize()
+L.tds_raster_set_debug(0)
+L.tds_raster_get_stats(buf)
+names = ['batches', 'faces', 'fill chunks', 'fill windows', 'fill rows', 'edges', 'edge rounds', 'V chunks', 'V windows', 'V rows', 'H chunks',
+         'H windows', 'H rows', 'V edges', 'clipped edges', 'faces with rows']
+nimg = B * 64
+for n, v in zip(names, buf):
+    print(f'{n:14s} {v / nimg:10.1f} per image {v / nimg / 4:10.2f} per wave')

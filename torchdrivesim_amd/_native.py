@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtdship.so')
+LIB_PATH = os.environ.get('TDSHIP_LIB') or os.path.join(_HERE, 'lib', 'libtdship.so')     # TDSHIP_LIB: tuning builds (tools/)
 CSRC = os.path.join(_HERE, 'csrc')
 
 METRIC_IOU, METRIC_DISCS = 0, 1

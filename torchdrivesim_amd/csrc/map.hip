@@ -125,7 +125,8 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
             int cy0 = tds::cell_coord(fy0, oy, inv), cy1 = tds::cell_coord(fy1, oy, inv);
             for (int cy = cy0; cy <= cy1; ++cy)
                 for (int cx = cx0; cx <= cx1; ++cx) {
-                    e.ddx = (uint16_t)(cx - cx0); e.ddy = (uint16_t)((cy - cy0) | ((int)dup[(size_t)f] << 13));
+                    e.own = (uint32_t)cx0 | ((uint32_t)cx1 << 13) | (cx > cx0 ? (1u << 26) : 0u) | (cy > cy0 ? (1u << 27) : 0u) |
+                            ((uint32_t)dup[(size_t)f] << 29);
                     entries[(size_t)cursor[(size_t)cy * nx + cx]++] = e;
                 }
         }

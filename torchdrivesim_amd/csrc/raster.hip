@@ -107,7 +107,7 @@ __device__ inline bool inside_polygon(const Camera &cam, float x, float y) {
 }
 
 // Cameras.transform_points_screen (base.py:102-115) on camera-shifted coordinates, then .to(int32) (cv2.py:48)
-__device__ inline void project(const Camera &cam, float scale, int res, float vx, float vy, int &ox, int &oy) {
+__device__ inline void project(const Camera &cam, float scale, int res, float vx, float vy, int &ox, int &oy, float &fx, float &fy) {
     float x = vx - 0.0f, y = vy - 0.0f;
     float rx = cam.c * x + cam.s * y;
     float ry = (-cam.s) * x + cam.c * y;
@@ -115,6 +115,7 @@ __device__ inline void project(const Camera &cam, float scale, int res, float vx
     rx = (rx * (float)res) / 2.0f; ry = (ry * (float)res) / 2.0f;
     rx = rx + (float)res / 2.0f; ry = ry + (float)res / 2.0f;
     ox = (int)rx; oy = (int)ry;
+    fx = rx; fy = ry;
 }
 
 // truncating division n / d for d > 0, |n| < 2^52: the correctly rounded double quotient can only hit an integer
@@ -463,12 +464,31 @@ __device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
 __device__ inline bool trim_project(const Camera &cam, float scale, int res, int X0, int TW, const float *sx, const float *sy,
                                     int *px, int *py, unsigned &ins) {
     ins = 0;
+    float fx[3], fy[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) project(cam, scale, res, sx[k], sy[k], px[k], py[k]);
+    for (int k = 0; k < 3; ++k) project(cam, scale, res, sx[k], sy[k], px[k], py[k], fx[k], fy[k]);
     int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
     int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
     if (xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res) return false;
-    ins = (inside_polygon(cam, sx[0], sy[0]) ? 1u : 0u) | (inside_polygon(cam, sx[1], sy[1]) ? 2u : 0u) | (inside_polygon(cam, sx[2], sy[2]) ? 4u : 0u);
+    // The trim polygon is the image square scaled by 1.05 about its centre, i.e. pixel coordinates in [-0.025 res, 1.025 res]^2.
+    // The two fp32 formulations (pixel coordinates here, the reference's half-plane tests in world coordinates) agree to well
+    // below 1e-2 pixel, so only vertices within `band` of the border need the reference's own test (NaNs end up there too).
+    const float lo = -0.025f * (float)res, hi = 1.025f * (float)res, band = 0.0625f * fmaxf(1.0f, (float)res * (1.0f / 256.0f));
+    unsigned amb = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float mn = fminf(fx[k], fy[k]), mx = fmaxf(fx[k], fy[k]), sum = fx[k] + fy[k];
+        const bool fin = sum == sum;                                   // fminf / fmaxf drop NaNs: keep them for the exact test
+        const bool in = fin && mn > lo + band && mx < hi - band;
+        const bool out = fin && (mn < lo - band || mx > hi + band);
+        ins |= in ? (1u << k) : 0u;
+        amb |= (!in && !out) ? (1u << k) : 0u;
+    }
+    if (__builtin_expect(__ballot(amb != 0) != 0, 0)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if ((amb >> k) & 1u) ins |= inside_polygon(cam, sx[k], sy[k]) ? (1u << k) : 0u;
+    }
     return ins != 0;
 }
 
@@ -596,16 +616,66 @@ __device__ __forceinline__ void drain(WaveCtx &w, bool acc, uint32_t key, const 
     __syncthreads();
 
 // ---- scene producer: actors, then the masked-agent dot, then the static map cells under a pixel window --------------
+constexpr int SCAN_EMPTY_ROW = (int)0xffff7fffu;     // cell range lo = 0x7fff, hi = -1
 struct ScanState {
     int phase, a0, f;
     bool masked_seen, near;
     float sx0, sx1, sx2, sx3, sx4, sx5, sx6, sy0, sy1, sy2, sy3, sy4, sy5, sy6;
     uint32_t kbody, kdir;
-    int cx0, cx1, cy0, cy1, cy, chunk;
+    int cx0, cx1, cy0, nrows, row, chunk, prev_rw;       // wave-uniform: cell rectangle, grid rows to scan, position
+    int rw, re0, re1, rfe;                               // lane r: grid row (block start + r): cell range lo | hi << 16, entry range, end of its first cell
 };
 
+// Lane r prepares grid row `row0 + r` of the scan: the cells of that row under the window polygon (the pixel window plus a 2 px
+// margin, a rotated rectangle in world space) and where their entries start and end.  The entries of consecutive cells of a
+// grid row are contiguous, so a row is ONE range of entries.
+__device__ __forceinline__ void scan_load_rows(ScanState &st, const MapView &m, const CommonArgs &c, const Camera &cam, int lane, int X0, int TWw,
+                                               int row0) {
+    const int res = c.res;
+    const float half = (float)res / 2.0f;
+    const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TWw, res) + 2.0f}, pys[2] = {-2.0f, (float)res + 2.0f};
+    float qx[4], qy[4];                                    // corners in order around the rectangle
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x = -((pxs[(k == 1 || k == 2) ? 1 : 0] - half) / half) / c.scale, y = -((pys[k >= 2 ? 1 : 0] - half) / half) / c.scale;
+        qx[k] = cam.c * x - cam.s * y + cam.cx; qy[k] = cam.s * x + cam.c * y + cam.cy;
+    }
+    const float eps = 1e-3f + 1e-6f * (fabsf(cam.cx) + fabsf(cam.cy));
+    const int r = row0 + lane;
+    st.rw = SCAN_EMPTY_ROW; st.re0 = 0; st.re1 = 0; st.rfe = 0;
+    if (r < st.nrows) {
+        const int cy = st.cy0 + r;
+        const float ya = m.oy + (float)cy * m.cell - eps - 1e-4f * m.cell, yb = m.oy + (float)(cy + 1) * m.cell + eps + 1e-4f * m.cell;
+        float xmin = 3.0e38f, xmax = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x0 = qx[k], y0 = qy[k], x1 = qx[(k + 1) & 3], y1 = qy[(k + 1) & 3];
+            if (y0 >= ya && y0 <= yb) { xmin = fminf(xmin, x0); xmax = fmaxf(xmax, x0); }
+            const float dy = y1 - y0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float yl = j == 0 ? ya : yb;
+                if ((y0 - yl) * (y1 - yl) <= 0.0f && dy != 0.0f) {
+                    const float x = x0 + (yl - y0) / dy * (x1 - x0);
+                    xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+                }
+            }
+        }
+        if (xmin <= xmax) {
+            const float pad = eps + 1e-4f * m.cell;
+            const float f0 = fminf(fmaxf((xmin - pad - m.ox) * m.inv_cell, -1.0f), (float)m.nx), f1 = fminf(fmaxf((xmax + pad - m.ox) * m.inv_cell, -1.0f), (float)m.nx);
+            const int lo = max((int)floorf(f0), st.cx0), hi = min((int)floorf(f1), st.cx1);
+            if (lo <= hi) {
+                const int32_t *cs = m.cell_start + (size_t)cy * m.nx;
+                st.rw = lo | (hi << 16);
+                st.re0 = cs[lo]; st.re1 = cs[hi + 1]; st.rfe = cs[lo + 1];
+            }
+        }
+    }
+}
+
 // window = pixel columns [X0, X0 + TWw) of the image (the whole image when binning)
-__device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int wave, int X0, int TWw) {   // wave = index among the cooperating waves
+__device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int lane, int wave, int X0, int TWw) {   // wave = index among the cooperating waves
     const MapView &m = a.map;
     const int res = c.res;
     st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map
@@ -613,9 +683,10 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, con
     st.sx0 = st.sx1 = st.sx2 = st.sx3 = st.sx4 = st.sx5 = st.sx6 = 0.0f;
     st.sy0 = st.sy1 = st.sy2 = st.sy3 = st.sy4 = st.sy5 = st.sy6 = 0.0f;
     st.kbody = st.kdir = 0;
-    st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.cy1 = -1; st.cy = 0; st.chunk = wave;
+    st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
+    st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
     if (m.nx > 0 && !(c.debug & 1)) {
-        // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell range
+        // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell rectangle
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
         const float half = (float)res / 2.0f;
         const float pxs[2] = {(float)X0 - 2.0f, (float)min(X0 + TWw, res) + 2.0f}, pys[2] = {-2.0f, (float)res + 2.0f};
@@ -631,9 +702,10 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, con
         float fx0 = fminf(fmaxf((wx0 - eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx), fx1 = fminf(fmaxf((wx1 + eps - m.ox) * m.inv_cell, -1.0f), (float)m.nx);
         float fy0 = fminf(fmaxf((wy0 - eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny), fy1 = fminf(fmaxf((wy1 + eps - m.oy) * m.inv_cell, -1.0f), (float)m.ny);
         st.cx0 = max((int)floorf(fx0), 0); st.cx1 = min((int)floorf(fx1), m.nx - 1);
-        st.cy0 = max((int)floorf(fy0), 0); st.cy1 = min((int)floorf(fy1), m.ny - 1);
-        st.cy = st.cy0;
-        if (st.cx0 > st.cx1) st.cy1 = st.cy0 - 1;
+        st.cy0 = max((int)floorf(fy0), 0);
+        const int cy1 = min((int)floorf(fy1), m.ny - 1);
+        st.nrows = (st.cx0 <= st.cx1 && st.cy0 <= cy1) ? __builtin_amdgcn_readfirstlane(cy1 - st.cy0 + 1) : 0;
+        if (st.nrows > 0) scan_load_rows(st, m, c, cam, lane, X0, TWw, 0);
     }
 }
 
@@ -711,33 +783,43 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
         st.phase = 2;
         return true;
     }
-    // static map: the cells cx0..cx1 of one grid row are ONE contiguous range of entries; chunks of 64 consecutive
+    // static map: the cells of one grid row under the window are ONE contiguous range of entries; chunks of 64 consecutive
     // entries are dealt round-robin to the waves
-    while (st.cy <= st.cy1) {
-        const int e0 = m.cell_start[st.cy * m.nx + st.cx0], e1 = m.cell_start[st.cy * m.nx + st.cx1 + 1];
+    while (st.row < st.nrows) {
+        const int rl = st.row & 63;
+        const int e0 = __builtin_amdgcn_readlane(st.re0, rl), e1 = __builtin_amdgcn_readlane(st.re1, rl);
         const int nchunks = (e1 - e0 + 63) >> 6;
         if (st.chunk < nchunks) {
-            const int first_end = m.cell_start[st.cy * m.nx + st.cx0 + 1];
+            const int first_end = __builtin_amdgcn_readlane(st.rfe, rl);
+            const int pw = rl > 0 ? __builtin_amdgcn_readlane(st.rw, rl > 0 ? rl - 1 : 0) : st.prev_rw;     // cell range of the row above
+            const int plo = pw & 0xffff, phi = pw >> 16;
             int i = e0 + st.chunk * 64 + lane;
             if (i < e1) {
                 const uint4 *ep = (const uint4 *)(m.entries + i);
                 uint4 u0 = ep[0], u1 = ep[1];
-                unsigned dd = u1.w;                                     // ddx | ddy << 16 (offsets from the bbox-min cell) | repeated-edge bits << 29
-                // exactly one of the scanned cells owns the face: the first one its bounding box touches
-                bool owner = (((dd & 0xffffu) == 0) || (i < first_end)) && ((((dd >> 16) & 0x1fffu) == 0) || (st.cy == st.cy0));
-                if (owner) {
+                const unsigned own = u1.w;              // see GridEntry::own
+                // Exactly one of the scanned cells emits the face: in its grid row the first scanned cell of the face's bounding
+                // box; among the rows the first one where the bounding box meets the scanned cells (the row above has none).
+                const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
+                const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
+                const bool none_above = !(own & (1u << 27)) || st.row == 0 || bx1 < plo || bx0 > phi;
+                if (first_in_row && none_above) {
                     float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
                     float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
                     key = u1.z;
                     acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins);
-                    edges = edge_mask(dd >> 29, ins);
+                    edges = edge_mask(own >> 29, ins);
                 }
             }
             st.chunk += NW;
             return true;
         }
         st.chunk -= nchunks;
-        ++st.cy;
+        ++st.row;
+        if ((st.row & 63) == 0 && st.row < st.nrows) {            // more than 64 grid rows: prepare the next block
+            st.prev_rw = __builtin_amdgcn_readlane(st.rw, 63);
+            scan_load_rows(st, m, c, cam, lane, X0, TWw, st.row);
+        }
     }
     return false;
 }
@@ -748,7 +830,7 @@ template <int TW, typename OutT>
 __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgs a, CommonArgs c) {
     TDS_RASTER_PROLOGUE()
     ScanState st;
-    scan_init(st, a, c, cam, wave, X0, TW);
+    scan_init(st, a, c, cam, lane, wave, X0, TW);
     for (;;) {
         bool acc;
         uint32_t key;
@@ -790,7 +872,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgs a, 
     wave_sync();
     uint4 *mine = lists + (size_t)img * strips * caps;
     ScanState st;
-    scan_init(st, a, c, cam, 0, 0, W);
+    scan_init(st, a, c, cam, lane, 0, 0, W);
     for (;;) {
         bool acc;
         uint32_t key;
@@ -831,7 +913,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
         }
     } else {
         ScanState st;
-        scan_init(st, a, c, cam, wave, X0, TW);
+        scan_init(st, a, c, cam, lane, wave, X0, TW);
         for (;;) {
             bool acc;
             uint32_t key;
@@ -855,7 +937,6 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
 // with ds_max on packed keys -- the result does not depend on the order in which faces are processed.
 // =========================================================================================================
 constexpr int MAX_KEYS = 15;              // key indices 1..15 fit 4 bits (0 = background)
-constexpr int ROWS_PER_ITEM = 8;
 constexpr int BITS_WAVE_LDS_DW = Q_DW + 64;   // per wave: face queue + owner markers
 
 struct KeyTable { uint32_t key[16]; int n; };      // ascending = painter order (later wins)
@@ -871,12 +952,11 @@ struct BitCtx {
 __device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int s0, int s1) {
     const int w0 = s0 >> 5, w1 = s1 >> 5;
     const uint32_t m0 = 0xffffffffu << (s0 & 31), m1 = 0xffffffffu >> (31 - (s1 & 31));
-    if (w0 == w1) {
-        atomicOr(rowp + w0, m0 & m1);
-    } else {
-        atomicOr(rowp + w0, m0);
-        for (int wd = w0 + 1; wd < w1; ++wd) atomicOr(rowp + wd, 0xffffffffu);
+    atomicOr(rowp + w0, w0 == w1 ? (m0 & m1) : m0);
+    if (w1 > w0) {
         atomicOr(rowp + w1, m1);
+        // words in between become all ones: a plain store is as good as an OR whatever else is being OR-ed into them
+        for (int wd = w0 + 1; wd < w1; ++wd) *(volatile uint32_t *)(rowp + wd) = 0xffffffffu;
     }
 }
 
@@ -1116,7 +1196,22 @@ __device__ __forceinline__ int chain_x32(int xs1, int dx1, int ysw, int xs2, int
 //            c2 = 2 |dy| - dx - (sgn < 0).
 // Both are floor((N0 + tau * 2 dx) / D): stepping tau adds divmod(2 dx, D) = (ia, ib) to (quotient, remainder) with one carry.
 // (checked exhaustively against the iterative walk in tests/test_oracle_fill.py::test_line_rows_closed_form)
-constexpr int CHUNK = 4;
+// optional work counters (profiling hook tds_raster_get_stats; active with debug flag 128)
+__device__ unsigned long long g_stats[16];
+#define TDS_STAT_LANES(W, I, V) do { if ((W).debug & 128) { const unsigned long long v_ = (unsigned long long)(V); if (v_) atomicAdd(&g_stats[I], v_); } } while (0)
+#define TDS_STAT(W, I, V) do { if (((W).debug & 128) && (W).lane == 0) atomicAdd(&g_stats[I], (unsigned long long)(V)); } while (0)
+#ifndef TDS_FCHUNK
+#define TDS_FCHUNK 4
+#endif
+#ifndef TDS_VCHUNK
+#define TDS_VCHUNK 6
+#endif
+#ifndef TDS_HCHUNK
+#define TDS_HCHUNK 3
+#endif
+constexpr int CHUNK = TDS_FCHUNK;     // rows per item: scan conversion
+constexpr int VCHUNK = TDS_VCHUNK;    // rows per item: y-major outline edges (one pixel per row)
+constexpr int HCHUNK = TDS_HCHUNK;    // rows per item: x-major outline edges (one run per row)
 
 __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
     const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0, TWp = w.TWp, wpr = w.wpr;
@@ -1135,11 +1230,14 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
             b = make_chain(px, py, r.imin, i2, i1);
         }
     }
+    TDS_STAT(w, 0, 1); TDS_STAT(w, 1, n);
     // ---- scan-converted rows ----
     if (!(w.debug & 16)) {
         const int nch = (r.nrows + CHUNK - 1) / CHUNK;
         const int incl = wave_scan_add(nch), excl = incl - nch;
         const int total = __builtin_amdgcn_readlane(incl, 63);
+        TDS_STAT(w, 2, total); TDS_STAT(w, 3, (total + 63) / 64);
+        TDS_STAT_LANES(w, 4, r.nrows); TDS_STAT_LANES(w, 15, r.nrows > 0 ? 1 : 0);
         const int sh_a = (a.xs1 & 0xffff) | (a.xs2 << 16), sh_b = (b.xs1 & 0xffff) | (b.xs2 << 16);
         const int sh_sw = (min(a.ysw, 0x7fff) & 0xffff) | (min(b.ysw, 0x7fff) << 16);
         const int sh_y = (r.ymin & 0xffff) | (r.ystart << 16), sh_n = r.nrows | ((int)kidx << 16);
@@ -1179,6 +1277,7 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
         const int cnt = lane < n ? __popc(em) : 0;
         const int eincl = wave_scan_add(cnt), eexcl = eincl - cnt;
         const int etotal = __builtin_amdgcn_readlane(eincl, 63);
+        TDS_STAT(w, 5, etotal); TDS_STAT(w, 6, (etotal + 63) / 64);
         for (int ebase = 0; ebase < etotal; ebase += 64) {
             // lane -> (face, edge): the j-th edge of the face's mask
             const int f = wave_owner(w.slots, w.gen, lane, cnt > 0, eexcl, eincl, ebase);
@@ -1201,56 +1300,90 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
             const int ady = abs(dy);
             const bool up = dy < 0, vert = ady > dx;
             const int x0 = up ? sx + dx : sx, ytop = up ? sy - ady : sy;
-            // per-row increment of (quotient, remainder): divmod(2 dx, 2 |dy|); y-major: (0, 2 dx)
-            int ia = 0, ib = 2 * dx;
+            // x-major edges: per-row increment of (quotient, remainder) = divmod(2 dx, 2 |dy|)
+            int ia = 0, ib = 0;
             if (!vert && ady > 0) { ia = (int)udiv_small((unsigned)dx, (unsigned)ady); ib = 2 * (dx - __mul24(ia, ady)); }
-            const int nch = ok ? (ady + CHUNK) / CHUNK : 0;
-            const int rincl = wave_scan_add(nch), rexcl = rincl - nch;
-            const int rtotal = __builtin_amdgcn_readlane(rincl, 63);
-            const int e1 = (ytop & 0xffff) | (x0 << 16), e2 = dx | (ady << 16), e3 = ia | (ib << 16);
-            const int e4 = ek | (up ? 16 : 0) | (vert ? 32 : 0);
-            for (int rbase = 0; rbase < rtotal; rbase += 64) {
-                const int e = wave_owner(w.slots, w.gen, lane, nch > 0, rexcl, rincl, rbase);
-                const int g1 = __shfl(e1, e), g2 = __shfl(e2, e), g3 = __shfl(e3, e), g4 = __shfl(e4, e), gx = __shfl(rexcl, e);
-                if (rbase + lane < rtotal) {
-                    const int tau0 = CHUNK * (rbase + lane - gx);
-                    const int gdx = g2 & 0xffff, gady = g2 >> 16, D = 2 * gady;
-                    const int gia = g3 & 0xffff, gib = (int)((unsigned)g3 >> 16);
-                    const bool gup = (g4 & 16) != 0, gvert = (g4 & 32) != 0;
-                    // state: q = floor(N / D), rem = N - q D for the row's N; x-major rows run from `lo` (the previous q) to q - 1
-                    int q, rem, lo = 0;
-                    if (gady == 0) {                                         // horizontal: one row, offsets 0..dx
-                        q = gdx + 1; rem = 0;
-                    } else {
-                        const int c = gvert ? gady - (gup ? 0 : 1) : 2 * gdx + D - gdx - (gup ? 1 : 0);
-                        if (tau0 == 0) {
-                            // N = c < 2 D:  y-major c < D;  x-major c = dx + D - s in [D - 1, ...): one division all the same
-                            q = (int)udiv_small((unsigned)c, (unsigned)D);
-                            rem = c - __mul24(q, D);
-                        } else {
-                            const unsigned N = (unsigned)(__mul24(2 * gdx, tau0) + c);
-                            q = (int)udiv_small(N, (unsigned)D);
-                            rem = (int)N - __mul24(q, D);
-                            if (!gvert) lo = q - gia - (rem < gib ? 1 : 0);
+            const int e1 = (ytop & 0xffff) | (x0 << 16), e2 = dx | (ady << 16), e3 = ia | (ib << 16), e4 = ek | (up ? 16 : 0);
+            // ---- y-major edges: one pixel per row, items of VCHUNK rows
+            {
+                const int nch = (ok && vert) ? (ady + VCHUNK) / VCHUNK : 0;
+                const int rincl = wave_scan_add(nch), rexcl = rincl - nch;
+                const int rtotal = __builtin_amdgcn_readlane(rincl, 63);
+                TDS_STAT(w, 7, rtotal); TDS_STAT(w, 8, (rtotal + 63) / 64);
+                TDS_STAT_LANES(w, 9, (ok && vert) ? ady + 1 : 0); TDS_STAT_LANES(w, 13, (ok && vert) ? 1 : 0);
+                for (int rbase = 0; rbase < rtotal; rbase += 64) {
+                    const int e = wave_owner(w.slots, w.gen, lane, nch > 0, rexcl, rincl, rbase);
+                    const int g1 = __shfl(e1, e), g2 = __shfl(e2, e), g4 = __shfl(e4, e), gx = __shfl(rexcl, e);
+                    const bool live = rbase + lane < rtotal;
+                    const int tau0 = VCHUNK * (rbase + lane - gx);
+                    const int gdx = g2 & 0xffff, gady = g2 >> 16, D = 2 * gady, A = 2 * gdx;
+                    const bool gup = (g4 & 16) != 0;
+                    int q = 0, rem = gady - (gup ? 0 : 1);                  // row 0: N = c < D
+                    if (__ballot(live && tau0 > 0) != 0) {
+                        const unsigned N = (unsigned)(__mul24(A, tau0) + rem);
+                        q = (int)udiv_small(N, (unsigned)max(D, 1));
+                        rem = (int)N - __mul24(q, D);
+                    }
+                    if (live) {
+                        const int gx0 = g1 >> 16, ytop_e = (int)(short)(g1 & 0xffff);
+                        const int nrow = min(VCHUNK, gady - tau0 + 1);
+                        uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H) + (unsigned)(ytop_e + tau0), (unsigned)wpr);
+#pragma unroll
+                        for (int i = 0; i < VCHUNK; ++i) {
+                            const int lx = (gup ? gx0 - q : gx0 + q) - X0;
+                            if (i < nrow && (unsigned)lx < (unsigned)TWp) atomicOr(rowp + (lx >> 5), 1u << (lx & 31));
+                            rem += A;
+                            const bool carry = rem >= D;
+                            rem -= carry ? D : 0;
+                            q += carry ? 1 : 0;
+                            rowp += wpr;
                         }
                     }
-                    const int gx0 = g1 >> 16, ytop_e = (int)(short)(g1 & 0xffff);
-                    const int taue = min(tau0 + CHUNK - 1, gady);
-                    uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H) + (unsigned)(ytop_e + tau0), (unsigned)wpr);
-#pragma unroll
-                    for (int i = 0; i < CHUNK; ++i) {
-                        if (tau0 + i <= taue) {
-                            const int l0 = gvert ? q : lo, h0 = gvert ? q : min(q - 1, gdx);
-                            const int xs = gup ? gx0 - h0 : gx0 + l0, xe = gup ? gx0 - l0 : gx0 + h0;
-                            const int s0 = max(xs, X0), s1 = min(xe, X0 + TWp - 1);
-                            if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
+                }
+            }
+            // ---- x-major edges: one run per row, items of HCHUNK rows
+            {
+                const int nch = (ok && !vert) ? (ady + HCHUNK) / HCHUNK : 0;
+                const int rincl = wave_scan_add(nch), rexcl = rincl - nch;
+                const int rtotal = __builtin_amdgcn_readlane(rincl, 63);
+                TDS_STAT(w, 10, rtotal); TDS_STAT(w, 11, (rtotal + 63) / 64);
+                TDS_STAT_LANES(w, 12, (ok && !vert) ? ady + 1 : 0); TDS_STAT_LANES(w, 14, (valid && outside) ? 1 : 0);
+                for (int rbase = 0; rbase < rtotal; rbase += 64) {
+                    const int e = wave_owner(w.slots, w.gen, lane, nch > 0, rexcl, rincl, rbase);
+                    const int g1 = __shfl(e1, e), g2 = __shfl(e2, e), g3 = __shfl(e3, e), g4 = __shfl(e4, e), gx = __shfl(rexcl, e);
+                    if (rbase + lane < rtotal) {
+                        const int tau0 = HCHUNK * (rbase + lane - gx);
+                        const int gdx = g2 & 0xffff, gady = g2 >> 16, D = 2 * gady;
+                        const int gia = g3 & 0xffff, gib = (int)((unsigned)g3 >> 16);
+                        const bool gup = (g4 & 16) != 0;
+                        // state: q = G_{tau+1} = floor(N / D), rem = N - q D; the row runs from lo = G_tau to q - 1
+                        int q, rem = 0, lo = 0;
+                        if (gady == 0) {                                     // horizontal: one row, offsets 0..dx
+                            q = gdx + 1;
+                        } else {
+                            const unsigned N = (unsigned)(__mul24(2 * gdx, tau0) + gdx + D - (gup ? 1 : 0));
+                            q = (int)udiv_small(N, (unsigned)D);
+                            rem = (int)N - __mul24(q, D);
+                            if (tau0 > 0) lo = q - gia - (rem < gib ? 1 : 0);
                         }
-                        lo = q;
-                        rem += gib;
-                        const bool carry = rem >= D;
-                        rem -= carry ? D : 0;
-                        q += gia + (carry ? 1 : 0);
-                        rowp += wpr;
+                        const int gx0 = g1 >> 16, ytop_e = (int)(short)(g1 & 0xffff);
+                        const int nrow = min(HCHUNK, gady - tau0 + 1);
+                        uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H) + (unsigned)(ytop_e + tau0), (unsigned)wpr);
+#pragma unroll
+                        for (int i = 0; i < HCHUNK; ++i) {
+                            if (i < nrow) {
+                                const int h0 = min(q - 1, gdx);
+                                const int xs = gup ? gx0 - h0 : gx0 + lo, xe = gup ? gx0 - lo : gx0 + h0;
+                                const int s0 = max(xs, X0), s1 = min(xe, X0 + TWp - 1);
+                                if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
+                            }
+                            lo = q;
+                            rem += gib;
+                            const bool carry = rem >= D;
+                            rem -= carry ? D : 0;
+                            q += gia + (carry ? 1 : 0);
+                            rowp += wpr;
+                        }
                     }
                 }
             }
@@ -1433,7 +1566,7 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
     }
     __syncthreads();
     ScanState st;
-    scan_init(st, a, c, cam, wave, X0, TWp);
+    scan_init(st, a, c, cam, lane, wave, X0, TWp);
     for (;;) {
         bool acc;
         uint32_t key;
@@ -1523,6 +1656,15 @@ TDS_EXPORT int tds_raster_set_strip_width(int tw) {
 TDS_EXPORT int tds_raster_set_bits_waves(int n) {
     TDS_CHECK_ARG(n == 4 || n == 8, "waves per workgroup must be 4 or 8");
     g_bits_waves = n;
+    return TDS_OK;
+}
+
+// profiling hook (not part of include/tdship.h): read and reset the work counters of the bit-plane kernel (debug flag 128)
+TDS_EXPORT int tds_raster_get_stats(unsigned long long *out16) {
+    TDS_CHECK_ARG(out16, "tds_raster_get_stats: null output");
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stats), sizeof(zero)) != hipSuccess) { tds::set_error("tds_raster_get_stats: copy failed"); return TDS_EHIP; }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), zero, sizeof(zero)) != hipSuccess) { tds::set_error("tds_raster_get_stats: reset failed"); return TDS_EHIP; }
     return TDS_OK;
 }
 

@@ -46,9 +46,11 @@ constexpr int WAVE = 64;
 struct GridEntry {          // 32 bytes, one per (cell, face whose bounding box touches the cell)
     float x0, y0, x1, y1, x2, y2;   // world coordinates of the three vertices
     uint32_t key;                   // rank << 24 | 0x00RRGGBB  (0 when the map carries no rendering data)
-    uint16_t ddx;                   // this cell minus the cell of the face's bounding-box minimum (owner rule), x
-    uint16_t ddy;                   // same for y in bits 0..12; bits 13..15: outline edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) is also
-                                    // an edge of an earlier face with the same key (identical end points) -- see raster.hip
+    uint32_t own;                   // owner rule of the rasteriser's grid scan (raster.hip: scan_step) + outline flags:
+                                    //   bits 0..12 / 13..25: first / last grid column of the face's bounding box;
+                                    //   bit 26: this cell is not the first column of the box; bit 27: not its first row;
+                                    //   bits 29..31: outline edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) is also an edge of an earlier
+                                    //   face with the same key (identical end points)
 };
 
 struct MapView {
