@@ -1225,9 +1225,12 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
         const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
         r = face_rows(px, py, H, W, X0, TWp);
         if (r.nrows > 0) {
-            int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
-            a = make_chain(px, py, r.imin, i1, i2);
-            b = make_chain(px, py, r.imin, i2, i1);
+            // vertices rotated so that the first top vertex comes first (selects: a dynamically indexed array would live in scratch)
+            const int im = r.imin;
+            const int rx[3] = {im == 0 ? px[0] : (im == 1 ? px[1] : px[2]), im == 0 ? px[1] : (im == 1 ? px[2] : px[0]), im == 0 ? px[2] : (im == 1 ? px[0] : px[1])};
+            const int ry[3] = {im == 0 ? py[0] : (im == 1 ? py[1] : py[2]), im == 0 ? py[1] : (im == 1 ? py[2] : py[0]), im == 0 ? py[2] : (im == 1 ? py[0] : py[1])};
+            a = make_chain(rx, ry, 0, 1, 2);
+            b = make_chain(rx, ry, 0, 2, 1);
         }
     }
     TDS_STAT(w, 0, 1); TDS_STAT(w, 1, n);
@@ -1392,12 +1395,12 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
     wave_sync();
 }
 
-__device__ __forceinline__ void drain_bits(BitCtx &w, const KeyTable &kt, bool acc, uint32_t key, unsigned edges, const int (&px)[3],
+__device__ __forceinline__ void drain_bits(BitCtx &w, const uint32_t *keys, int K, bool acc, uint32_t key, unsigned edges, const int (&px)[3],
                                            const int (&py)[3], bool more) {
     // plane of the key = its position in the ascending table
     int k = 0;
-#pragma unroll
-    for (int i = 0; i < MAX_KEYS; ++i) k += (i < kt.n && kt.key[i] < key) ? 1 : 0;
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) k += (keys[i] < key) ? 1 : 0;             // keys: ascending table in LDS (broadcast reads)
     bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
     if (__builtin_expect(__ballot(big) != 0, 0)) {
         if (big) fill_generic_bits(w.planes + (size_t)k * w.H * w.wpr, w.H, w.W, w.X0, w.TWp, w.wpr, px[0], py[0], px[1], py[1], px[2], py[2]);
@@ -1539,14 +1542,17 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
     uint32_t *planes = smem;
     E *tab = (E *)(smem + ((plane_dw + 3) & ~3));                     // [3][P] output values of an index pair
     for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
+    uint32_t *lkeys = (uint32_t *)tab + pair_tab_dw<NB, OutT>();          // [16] ascending key table
+    if (tid < 16) {
+        uint32_t kv = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kv = (tid == i) ? kt.key[i] : kv;     // kt lives in SGPRs: no dynamic indexing
+        lkeys[tid] = kv;
+    }
+    __syncthreads();
     for (int e = tid; e < 3 * P; e += BBLOCK) {
         const int ch = e / P, pr = e - ch * P, ilo = pr & ((1 << NB) - 1), ihi = pr >> NB;
-        uint32_t klo = 0, khi = 0;
-#pragma unroll
-        for (int i = 0; i < MAX_KEYS; ++i) {                         // kt lives in SGPRs: no dynamic indexing
-            klo = (i < K && ilo == i + 1) ? kt.key[i] : klo;
-            khi = (i < K && ihi == i + 1) ? kt.key[i] : khi;
-        }
+        const uint32_t klo = (ilo >= 1 && ilo <= K) ? lkeys[ilo - 1] : 0u, khi = (ihi >= 1 && ihi <= K) ? lkeys[ihi - 1] : 0u;
         const int sh = 16 - 8 * ch;
         const uint32_t vlo = (klo >> sh) & 255u, vhi = (khi >> sh) & 255u;
         if constexpr (sizeof(OutT) == 4) tab[e] = make_float2((float)vlo, (float)vhi);
@@ -1554,7 +1560,7 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
     }
     BitCtx w;
     w.planes = planes;
-    w.q = (uint32_t *)tab + pair_tab_dw<NB, OutT>() + wave * BITS_WAVE_LDS_DW;
+    w.q = lkeys + 16 + wave * BITS_WAVE_LDS_DW;
     w.slots = w.q + Q_DW;
     w.slots[lane] = 0;
     w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug; w.gen = 0;
@@ -1573,7 +1579,7 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
         int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
         unsigned edges;
         const bool more = scan_step<BWAVES>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
-        drain_bits(w, kt, acc, key, edges, px, py, more);
+        drain_bits(w, lkeys, K, acc, key, edges, px, py, more);
         if (!more) break;
     }
     __syncthreads();
@@ -1585,7 +1591,7 @@ inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) 
     size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
     size_t P = (size_t)1 << (2 * bits_index_bits(K));
     size_t tab_dw = 3 * P * (out_mode == TDS_OUT_F32 ? 2 : 1);
-    return (plane_dw + tab_dw + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
+    return (plane_dw + tab_dw + 16 + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
 }
 int g_bits_waves = 4;
 
