@@ -162,6 +162,18 @@ int tds_raster_scene(const tds_map_t *map, const float *state, const float *agen
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 
+/* Backward of tds_raster_scene with respect to the poses of the actors and cameras.  The CV2 backend of the reference has no
+ * gradient (rendering/cv2.py:27-70 runs in numpy); this one is build-defined (edge sampling of the actors' outlines against the
+ * forward image, DESIGN.md "K3 backward") and plays the role of the pytorch3d backend's soft-blend gradient
+ * (rendering/pytorch3d.py:57-119) for policy learning through the renderer.
+ *   image, grad_out  B x Nc x 3 x H x W float32: the forward output (TDS_OUT_F32) and the incoming gradient
+ *   grad_agent       B x Nc x N x 4   [d/dx, d/dy, d/dsin(psi), d/dcos(psi)] of actor n as seen by camera c (caller sums over c)
+ *   grad_cam         B x Nc x 4       [d/dcx, d/dcy, d/dsin, d/dcos] of the camera, through the actors' outlines only
+ * Both outputs are overwritten. */
+int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
+                             const float *cam_sc, const float *image, const float *grad_out, int64_t B, int64_t Nc, int64_t N,
+                             float scale, int res, float *grad_agent, float *grad_cam, void *stream);
+
 /* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
  *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,
  *   levels: n_levels HOST floats sorted descending containing every z in use (<= 255)
@@ -170,7 +182,7 @@ int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces
                     const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,
                     int out_mode, void *out, void *stream);
 
-/* test / tuning hook: force the LDS strip width of K3 (0 = automatic, else 8, 16, 32 or 64 output rows) */
+/* test / tuning hook: force the LDS strip width of K3 (0 = automatic, else 8 .. 128 output rows) */
 int tds_raster_set_strip_width(int tw);
 
 #ifdef __cplusplus

@@ -370,6 +370,47 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     return out
 
 
+class _RasterScene(torch.autograd.Function):
+    """Differentiable wrapper of the fused scene rasteriser.  Forward: tds_raster_scene (CV2 pixel semantics).  Backward:
+    tds_raster_scene_bwd_f32, the build-defined edge-sampling gradient with respect to actor position / heading and camera position /
+    heading (DESIGN.md "K3 backward"); the reference's CV2 backend has none (rendering/cv2.py:27-70)."""
+
+    @staticmethod
+    def forward(ctx, state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, fov, res, key_table):
+        out = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table)
+        ctx.save_for_backward(state, agent_sc, cam_xy, cam_sc, tmpl, mask, out)
+        ctx.fov, ctx.res = fov, res
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        state, agent_sc, cam_xy, cam_sc, tmpl, mask, out = ctx.saved_tensors
+        B, Nc = cam_xy.shape[:2]
+        N = state.shape[1]
+        dev = cam_xy.device
+        gout = _c(gout)
+        g_agent = torch.empty((B, Nc, max(N, 1), 4), dtype=f32, device=dev)
+        g_cam = torch.empty((B, Nc, 4), dtype=f32, device=dev)
+        m8 = mask.contiguous().view(u8) if mask.dtype == torch.bool else _c(mask, u8)
+        p = lambda t, d, nme: nat.dev_ptr(_c(t, d), d, nme) if N > 0 else None
+        nat.call('tds_raster_scene_bwd_f32', dev, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
+                 None if N == 0 else nat.dev_ptr(m8, u8, 'mask'), nat.dev_ptr(_c(cam_xy), f32, 'cam_xy'), nat.dev_ptr(_c(cam_sc), f32, 'cam_sc'),
+                 nat.dev_ptr(out, f32, 'image'), nat.dev_ptr(gout, f32, 'grad_out'), B, Nc, N, float(2.0 / ctx.fov), int(ctx.res),
+                 nat.dev_ptr(g_agent, f32, 'grad_agent'), nat.dev_ptr(g_cam, f32, 'grad_cam'), nat.stream_ptr(dev))
+        ga = g_agent.sum(dim=1) if N > 0 else None                   # over cameras: (B, N, 4)
+        g_state = g_sc = None
+        if N > 0:
+            g_state = torch.zeros_like(state)
+            g_state[..., :2] = ga[..., :2]
+            g_sc = ga[..., 2:].contiguous()
+        return g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), None, None, None, None, None, None, None
+
+
+def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None):
+    """raster_scene with a backward pass (float32 output only)"""
+    return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, float(fov), int(res), key_table)
+
+
 def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32):
     """Generic render_rgb_mesh: verts (n,V,3), attrs (n,V,3), faces (n,F,3) -> (n,3,res,res)"""
     n = cam_xy.shape[0]

@@ -1,0 +1,160 @@
+// K3 backward: gradient of the rendered bird's-eye view with respect to the poses of the actors and of the cameras.
+//
+// The reference's CV2 backend has no gradient (numpy; rendering/cv2.py:27-70) and its differentiable backends (pytorch3d soft
+// blend, rendering/pytorch3d.py:57-119) are not runnable here, so this backward is BUILD-DEFINED and documented in
+// the rendered image is piecewise constant, and the derivative of a pixel-integrated loss  L = sum_p f(p) I(p)  with
+// respect to a parameter that moves a polygon is the boundary integral (Reynolds transport; "edge sampling")
+//
+//      dL/dtheta = integral over the polygon's boundary of  f(s) (I_in(s) - I_out(s)) (n(s) . ds/dtheta) dl
+//
+// with n the outward normal.  The kernel evaluates it for the outlines of the actors (body rectangle, direction triangle;
+// mesh.py:911-996) as drawn into each camera: samples one pixel apart along every edge, I_in / I_out read from the FORWARD image
+// just inside / just outside the drawn edge, f = the incoming gradient averaged over the same two pixels.  Occlusion needs no special
+// case: where another actor covers the edge both sides show the same colour and the term vanishes.
+// Gradients produced: actor position (x, y) and heading (through [sin, cos], the form the forward consumes) per (camera, actor) --
+// the host sums over cameras -- and camera position / heading through the actors' outlines.  NOT produced: the part of the camera
+// gradient that comes from the static map moving under the camera, and gradients with respect to actor sizes (templates).
+#include "tds_common.h"
+
+namespace {
+
+constexpr int BW_BLOCK = 256;
+constexpr int LANES_PER_AGENT = 8;          // 4 body edges + 3 direction-triangle edges (+1 idle)
+// Where the colours on the two sides of an edge are read.  The forward draws the polygon through the TRUNCATED vertices with OpenCV's
+// rules (fill + outline): in continuous pixel coordinates that is the polygon through the centres of the vertex pixels, grown by about
+// half a pixel.  Samples therefore run along the edge between the vertex-pixel centres; the inner tap sits 0.25 px inside it, the outer
+// tap 1.25 px outside (beyond the grown border, 0.5 .. 0.71 px).
+constexpr float SIDE_IN = 0.25f, SIDE_OUT = 1.25f;
+
+struct BwdArgs {
+    const float4 *state;        // B x N
+    const float2 *agent_sc;     // B x N   [sin, cos]
+    const float2 *tmpl;         // B x N x 7
+    const uint8_t *mask;        // B x Nc x N
+    const float2 *cam_xy, *cam_sc;   // B x Nc
+    const float *image;         // B x Nc x 3 x res x res   (forward output)
+    const float *grad_out;      // same shape
+    float *grad_agent;          // B x Nc x N x 4   [d/dx, d/dy, d/dsin, d/dcos]
+    float *grad_cam;            // B x Nc x 4       [d/dcx, d/dcy, d/dsin, d/dcos]
+    int N, Nc, res;
+    float scale;
+};
+
+__global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
+    __shared__ float cam_acc[4];
+    const int64_t img = blockIdx.x;
+    const int64_t b = img / a.Nc;
+    const int tid = threadIdx.x, sub = tid & (LANES_PER_AGENT - 1);
+    const int res = a.res;
+    const float k = a.scale * (float)res * 0.5f, half = (float)res * 0.5f;
+    const float2 cxy = a.cam_xy[img], csc = a.cam_sc[img];
+    const float cs = csc.x, cc = csc.y;
+    const int64_t plane = (int64_t)res * res;
+    const float *I = a.image + img * 3 * plane, *G = a.grad_out + img * 3 * plane;
+    if (tid < 4) cam_acc[tid] = 0.0f;
+    __syncthreads();
+    float gcam[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float view_r = 1.05f * 1.41421356f / a.scale;
+    for (int j0 = 0; j0 < a.N; j0 += BW_BLOCK / LANES_PER_AGENT) {
+        const int j = j0 + tid / LANES_PER_AGENT;
+        float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (j < a.N && sub < 7 && a.mask[img * a.N + j] != 0) {
+            const int64_t ia = b * a.N + j;
+            const float4 s = a.state[ia];
+            const float2 sc = a.agent_sc[ia];
+            const float2 t0 = a.tmpl[ia * 7];
+            const float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y) + 2.0f / a.scale;
+            const float ddx = s.x - cxy.x, ddy = s.y - cxy.y;
+            if (ddx * ddx + ddy * ddy <= reach * reach) {
+                // edge end points (template space) and the centroid of their polygon
+                const int ea = sub < 4 ? sub : sub, eb = sub < 4 ? ((sub + 1) & 3) : (sub == 6 ? 4 : sub + 1);
+                const float2 ta = a.tmpl[ia * 7 + ea], tb = a.tmpl[ia * 7 + eb];
+                float2 ctr;
+                if (sub < 4) {
+                    const float2 q1 = a.tmpl[ia * 7 + 1], q2 = a.tmpl[ia * 7 + 2], q3 = a.tmpl[ia * 7 + 3];
+                    ctr = make_float2(0.25f * (t0.x + q1.x + q2.x + q3.x), 0.25f * (t0.y + q1.y + q2.y + q3.y));
+                } else {
+                    const float2 q4 = a.tmpl[ia * 7 + 4], q5 = a.tmpl[ia * 7 + 5], q6 = a.tmpl[ia * 7 + 6];
+                    ctr = make_float2((q4.x + q5.x + q6.x) / 3.0f, (q4.y + q5.y + q6.y) / 3.0f);
+                }
+                // template -> world (relative to the camera) -> continuous pixel coordinates:  p = -k Rc (w - cam) + res/2
+                auto to_rel = [&](float2 t) { return make_float2(sc.y * t.x - sc.x * t.y + s.x - cxy.x, sc.x * t.x + sc.y * t.y + s.y - cxy.y); };
+                auto to_pix = [&](float2 v) { return make_float2(-k * (cc * v.x + cs * v.y) + half, -k * (-cs * v.x + cc * v.y) + half); };
+                const float2 va = to_rel(ta), vb = to_rel(tb), pc = to_pix(to_rel(ctr));
+                float2 pa = to_pix(va), pb = to_pix(vb);
+                pa = make_float2(floorf(pa.x) + 0.5f, floorf(pa.y) + 0.5f);       // centres of the vertex pixels
+                pb = make_float2(floorf(pb.x) + 0.5f, floorf(pb.y) + 0.5f);
+                const float ex = pb.x - pa.x, ey = pb.y - pa.y, len = sqrtf(ex * ex + ey * ey);
+                if (len > 1e-6f && len < 1e5f) {
+                    float nx = ey / len, ny = -ex / len;
+                    if (nx * (0.5f * (pa.x + pb.x) - pc.x) + ny * (0.5f * (pa.y + pb.y) - pc.y) < 0.0f) { nx = -nx; ny = -ny; }
+                    const int ns = max(1, min(4096, (int)ceilf(len)));
+                    const float dl = len / (float)ns;
+                    float A0 = 0.0f, A1 = 0.0f;
+                    for (int si = 0; si < ns; ++si) {
+                        const float u = ((float)si + 0.5f) / (float)ns;
+                        const float px = pa.x + u * ex, py = pa.y + u * ey;
+                        const float xi = floorf(px - SIDE_IN * nx), yi = floorf(py - SIDE_IN * ny), xo = floorf(px + SIDE_OUT * nx), yo = floorf(py + SIDE_OUT * ny);
+                        if (xi < 0.0f || yi < 0.0f || xo < 0.0f || yo < 0.0f || xi >= (float)res || yi >= (float)res || xo >= (float)res || yo >= (float)res)
+                            continue;
+                        const int64_t oi = (int64_t)xi * res + (int64_t)yi, oo = (int64_t)xo * res + (int64_t)yo;      // out[ch][x][y]
+                        float D = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            D += 0.5f * (G[ch * plane + oi] + G[ch * plane + oo]) * (I[ch * plane + oi] - I[ch * plane + oo]);
+                        const float wgt = D * dl;
+                        A0 += wgt * (1.0f - u); A1 += wgt * u;
+                    }
+                    // n . dp/dtheta for the parameters, with M = -k Rc (a similarity): M q = -k (cc qx + cs qy, -cs qx + cc qy)
+                    auto nM = [&](float qx, float qy) { return -k * (nx * (cc * qx + cs * qy) + ny * (-cs * qx + cc * qy)); };
+                    const float At = A0 + A1;
+                    const float Tx = A0 * ta.x + A1 * tb.x, Ty = A0 * ta.y + A1 * tb.y;       // weighted template point
+                    const float Vx = A0 * va.x + A1 * vb.x, Vy = A0 * va.y + A1 * vb.y;       // weighted camera-relative point
+                    g[0] = At * nM(1.0f, 0.0f);
+                    g[1] = At * nM(0.0f, 1.0f);
+                    g[2] = nM(-Ty, Tx);                 // d w / d sin_j = (-ty, tx)
+                    g[3] = nM(Tx, Ty);                  // d w / d cos_j = ( tx, ty)
+                    gcam[0] -= g[0]; gcam[1] -= g[1];
+                    gcam[2] += -k * (nx * Vy - ny * Vx);        // d p / d sin_c = -k ( vy, -vx)
+                    gcam[3] += -k * (nx * Vx + ny * Vy);        // d p / d cos_c = -k ( vx,  vy)
+                }
+            }
+        }
+        // sum the edges of an agent (8 consecutive lanes) and store; agents out of sight store zeros
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            g[q] += __shfl_xor(g[q], 1); g[q] += __shfl_xor(g[q], 2); g[q] += __shfl_xor(g[q], 4);
+        }
+        if (j < a.N && sub == 0) *(float4 *)(a.grad_agent + (img * a.N + j) * 4) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = gcam[q];
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if ((tid & 63) == 0) atomicAdd(&cam_acc[q], v);
+    }
+    __syncthreads();
+    if (tid < 4) a.grad_cam[img * 4 + tid] = cam_acc[tid];
+}
+
+}  // namespace
+
+TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
+                                        const float *cam_sc, const float *image, const float *grad_out, int64_t B, int64_t Nc, int64_t N,
+                                        float scale, int res, float *grad_agent, float *grad_cam, void *stream) {
+    TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene_bwd_f32: bad sizes");
+    TDS_CHECK_ARG(res > 0 && res <= 4096, "tds_raster_scene_bwd_f32: resolution out of range");
+    TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene_bwd_f32: scale must be positive");
+    const int64_t n_img = B * Nc;
+    if (n_img == 0) return TDS_OK;
+    TDS_CHECK_ARG(n_img < (1ll << 31), "tds_raster_scene_bwd_f32: too many cameras");
+    TDS_CHECK_ARG(cam_xy && cam_sc && image && grad_out && grad_cam, "tds_raster_scene_bwd_f32: null array");
+    TDS_CHECK_ARG(N == 0 || (state && agent_sc && tmpl && mask && grad_agent), "tds_raster_scene_bwd_f32: null agent array");
+    BwdArgs a;
+    a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl; a.mask = mask;
+    a.cam_xy = (const float2 *)cam_xy; a.cam_sc = (const float2 *)cam_sc; a.image = image; a.grad_out = grad_out;
+    a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
+    hipLaunchKernelGGL(raster_scene_bwd_kernel, dim3((unsigned)n_img), dim3(BW_BLOCK), 0, (hipStream_t)stream, a);
+    TDS_LAUNCH_CHECK("raster_scene_bwd_kernel");
+    return TDS_OK;
+}

@@ -70,11 +70,16 @@ class HipRenderer(BirdviewRenderer):
 
     def render_scene(self, static_map: _ops.StaticMap, state: Tensor, agent_sc: Tensor, tmpl: Tensor, actor_key: Tensor, mask: Tensor,
                      camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None,
-                     key_table=None) -> Tensor:
-        """-> B x Nc x 3 x H x W"""
+                     key_table=None, differentiable: bool = False) -> Tensor:
+        """-> B x Nc x 3 x H x W.  `differentiable`: attach the K3 backward (gradients w.r.t. state[..., :2], agent_sc, camera_xy,
+        camera_sc; float32 output only)."""
         res = self.res if res is None else res
         if res.width != res.height:
             raise RuntimeError('only square resolutions are supported')
         fov = fov if fov is not None else 2.0 / self.scale
+        if differentiable:
+            if self.out_dtype != torch.float32:
+                raise RuntimeError('the differentiable path renders float32 images')
+            return _ops.raster_scene_diff(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, key_table=key_table)
         return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype,
                                  key_table=key_table)

@@ -484,7 +484,12 @@ class Simulator:
             mask = mask.logical_and(rendering_mask.to(torch.bool))
         if isinstance(self.renderer, HipRenderer):
             scene = self._scene()
-            state = self.get_all_agent_state().detach()
+            state = self.get_all_agent_state()
+            # gradients through the rasteriser (K3 backward, build-defined) only when someone asks for them
+            diff = torch.is_grad_enabled() and (state.requires_grad or camera_xy.requires_grad or camera_sc.requires_grad) and \
+                self.renderer.out_dtype == torch.float32
+            if not diff:
+                state, camera_xy, camera_sc = state.detach(), camera_xy.detach(), camera_sc.detach()
             agent_sc = _ops.heading_sc(state[..., 2])
             out = []
             for (smap, b), keys, ktab in zip(scene['maps'], scene['keys'], scene['key_tables']):
@@ -493,7 +498,7 @@ class Simulator:
                 if custom_agent_colors is not None:
                     raise NotImplementedError('custom_agent_colors: per-camera colours are not wired into the fused path yet')
                 out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], scene['tmpl'][sl], k, mask[sl].contiguous(),
-                                                      camera_xy[sl].detach(), camera_sc[sl].detach(), res=res, fov=fov, key_table=ktab))
+                                                      camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
         # any other BirdviewRenderer: the reference's generic dataflow (explicit per-camera mesh)
         rgb_mesh = self.birdview_mesh_generator.generate(n_cam, agent_state=self.get_all_agent_state()[:, None].expand(-1, n_cam, -1, -1),
