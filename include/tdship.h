@@ -154,11 +154,14 @@ int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, const float *l
  *
  * actor_keys: optional HOST array of the distinct values occurring in `actor_key` (one per agent type and part).  When it is
  * given and the scene (map + actors) uses at most 16 distinct keys, the bit-plane kernel is used: one bit per pixel and key in
- * LDS, a whole camera per workgroup, spans painted with one ds_or.  Same pixels as the other paths. */
+ * LDS, a whole camera per workgroup, spans painted with one ds_or.  Same pixels as the other paths.
+ *
+ * actor_key_per_camera != 0: `actor_key` is B x Nc x N x 2 -- every camera sees its own colours, the fused form of generate()'s
+ * custom_agent_colors (mesh.py:1092-1099; only the body faces take the custom colour there). */
 int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                      const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc,
                      int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                     int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, void *stream);
+                     int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 

@@ -130,3 +130,31 @@ def test_step_render_loop_and_single_agent_rendering():
     solo = sim.render_egocentric(res=Resolution(64, 64))
     veh = torch.tensor([32.0, 74.0, 135.0], device=DEV).view(1, 1, 3, 1, 1)
     assert ((solo == veh).all(2).flatten(2).sum(-1) <= (img == veh).all(2).flatten(2).sum(-1)).all()
+
+
+def test_custom_agent_colors_fused_equals_reference_dataflow(oracle):
+    """custom_agent_colors (simulator.py:979-984 -> mesh.py:1092-1099): the fused path (per-camera actor keys) paints the same
+    pixels as the reference's dataflow -- explicit per-camera RGB mesh from generate(), then render_frame -- which is checked
+    against the oracle's render_rgb_mesh."""
+    from torchdrivesim_amd.utils import Resolution
+    g = load_golden('g45_mesh_preraster.npz')
+    st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']
+    B, A = st.shape[:2]
+    road, t = town_mesh(B)
+    sim = make_sim(st, sz, pr, road)
+    gen = np.random.default_rng(4)
+    palette = np.array([[255, 0, 0], [0, 255, 0], [32, 74, 135], [250, 250, 10], [1, 2, 3]], np.float32) / 255.0
+    cc = torch.from_numpy(palette[gen.integers(0, len(palette), (B, A, A))]).to(DEV)
+    res = Resolution(96, 96)
+    img = sim.render_egocentric(res=res, fov=35.0, custom_agent_colors=cc)
+    plain = sim.render_egocentric(res=res, fov=35.0)
+    assert (img != plain).any()
+    s = sim.get_state()
+    mask = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))).to(DEV)
+    rgb = sim.birdview_mesh_generator.generate(A, agent_state=s[:, None].expand(-1, A, -1, -1), present_mask=mask, custom_agent_colors=cc)
+    cam_sc = torch.stack([torch.sin(s[..., 2]), torch.cos(s[..., 2])], -1)
+    img2 = sim.renderer.render_frame(rgb, s[..., :2], cam_sc, res=res, fov=35.0).reshape(img.shape)
+    np.testing.assert_array_equal(img.cpu().numpy(), img2.cpu().numpy())
+    ref = oracle.render_rgb_mesh(rgb.verts.cpu().numpy(), rgb.attrs.cpu().numpy(), rgb.faces.cpu().numpy().astype(np.int32),
+                                 s[..., :2].reshape(-1, 2).cpu().numpy(), cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / 35.0, 96)     # n x H x W x 3
+    np.testing.assert_array_equal(img.reshape((-1,) + tuple(img.shape[2:])).cpu().numpy(), np.transpose(ref, (0, 3, 1, 2)))

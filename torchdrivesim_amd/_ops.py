@@ -329,8 +329,9 @@ def _raster_workspace(dev, n_img, res):
 raster_events = None
 
 def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None):
-    """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns,
-    mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2) -> (B,Nc,3,res,res) float32 [0,255] or uint8."""
+    """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns -- or (B,Nc,N,2)
+    when every camera sees its own colours (custom_agent_colors) --, mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2)
+    -> (B,Nc,3,res,res) float32 [0,255] or uint8."""
     B, Nc = cam_xy.shape[:2]
     N = state.shape[1]
     dev = cam_xy.device
@@ -338,6 +339,7 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     if N > 0:
         state, agent_sc, tmpl = _c(state), _c(agent_sc), _c(tmpl)
         actor_key = _c(actor_key, i32)
+        assert tuple(actor_key.shape) in ((B, N, 2), (B, Nc, N, 2)), 'actor_key must be (B,N,2) or (B,Nc,N,2)'
         mask = mask.contiguous().view(u8) if mask.dtype == torch.bool else _c(mask, u8)
     assert out_dtype in (torch.float32, torch.uint8)
     if out is None:
@@ -363,7 +365,8 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
              p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
              B, Nc, N, float(2.0 / fov), int(res), mode, nat.dev_ptr(out, out_dtype, 'out'),
              None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(),
-             None if kt is None else ctypes.cast(kt, ctypes.c_void_p), 0 if kt is None else len(key_table), nat.stream_ptr(dev))
+             None if kt is None else ctypes.cast(kt, ctypes.c_void_p), 0 if kt is None else len(key_table),
+             1 if (N > 0 and actor_key.dim() == 4) else 0, nat.stream_ptr(dev))
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         raster_events.append(ev)

@@ -34,9 +34,10 @@ struct SceneArgs {
     const float4 *state;        // B x N
     const float2 *agent_sc;     // B x N   [sin, cos]
     const float2 *tmpl;         // B x N x 7
-    const uint32_t *actor_key;  // B x N x 2
+    const uint32_t *actor_key;  // B x N x 2, or B x Nc x N x 2 when key_per_cam
     const uint8_t *mask;        // B x Nc x N
     int N, Nc;
+    int key_per_cam;            // custom_agent_colors (mesh.py:1092-1099): the actors' keys differ from camera to camera
 };
 
 struct MeshArgs {
@@ -740,7 +741,8 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
                     st.near = !(ddx * ddx + ddy * ddy > reach * reach);  // NaNs are kept
                     if (st.near) {
                         float2 sc = a.agent_sc[ia];
-                        st.kbody = a.actor_key[2 * ia]; st.kdir = a.actor_key[2 * ia + 1];
+                        const int64_t ik = a.key_per_cam ? img * a.N + ag : ia;
+                        st.kbody = a.actor_key[2 * ik]; st.kdir = a.actor_key[2 * ik + 1];
                         // utils.transform :82-96, then mesh.translate(-cameras.xy) cv2.py:29-31
 #define TDS_ACTOR_VERT(K)                                                                                                          \
     { float2 t = a.tmpl[ia * 7 + K];                                                                                               \
@@ -778,7 +780,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
             float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
             float fx[3] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[3] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
             acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
-            key = a.actor_key[2 * b * a.N];
+            key = a.actor_key[2 * (a.key_per_cam ? img * a.N : b * a.N)];
         }
         st.phase = 2;
         return true;
@@ -1728,7 +1730,7 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
 TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                                 const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                 int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, void *stream) {
+                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
     TDS_CHECK_ARG(map, "tds_raster_scene: null map");
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
     TDS_CHECK_ARG(map->n_levels > 0 || map->view.nx == 0, "tds_raster_scene: the map was created without rendering data");
@@ -1743,7 +1745,7 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
     TDS_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "tds_raster_scene: bad workspace");
     SceneArgs a;
     a.map = map->view; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
-    a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc;
+    a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc; a.key_per_cam = actor_key_per_camera ? 1 : 0;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;

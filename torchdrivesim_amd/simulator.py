@@ -496,7 +496,13 @@ class Simulator:
                 sl = slice(None) if b is None else slice(b, b + 1)
                 k = keys[sl]
                 if custom_agent_colors is not None:
-                    raise NotImplementedError('custom_agent_colors: per-camera colours are not wired into the fused path yet')
+                    # generate() paints the four body vertices of agent a with custom_agent_colors[b, c, a] for camera c
+                    # (mesh.py:1092-1099); the direction triangle keeps its colour.  Same rendering level, so only the colour
+                    # bits of the body key change -- per camera.
+                    rgb = _ops.quantise_colors(custom_agent_colors[sl].to(state.device)).to(torch.int32)          # (b,Nc,A,)
+                    kc = k[:, None].expand(-1, n_cam, -1, -1).clone()
+                    kc[..., 0] = (kc[..., 0] & ~0xFFFFFF) | rgb
+                    k, ktab = kc.contiguous(), None
                 out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], scene['tmpl'][sl], k, mask[sl].contiguous(),
                                                       camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
