@@ -939,7 +939,8 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
 // with ds_max on packed keys -- the result does not depend on the order in which faces are processed.
 // =========================================================================================================
 constexpr int MAX_KEYS = 15;              // key indices 1..15 fit 4 bits (0 = background)
-constexpr int BITS_WAVE_LDS_DW = Q_DW + 64;   // per wave: face queue + owner markers
+constexpr int EQCAP = 128;                    // ring of queued outline edges per wave (power of two, >= 2 * 64)
+constexpr int BITS_WAVE_LDS_DW = Q_DW + 64 + 2 * EQCAP;   // per wave: face queue + owner markers + edge ring
 
 struct KeyTable { uint32_t key[16]; int n; };      // ascending = painter order (later wins)
 
@@ -947,8 +948,14 @@ struct BitCtx {
     uint32_t *planes;   // [K][H][wpr]
     uint32_t *q;        // [4][QCAP]: plane index, then the three packed vertices
     uint32_t *slots;    // [64] owner markers of wave_owner()
-    int qlen, lane, H, W, X0, TWp, wpr, debug, gen;
+    uint32_t *eq;       // [2][EQCAP] ring of outline edges waiting to be drawn: end points + plane index (pack_xyk)
+    int qlen, lane, H, W, X0, TWp, wpr, debug, gen, eq_head, eq_count;
 };
+
+// end point of a queued edge: x, y in 15 bits each (|coordinate| < COORD_LIMIT) and two bits of the plane index
+__device__ __forceinline__ uint32_t pack_xyk(int x, int y, uint32_t k2) { return (k2 & 3u) | (((uint32_t)x & 0x7fffu) << 2) | ((uint32_t)y << 17); }
+__device__ __forceinline__ int unpack_xk(uint32_t p) { return (int)(p << 15) >> 17; }
+__device__ __forceinline__ int unpack_yk(uint32_t p) { return (int)p >> 17; }
 
 // bits [s0, s1] (strip-local columns) of one row of one plane
 __device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int s0, int s1) {
@@ -1215,7 +1222,7 @@ constexpr int CHUNK = TDS_FCHUNK;     // rows per item: scan conversion
 constexpr int VCHUNK = TDS_VCHUNK;    // rows per item: y-major outline edges (one pixel per row)
 constexpr int HCHUNK = TDS_HCHUNK;    // rows per item: x-major outline edges (one run per row)
 
-__device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
+__device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush) {
     const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0, TWp = w.TWp, wpr = w.wpr;
     wave_sync();
     uint32_t kidx = 0, em = 0, v0 = 0, v1 = 0, v2 = 0;
@@ -1278,22 +1285,36 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
         }
     }
     // ---- outline edges ----
+    // The edges to draw go through a per-wave ring of EQCAP entries (two packed end points + plane index) that lives across
+    // batches: 64 of them are taken at a time, so that the per-edge set-up and the row items below run on full waves.
     if (!(w.debug & 8)) {
-        const int cnt = lane < n ? __popc(em) : 0;
-        const int eincl = wave_scan_add(cnt), eexcl = eincl - cnt;
-        const int etotal = __builtin_amdgcn_readlane(eincl, 63);
-        TDS_STAT(w, 5, etotal); TDS_STAT(w, 6, (etotal + 63) / 64);
-        for (int ebase = 0; ebase < etotal; ebase += 64) {
-            // lane -> (face, edge): the j-th edge of the face's mask
-            const int f = wave_owner(w.slots, w.gen, lane, cnt > 0, eexcl, eincl, ebase);
-            const int emf = __shfl((int)em, f), j = ebase + lane - __shfl(eexcl, f);
-            const bool valid = ebase + lane < etotal;
-            const int first = (emf & 1) ? 0 : ((emf & 2) ? 1 : 2), second = ((emf & 3) == 3) ? 1 : 2;
-            const int l = j == 0 ? first : (j == 1 ? second : 2);
-            const int fa = valid ? f : 0;
-            const uint32_t pa = w.q[(l == 0 ? 3 : l) * QCAP + fa], pb = w.q[(1 + l) * QCAP + fa];   // vertex (l == 0 ? 2 : l - 1), vertex l
-            const int ek = (int)(w.q[fa] & 15u);
-            int x1 = unpack_x(pa), y1 = unpack_y(pa), x2 = unpack_x(pb), y2 = unpack_y(pb);
+        TDS_STAT(w, 5, __popcll(__ballot(lane < n && (em & 1))) + __popcll(__ballot(lane < n && (em & 2))) + __popcll(__ballot(lane < n && (em & 4))));
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+            if (l < 3) {
+                // push edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) of every face that has to draw it
+                const bool has = lane < n && ((em >> l) & 1u);
+                const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
+                const unsigned long long bm = __ballot(has);
+                if (has) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                    const int slot = (w.eq_head + w.eq_count + rank) & (EQCAP - 1);
+                    w.eq[slot] = pack_xyk(unpack_x(pa), unpack_y(pa), kidx & 3u);
+                    w.eq[EQCAP + slot] = pack_xyk(unpack_x(pb), unpack_y(pb), kidx >> 2);
+                }
+                w.eq_count += __popcll(bm);
+                wave_sync();
+            }
+            while (w.eq_count >= 64 || (l == 3 && flush && w.eq_count > 0)) {
+            const int take = min(w.eq_count, 64);
+            const bool valid = lane < take;
+            const int slot = (w.eq_head + lane) & (EQCAP - 1);
+            const uint32_t pa = valid ? w.eq[slot] : 0u, pb = valid ? w.eq[EQCAP + slot] : 0u;
+            const int ek = (int)((pa & 3u) | ((pb & 3u) << 2));
+            w.eq_head = (w.eq_head + take) & (EQCAP - 1);
+            w.eq_count -= take;
+            TDS_STAT(w, 6, 1);
+            int x1 = unpack_xk(pa), y1 = unpack_yk(pa), x2 = unpack_xk(pb), y2 = unpack_yk(pb);
             bool ok = valid;
             const bool outside = (unsigned)x1 >= (unsigned)W || (unsigned)x2 >= (unsigned)W || (unsigned)y1 >= (unsigned)H || (unsigned)y2 >= (unsigned)H;
             if (__ballot(ok && outside) != 0) {
@@ -1392,6 +1413,7 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n) {
                     }
                 }
             }
+            }       // while: 64 queued edges at a time
         }
     }
     wave_sync();
@@ -1425,8 +1447,8 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, const uint32_t *keys, int 
             w.qlen += __popcll(taken);
             pending &= ~taken;
         }
-        if (w.qlen == QCAP || (!more && pending == 0 && w.qlen > 0)) {
-            process_batch_bits(w, w.qlen);
+        if (w.qlen == QCAP || (!more && pending == 0)) {          // the last call also empties the edge queue
+            process_batch_bits(w, w.qlen, !more && pending == 0);
             w.qlen = 0;
         }
         if (pending == 0) break;
@@ -1564,6 +1586,8 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
     w.planes = planes;
     w.q = lkeys + 16 + wave * BITS_WAVE_LDS_DW;
     w.slots = w.q + Q_DW;
+    w.eq = w.slots + 64;
+    w.eq_head = 0; w.eq_count = 0;
     w.slots[lane] = 0;
     w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug; w.gen = 0;
     Camera cam;
