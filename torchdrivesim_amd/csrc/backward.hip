@@ -310,7 +310,8 @@ __device__ __forceinline__ float tri_d2_grad(float px, float py, const GridEntry
     return dist;
 }
 
-__device__ float nearest_face_d2_grad(const MapView &m, float px, float py, float &gx, float &gy) {
+// `stop`: below it the caller's gradient is zero (F.threshold), so the walk may end early (see nearest_face_d2 in map.hip)
+__device__ float nearest_face_d2_grad(const MapView &m, float px, float py, float &gx, float &gy, float stop) {
     float best = __builtin_inff();
     gx = gy = 0.0f;
     if (m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return best;
@@ -321,7 +322,7 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
         float ddx = fmaxf(fmaxf(bx0 - px, px - (bx0 + m.cell)), 0.0f), ddy = fmaxf(fmaxf(by0 - py, py - (by0 + m.cell)), 0.0f);
         if ((ddx * ddx + ddy * ddy) * 0.998f - 1e-3f >= best) return;
         int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
-        for (int i = s; i < e && best > 0.0f; ++i) {
+        for (int i = s; i < e && best > stop; ++i) {
             GridEntry ge = m.entries[i];
             float tgx, tgy;
             float d = tri_d2_grad(px, py, ge, tgx, tgy);
@@ -339,7 +340,7 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
                 if (k > 0 && cx + k >= 0 && cx + k < m.nx) visit(cx + k, y);
             }
         }
-        if (best == 0.0f) break;
+        if (best <= stop) break;
         float bound = (float)k * m.cell * 0.999f;
         if (best <= bound * bound) break;
         if (cx - k <= 0 && cx + k >= m.nx - 1 && cy - k <= 0 && cy + k >= m.ny - 1) break;
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(GBLOCK) offroad_bwd_kernel(MapView m, const fl
             float x4 = sx * lw.x, y4 = sy * lw.y;
             float px = (x4 * scv.y + y4 * (-scv.x)) + s.x, py = (x4 * scv.x + y4 * scv.y) + s.y;
             float dgx, dgy;
-            float d = nearest_face_d2_grad(m, px, py, dgx, dgy);
+            float d = nearest_face_d2_grad(m, px, py, dgx, dgy, fmaxf(threshold, 0.0f));
             if (d == d && !__builtin_isinf(d) && d > threshold) {
                 float ggx = go * dgx, ggy = go * dgy;
                 gx = ggx; gy = ggy;

@@ -130,6 +130,13 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
                     entries[(size_t)cursor[(size_t)cy * nx + cx]++] = e;
                 }
         }
+        // Within a cell, large faces first: the nearest-face walk of K2b stops at the first face that contains the query point,
+        // and a random point of a cell is most likely inside one of its large faces.  (No consumer depends on the order.)
+        for (size_t c = 0; c + 1 < cell_start.size(); ++c)
+            std::stable_sort(entries.begin() + cell_start[c], entries.begin() + cell_start[c + 1], [](const GridEntry &a, const GridEntry &b) {
+                auto area2 = [](const GridEntry &g) { return std::fabs((g.x1 - g.x0) * (g.y2 - g.y0) - (g.x2 - g.x0) * (g.y1 - g.y0)); };
+                return area2(a) > area2(b);
+            });
         break;
     }
     if (!any) { nx = ny = 0; cell_start.assign(1, 0); entries.clear(); }
@@ -234,7 +241,9 @@ __device__ __forceinline__ float tri_d2(float px, float py, const GridEntry &e) 
 // min over all faces of tri_d2, found by walking grid rings outwards from the point's cell.  A face is listed in every
 // cell its bounding box touches, so its closest point lies in a listed cell whose box is at least as close as the face:
 // cells whose box is not closer than the best distance so far can be skipped, and the walk stops once a whole ring is.
-__device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, float py) {
+// `stop`: the caller only needs the exact minimum if it exceeds `stop` (F.threshold zeroes everything else), so the walk ends as soon
+// as the running minimum is <= stop.
+__device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, float py, float stop) {
     float best = __builtin_inff();
     if (m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return best;
     // unclamped cell of the point (float -> int conversion saturates, keep it in a sane range first)
@@ -247,7 +256,7 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
         float cd = (ddx * ddx + ddy * ddy) * 0.998f - 1e-3f;
         if (cd >= best) return;
         int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
-        for (int i = s; i < e && best > 0.0f; ++i) {
+        for (int i = s; i < e && best > stop; ++i) {
             GridEntry ge = m.entries[i];
             // the face cannot beat `best` if even its bounding box is farther (same safety shrink as for the cell)
             float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
@@ -271,7 +280,7 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
                 if (k > 0 && cx + k >= 0 && cx + k < m.nx) visit(cx + k, y);
             }
         }
-        if (best == 0.0f) break;
+        if (best <= stop) break;
         float bound = (float)k * m.cell * 0.999f;            // everything unvisited is at least this far away
         if (best <= bound * bound) break;
         if (cx - k <= 0 && cx + k >= m.nx - 1 && cy - k <= 0 && cy + k >= m.ny - 1) break;
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, const float4
         float x4 = sx * lw.x, y4 = sy * lw.y;
         float px = (x4 * scv.y + y4 * (-scv.x)) + s.x;
         float py = (x4 * scv.x + y4 * scv.y) + s.y;
-        float d = nearest_face_d2(m, px, py);
+        float d = nearest_face_d2(m, px, py, fmaxf(threshold, 0.0f));
         d = (d != d) ? 0.0f : d;                                     // nan_to_num :171
         if (__builtin_isinf(d)) d = 3.4028234663852886e38f;
         v = (d > threshold) ? d : 0.0f;                              // F.threshold(d, thr, 0) :172

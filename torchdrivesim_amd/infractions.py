@@ -4,6 +4,7 @@ kernels: oriented-box IoU, 5-disc overlap, and off-road distance to the driving-
 """
 from typing import List, Optional, Union
 
+import os
 import numpy as np
 import torch
 from torch import Tensor
@@ -34,6 +35,11 @@ def box2corners_th(box: Tensor) -> Tensor:
     return _ops.box2corners(box)
 
 
+#: grid cell (metres) of the geometry-only maps built for the off-road query: point location wants cells of about a face's size
+#: (the rasteriser's own maps keep the library default, 8 m, which suits its row scans)
+OFFROAD_CELL_SIZE = float(os.environ.get('TDS_OFFROAD_CELL', 3.0))
+
+
 def _static_maps_for(mesh: BaseMesh, device) -> List:
     """One device map per DISTINCT batch element of the mesh, cached on the mesh object: [(StaticMap, scene indices)]."""
     key = (mesh.verts.data_ptr(), mesh.faces.data_ptr(), tuple(mesh.verts.shape), tuple(mesh.faces.shape), str(device))
@@ -45,9 +51,9 @@ def _static_maps_for(mesh: BaseMesh, device) -> List:
     same = B == 1 or (verts.stride(0) == 0 and faces.stride(0) == 0) or \
         (bool((verts == verts[:1]).all()) and bool((faces == faces[:1]).all()))
     if same:
-        maps = [(_ops.StaticMap(verts[0], faces[0], device=device), None)]
+        maps = [(_ops.StaticMap(verts[0], faces[0], device=device, cell_size=OFFROAD_CELL_SIZE), None)]
     else:
-        maps = [(_ops.StaticMap(verts[b], faces[b], device=device), b) for b in range(B)]
+        maps = [(_ops.StaticMap(verts[b], faces[b], device=device, cell_size=OFFROAD_CELL_SIZE), b) for b in range(B)]
     try:
         object.__setattr__(mesh, '_tds_offroad_maps', (key, maps))
     except Exception:
