@@ -14,6 +14,7 @@
 // Finally the strip is converted and streamed to HBM as a flat, fully coalesced copy (the LDS layout [x][y] IS the
 // output layout out[img][ch][x][y]).  Roofline: HBM write, 3*H*W*4 B per camera (fp32) -- DESIGN.md.
 #include "tds_common.h"
+#include <type_traits>
 
 using tds::GridEntry;
 using tds::MapView;
@@ -1477,6 +1478,7 @@ __device__ inline void write_out_bits(const uint32_t *planes, const typename Pai
     const int cols = min(TWp, W - X0);
     if ((H & 3) == 0) {
         const int quads = H >> 2;
+        const bool full = (cols & 31) == 0;                          // wave-uniform: no partial 32-column word
         for (int item = tid; item < quads * wpr; item += BBLOCK) {
             const int rq = item % quads, xw = item / quads, y0 = rq * 4;
             if (xw * 32 >= cols) continue;
@@ -1503,32 +1505,39 @@ __device__ inline void write_out_bits(const uint32_t *planes, const typename Pai
                 R1[i] = rotl32(i < NB ? s[i % NB][2] : s[i % NB][3], i);
             }
             const int ncol = min(32, cols - xw * 32);
-            OutT *ob = o + (int64_t)(X0 + xw * 32) * H + y0;
+            // byte offsets from the (uniform) image base fit 32 bits: 3 * 4096^2 * 4 B at most
+            const uint32_t off0 = (uint32_t)(((X0 + xw * 32) * H + y0) * (int)sizeof(OutT)), colb = (uint32_t)(H * (int)sizeof(OutT));
+            const char *ob0 = (const char *)o, *ob1 = (const char *)(o + plane_px), *ob2 = (const char *)(o + 2 * plane_px);
+            auto emit = [&](auto check) {
+                constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
-            for (int ph = 0; ph < 8; ++ph) {
-                uint32_t A0 = 0, A1 = 0;
+                for (int ph = 0; ph < 8; ++ph) {
+                    uint32_t A0 = 0, A1 = 0;
 #pragma unroll
-                for (int i = 0; i < 2 * NB; ++i) {
-                    const uint32_t Mx = 0x01010101u << ((ph + i) & 7);      // every 8th column, bit i of its pair index
-                    A0 |= R0[i] & Mx;
-                    A1 |= R1[i] & Mx;
-                }
-                A0 = rotl32(A0, 32 - ph);
-                A1 = rotl32(A1, 32 - ph);
+                    for (int i = 0; i < 2 * NB; ++i) {
+                        const uint32_t Mx = 0x01010101u << ((ph + i) & 7);      // every 8th column, bit i of its pair index
+                        A0 |= R0[i] & Mx;
+                        A1 |= R1[i] & Mx;
+                    }
+                    A0 = rotl32(A0, 32 - ph);
+                    A1 = rotl32(A1, 32 - ph);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int p = ph + 8 * m;
-                    if (p >= ncol) continue;
-                    const uint32_t i01 = (A0 >> (8 * m)) & (uint32_t)(P - 1), i23 = (A1 >> (8 * m)) & (uint32_t)(P - 1);
-                    OutT *op = ob + (int64_t)p * H;
+                    for (int m = 0; m < 4; ++m) {
+                        const int p = ph + 8 * m;
+                        if (CHECK && p >= ncol) continue;
+                        const uint32_t i01 = (A0 >> (8 * m)) & (uint32_t)(P - 1), i23 = (A1 >> (8 * m)) & (uint32_t)(P - 1);
+                        const uint32_t off = off0 + (uint32_t)p * colb;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const E lo = tab[ch * P + i01], hi = tab[ch * P + i23];
-                        if constexpr (sizeof(OutT) == 4) *(float4 *)(op + ch * plane_px) = make_float4(lo.x, lo.y, hi.x, hi.y);
-                        else *(uint32_t *)(op + ch * plane_px) = lo | (hi << 16);
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const E lo = tab[ch * P + i01], hi = tab[ch * P + i23];
+                            char *dst = (char *)(ch == 0 ? ob0 : (ch == 1 ? ob1 : ob2)) + off;
+                            if constexpr (sizeof(OutT) == 4) *(float4 *)dst = make_float4(lo.x, lo.y, hi.x, hi.y);
+                            else *(uint32_t *)dst = lo | (hi << 16);
+                        }
                     }
                 }
-            }
+            };
+            if (full) emit(std::false_type{}); else emit(std::true_type{});
         }
         return;
     }
@@ -1582,6 +1591,8 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
         if constexpr (sizeof(OutT) == 4) tab[e] = make_float2((float)vlo, (float)vhi);
         else tab[e] = vlo | (vhi << 8);
     }
+    // waves that rasterise take precedence over the waves of other workgroups that are streaming out (measured: -2 % kernel time)
+    __builtin_amdgcn_s_setprio(1);
     BitCtx w;
     w.planes = planes;
     w.q = lkeys + 16 + wave * BITS_WAVE_LDS_DW;
@@ -1609,6 +1620,7 @@ __global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(Scene
         if (!more) break;
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     if (!(c.debug & 4)) write_out_bits<BBLOCK, NB, OutT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
 }
 
