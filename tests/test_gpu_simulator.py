@@ -158,3 +158,29 @@ def test_custom_agent_colors_fused_equals_reference_dataflow(oracle):
     ref = oracle.render_rgb_mesh(rgb.verts.cpu().numpy(), rgb.attrs.cpu().numpy(), rgb.faces.cpu().numpy().astype(np.int32),
                                  s[..., :2].reshape(-1, 2).cpu().numpy(), cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / 35.0, 96)     # n x H x W x 3
     np.testing.assert_array_equal(img.reshape((-1,) + tuple(img.shape[2:])).cpu().numpy(), np.transpose(ref, (0, 3, 1, 2)))
+
+
+def test_traffic_light_violations_match_reference():
+    """TrafficLightControl.compute_violation on K2a's box-intersection kernel and Simulator.compute_traffic_lights_violations
+    against the reference's outputs (g8_traffic.npz), incl. stepping the replayed light states"""
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    from torchdrivesim_amd.traffic_controls import TrafficLightControl
+    g = load_golden('g8_traffic.npz')
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    ctl = TrafficLightControl(d(g['pos']), replay_states=d(g['replay']), mask=d(g['mask']))
+    boxes = d(g['boxes'])
+    for t in range(7):
+        ctl.step(t)
+        np.testing.assert_array_equal(ctl.compute_violation(boxes).cpu().numpy(), g[f'violation_{t}'])
+    # through the Simulator: state [x, y, psi, v] + sizes; stepping with zero speed keeps the boxes where they are
+    B, A = boxes.shape[:2]
+    state = np.concatenate([g['boxes'][..., :2], g['boxes'][..., 4:5], np.zeros((B, A, 1), np.float32)], -1)
+    sim = make_sim(state, g['boxes'][..., 2:4], np.ones((B, A), bool), BirdviewMesh.empty(batch_size=B).to(DEV))
+    sim.traffic_controls = {'traffic_light': TrafficLightControl(d(g['pos']), replay_states=d(g['replay']), mask=d(g['mask']))}
+    np.testing.assert_array_equal(sim.compute_traffic_lights_violations().cpu().numpy() > 0, g['violation_0'])
+    for t in range(1, 4):
+        sim.step(torch.zeros(B, A, 2, device=DEV))
+        assert sim.internal_time == t
+        np.testing.assert_array_equal(sim.compute_traffic_lights_violations().cpu().numpy() > 0, g[f'violation_{t}'])
+    half = sim.select_batch_elements(torch.tensor([1]), in_place=False)
+    assert half.get_traffic_controls()['traffic_light'].pos.shape[0] == 1

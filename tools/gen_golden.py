@@ -515,6 +515,43 @@ def gen_grads(out, town):
     print('g7 |grad_state|', np.abs(d['iou_grad_state']).max(), np.abs(d['discs_grad_state']).max())
 
 
+# --------------------------------------------------------------------------------------
+# G8: traffic controls: map metadata + stop lines of Town01 (data files of the reference's resources) and
+#     TrafficLightControl.compute_violation / the state replay logic on them
+# --------------------------------------------------------------------------------------
+def gen_traffic(out):
+    import shutil
+    from torchdrivesim.traffic_controls import TrafficLightControl
+    src = os.path.join(REF, 'torchdrivesim', 'resources', 'maps', 'carla_Town01')
+    dst = os.path.join(out, 'maps', 'carla_Town01')
+    os.makedirs(dst, exist_ok=True)
+    for name in ('metadata.json', 'carla_Town01_stoplines.json'):          # data files, not source
+        shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
+    stop = json.load(open(os.path.join(src, 'carla_Town01_stoplines.json')))
+    pos1 = torch.tensor([[s['x'], s['y'], s['length'], s['width'], s['orientation']] for s in stop if s['agent_type'] == 'traffic_light'])
+    g = seeded(81)
+    B, A, T = 3, 64, 5
+    N = pos1.shape[0]
+    pos = pos1.unsqueeze(0).expand(B, -1, -1).clone()
+    mask = torch.rand(B, N, generator=g) < 0.85
+    replay = torch.randint(0, 3, (B, N, T), generator=g)
+    ctl = TrafficLightControl(pos, replay_states=replay, mask=mask)
+    # agents: around randomly chosen stop lines (so that many rear boxes overlap one), random headings and sizes
+    pick = torch.randint(0, N, (B, A), generator=g)
+    centre = torch.gather(pos[..., :2], 1, pick[..., None].expand(-1, -1, 2))
+    xy = centre + torch.randn(B, A, 2, generator=g) * 1.5
+    lw = torch.stack([torch.rand(B, A, generator=g) * 2 + 3.5, torch.rand(B, A, generator=g) * 0.6 + 1.7], -1)
+    psi = (torch.rand(B, A, 1, generator=g) * 2 - 1) * math.pi
+    boxes = torch.cat([xy, lw, psi], -1)
+    d = dict(pos=npy(pos), mask=npy(mask), replay=npy(replay), boxes=npy(boxes), corners=npy(ctl.corners))
+    for t in range(T + 2):                                       # beyond T the state repeats (compute_state default)
+        ctl.step(t)
+        d[f'state_{t}'] = npy(ctl.state)
+        d[f'violation_{t}'] = npy(ctl.compute_violation(boxes))
+    np.savez_compressed(os.path.join(out, 'g8_traffic.npz'), **d)
+    print('g8 violations per step', [int(d[f'violation_{t}'].sum()) for t in range(T + 2)], 'of', B * A)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -532,6 +569,7 @@ def main():
     gen_offroad(args.out, town)
     gen_mesh_and_preraster(args.out, cv2, town)
     gen_grads(args.out, town)
+    gen_traffic(args.out)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

@@ -1,0 +1,121 @@
+"""
+Map packages on disk (torchdrivesim/map.py): `<name>/metadata.json` naming `<name>_mesh.json` (the BirdviewMesh, mesh.py:700-719),
+`<name>_stoplines.json` (traffic-control stop lines) and the files this framework does not read (`.osm` Lanelet2 map, traffic-light
+controller).  Lets a Simulator be built from the reference's map folders without the reference or lanelet2.
+"""
+import dataclasses
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from torchdrivesim_amd.mesh import BirdviewMesh
+from torchdrivesim_amd.traffic_controls import BaseTrafficControl, StopSignControl, TrafficLightControl, YieldControl
+
+#: directories searched by find_map_config, like the reference's TDS_RESOURCE_PATH (torchdrivesim/__init__.py)
+RESOURCE_PATH = [p for p in os.environ.get('TDS_RESOURCE_PATH', '').split(os.pathsep) if p]
+
+_TYPE_ALIASES = {'traffic-light': 'traffic_light', 'stop-sign': 'stop_sign', 'yield-sign': 'yield_sign', 'yield': 'yield_sign'}
+_PATH_FIELDS = dict(lanelet_path='{}.osm', mesh_path='{}_mesh.json', stoplines_path='{}_stoplines.json',
+                    traffic_light_controller_path='{}_traffic_light_controller.json')
+
+
+@dataclass
+class Stopline:
+    actor_id: int
+    agent_type: str
+    x: float
+    y: float
+    length: float
+    width: float
+    orientation: float
+
+    def __post_init__(self):
+        self.agent_type = _TYPE_ALIASES.get(self.agent_type, self.agent_type)          # map.py:29-35
+
+
+@dataclass
+class MapConfig:
+    """Map metadata: coordinate frame and where the files are (map.py:37-54)."""
+    name: str
+    left_handed_coordinates: bool = False
+    center: Optional[Tuple[float, float]] = None
+    lanelet_path: Optional[str] = None
+    lanelet_map_origin: Tuple[float, float] = (0, 0)
+    mesh_path: Optional[str] = None
+    stoplines_path: Optional[str] = None
+    traffic_light_controller_path: Optional[str] = None
+    iai_location_name: Optional[str] = None
+    note: Optional[str] = None
+
+    @property
+    def lanelet_map(self):
+        if self.lanelet_path is None:
+            return None
+        raise NotImplementedError('Lanelet2 maps are outside the scope of torchdrivesim_amd (SURVEY.md section 8: wrong-way is a later row)')
+
+    @property
+    def road_mesh(self) -> Optional[BirdviewMesh]:
+        if self.mesh_path is None:
+            if self.lanelet_path is None:
+                return None
+            raise NotImplementedError('building the road mesh from a Lanelet2 map needs lanelet2; ship a <name>_mesh.json instead')
+        return BirdviewMesh.load(self.mesh_path)
+
+    @property
+    def stoplines(self) -> List[Stopline]:
+        if self.stoplines_path is None:
+            return []
+        with open(self.stoplines_path) as f:
+            return [Stopline(**d) for d in json.load(f)]
+
+
+def resolve_paths_to_absolute(cfg: MapConfig, root: str) -> MapConfig:
+    """relative (or defaulted) file names that exist under `root` become absolute paths (map.py:101-113)"""
+    found = {}
+    for field, pattern in _PATH_FIELDS.items():
+        path = getattr(cfg, field) or pattern.format(cfg.name)
+        if os.path.isabs(path):
+            continue
+        cand = os.path.join(root, path)
+        if os.path.exists(cand):
+            found[field] = cand
+    return dataclasses.replace(cfg, **found)
+
+
+def load_map_config(json_path: str, resolve_paths: bool = True) -> MapConfig:
+    with open(json_path) as f:
+        cfg = MapConfig(**json.load(f))
+    return resolve_paths_to_absolute(cfg, os.path.dirname(json_path)) if resolve_paths else cfg
+
+
+def store_map_config(cfg: MapConfig, json_path: str, store_absolute_paths: bool = False) -> None:
+    if not store_absolute_paths:
+        cfg = dataclasses.replace(cfg, **{f: (os.path.basename(getattr(cfg, f)) if getattr(cfg, f) is not None else None) for f in _PATH_FIELDS})
+    with open(json_path, 'w') as f:
+        json.dump(dataclasses.asdict(cfg), f, indent=4)
+
+
+def find_map_config(map_name: str, resolve_paths: bool = True, resource_path: Optional[List[str]] = None) -> Optional[MapConfig]:
+    """look for the folder `map_name` in the resource directories (map.py:134-157)"""
+    for root in (RESOURCE_PATH if resource_path is None else resource_path):
+        map_path = os.path.join(root, map_name)
+        if os.path.exists(map_path):
+            break
+    else:
+        return None
+    meta = os.path.join(map_path, 'metadata.json')
+    cfg = load_map_config(meta) if os.path.exists(meta) else MapConfig(name=map_name)
+    return resolve_paths_to_absolute(cfg, map_path) if resolve_paths else cfg
+
+
+def traffic_controls_from_map_config(cfg: MapConfig) -> Dict[str, BaseTrafficControl]:
+    """one control object (batch size 1) per kind of stop line present in the map (map.py:203-229)"""
+    kinds = {'traffic_light': TrafficLightControl, 'stop_sign': StopSignControl, 'yield_sign': YieldControl}
+    poses: Dict[str, list] = {k: [] for k in kinds}
+    for s in cfg.stoplines:
+        if s.agent_type in poses:
+            poses[s.agent_type].append([s.x, s.y, s.length, s.width, s.orientation])
+    return {k: kinds[k](torch.tensor(v).unsqueeze(0)) for k, v in poses.items() if v}

@@ -155,7 +155,7 @@ class Simulator:
                  waypoint_goals=None, agent_types: Optional[Tensor] = None, agent_type_names: Optional[List[str]] = None,
                  npc_controller: Optional[NPCController] = None, agent_lr: Optional[Tensor] = None, lane_features=None,
                  observation_noise_model=None, action_model_extras: Optional[Dict[str, Any]] = None):
-        for name, val in (('lanelet_map', lanelet_map), ('traffic_controls', traffic_controls), ('waypoint_goals', waypoint_goals),
+        for name, val in (('lanelet_map', lanelet_map), ('waypoint_goals', waypoint_goals),
                           ('lane_features', lane_features), ('observation_noise_model', observation_noise_model)):
             if val is not None and not (name == 'lanelet_map' and all(m is None for m in val)):
                 raise NotImplementedError(f'`{name}` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
@@ -166,7 +166,7 @@ class Simulator:
         self.agent_size = agent_size
         self.present_mask = initial_present_mask
         self.action_model_extras = action_model_extras
-        self.traffic_controls = None
+        self.traffic_controls = traffic_controls        # Dict[str, BaseTrafficControl]: state and violations; not rendered by the fused path
         self.waypoint_goals = None
         self.lane_features = None
 
@@ -244,6 +244,8 @@ class Simulator:
         self.kinematic_model = self.kinematic_model.to(device)
         self.birdview_mesh_generator = self.birdview_mesh_generator.to(device)
         self.npc_controller = self.npc_controller.to(device)
+        if self.traffic_controls is not None:
+            self.traffic_controls = {k: v.to(device) for k, v in self.traffic_controls.items()}
         self._scene_cache = None
         return self
 
@@ -253,7 +255,8 @@ class Simulator:
             road_mesh=self.road_mesh, kinematic_model=self.kinematic_model.copy(), agent_size=self.agent_size,
             initial_present_mask=self.present_mask, cfg=self.cfg, renderer=self.renderer.copy(), lanelet_map=self.lanelet_map,
             birdview_mesh_generator=self.birdview_mesh_generator.copy(), recenter_offset=self.recenter_offset, internal_time=self.internal_time,
-            agent_types=self.agent_type, agent_type_names=self.agent_types, agent_lr=self.agent_lr, npc_controller=self.npc_controller.copy())
+            agent_types=self.agent_type, agent_type_names=self.agent_types, agent_lr=self.agent_lr, npc_controller=self.npc_controller.copy(),
+            traffic_controls={k: v.copy() for k, v in self.traffic_controls.items()} if self.traffic_controls is not None else None)
         other._scene_cache = self._scene_cache          # static maps are immutable and can be shared
         return other
 
@@ -271,6 +274,8 @@ class Simulator:
         self._batch_size *= n
         self.birdview_mesh_generator = self.birdview_mesh_generator.expand(n)
         self.npc_controller = self.npc_controller.extend(n)
+        if self.traffic_controls is not None:
+            self.traffic_controls = {k: v.extend(n) for k, v in self.traffic_controls.items()}
         self._scene_cache = None
         return self
 
@@ -288,6 +293,8 @@ class Simulator:
         self._batch_size = len(idx)
         self.birdview_mesh_generator = self.birdview_mesh_generator.select_batch_elements(idx)
         self.npc_controller = self.npc_controller.select_batch_elements(idx)
+        if self.traffic_controls is not None:
+            self.traffic_controls = {k: v.select_batch_elements(idx) for k, v in self.traffic_controls.items()}
         self._scene_cache = None
         return self
 
@@ -409,6 +416,9 @@ class Simulator:
         assert_equal(agent_action.shape[-2], self.agent_count)
         self.npc_controller.advance_npcs(self)
         self.kinematic_model.step(agent_action)
+        if self.traffic_controls is not None:                       # simulator.py:857-859
+            for control in self.traffic_controls.values():
+                control.step(self.internal_time)
 
     def set_state(self, agent_state: Tensor, mask: Optional[Tensor] = None) -> None:
         if mask is None:
@@ -550,7 +560,12 @@ class Simulator:
         return torch.zeros(state.shape[0], state.shape[1], device=state.device)
 
     def compute_traffic_lights_violations(self) -> Tensor:
+        """BxA: the agent is (mostly) past the stop line of a red light (simulator.py:1046-1062)."""
         state = self.get_state()
+        controls = self.get_traffic_controls()
+        if controls is not None and 'traffic_light' in controls:
+            boxes = torch.cat([state[..., :2], self.get_agent_size()[..., :2], state[..., 2:3]], dim=-1)
+            return controls['traffic_light'].compute_violation(boxes) * self.get_present_mask().to(state.dtype)
         return torch.zeros(state.shape[0], state.shape[1], dtype=torch.bool, device=state.device)
 
     def _all_boxes(self):
