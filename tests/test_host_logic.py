@@ -62,7 +62,9 @@ def test_out_of_scope_arguments_are_refused():
     from torchdrivesim_amd.simulator import Simulator
     sim = make_sim()
     with pytest.raises(NotImplementedError):
-        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, traffic_controls={'traffic_light': object()})
+        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, waypoint_goals=object())
+    with pytest.raises(NotImplementedError):
+        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, observation_noise_model=object())
 
 
 def test_kinematic_bookkeeping_and_fit_action():
