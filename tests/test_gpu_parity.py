@@ -275,7 +275,9 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town):
         static = oracle_static(oracle, *mesh, town['categories']) if len(mesh[1]) else (np.zeros((0, 3), np.float32),) * 2 + (np.zeros((0, 3), np.int32),)
         mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
         # {bit-plane kernel} + strip widths x {binned, fused} packed-key kernels
-        for tw, ws, bits in ((0, True, True), (0, True, False), (0, False, False), (64, True, False), (16, True, False), (16, False, False)):
+        # (with bits=True a strip width >= 32 cuts the bit-plane kernel's image into strips as well)
+        for tw, ws, bits in ((0, True, True), (32, True, True), (64, True, True), (0, True, False), (0, False, False), (64, True, False),
+                             (16, True, False), (16, False, False)):
             from torchdrivesim_amd import _native
             _native.lib().tds_raster_set_strip_width(tw)
             ops.use_workspace, ops.use_bitplanes = ws, bits
@@ -329,6 +331,26 @@ def test_k3_random_town01_256_bit_exact(ops, oracle, town):
             ops.use_workspace, ops.use_bitplanes = True, True
         bad = img != ref
         assert not bad.any(), f'workspace={ws} bitplanes={bits}: {bad.sum()} values differ'
+    assert (ref > 0).mean() > 0.05
+
+
+@pytest.mark.parametrize('res', [320, 512])
+def test_k3_large_resolutions_use_strips(ops, oracle, town, res):
+    """above 256x256 with five keys the bit planes of a whole image no longer fit 64 KiB: the bit-plane kernel renders the camera in
+    strips (res 320 is not a multiple of 64 either); same pixels as the oracle"""
+    gen = np.random.default_rng(23)
+    B, A = 1, 5
+    road = town['verts'][town['vert_category'] == town['categories'].index('road')]
+    xy = road[gen.integers(0, len(road), (B, 1))] + gen.uniform(-12, 12, (B, A, 2))
+    state = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), gen.uniform(0, 10, (B, A, 1))], -1).astype(np.float32)
+    size = np.tile(np.array([4.6, 2.0], np.float32), (B, A, 1))
+    mask = np.ones((B, A, A), bool)
+    smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
+    img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 50.0, res)
+    bad = img != ref
+    assert not bad.any(), f'{bad.sum()} values differ'
     assert (ref > 0).mean() > 0.05
 
 
