@@ -141,7 +141,8 @@ int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, const float *l
  *   agent_sc  B x N x 2   [sin, cos] of psi
  *   tmpl      B x N x 7 x 2   actor template verts in the agent frame (mesh.py:911-996), built once by the host
  *   actor_key B x N x 2   uint32 (rank << 24 | 0x00RRGGBB) for (body, direction) faces, rank = 1 + index of the
- *                         part's rendering level in the map's `levels`
+ *                         part's rendering level in the map's `levels`; a key of 0 removes the part (quads without a direction
+ *                         triangle, e.g. the stop lines of traffic controls, mesh.py:1007-1035)
  *   mask      B x Nc x N  uint8, present & rendering mask (simulator.py:946-948)
  *   cam_xy    B x Nc x 2, cam_sc B x Nc x 2 [sin, cos]
  *   scale = 2 / fov (rendering/base.py:149), res = H = W

@@ -19,7 +19,7 @@ def town_mesh(B, crop=None):
                         vert_category=torch.from_numpy(t['vert_category'].astype(np.int64))[None]).expand(B).to(DEV), t
 
 
-def make_sim(state, size, present, road, metric='iou', npc=None, lr=None):
+def make_sim(state, size, present, road, metric='iou', npc=None, lr=None, **kw):
     from torchdrivesim_amd.kinematic import KinematicBicycle
     from torchdrivesim_amd.rendering import HipRendererConfig
     from torchdrivesim_amd.simulator import Simulator, TorchDriveConfig, CollisionMetric, NPCController
@@ -31,7 +31,7 @@ def make_sim(state, size, present, road, metric='iou', npc=None, lr=None):
     if npc is not None:
         ctrl = NPCController(npc_size=d(npc['size']), npc_state=d(npc['state']), npc_present_mask=d(npc['present']))
     cfg = TorchDriveConfig(collision_metric=CollisionMetric(metric), renderer=HipRendererConfig())
-    return Simulator(road, km, d(size), d(present), cfg, npc_controller=ctrl)
+    return Simulator(road, km, d(size), d(present), cfg, npc_controller=ctrl, **kw)
 
 
 def test_smoke_entry_point():
@@ -184,3 +184,45 @@ def test_traffic_light_violations_match_reference():
         np.testing.assert_array_equal(sim.compute_traffic_lights_violations().cpu().numpy() > 0, g[f'violation_{t}'])
     half = sim.select_batch_elements(torch.tensor([1]), in_place=False)
     assert half.get_traffic_controls()['traffic_light'].pos.shape[0] == 1
+
+
+def test_traffic_controls_are_rendered_like_the_reference_mesh(oracle):
+    """G9: stop lines as quads, lights coloured by their state.  The fused path (quads ride along with the actors) paints the pixels
+    of the RGB mesh the REFERENCE generated for the same scene (tests/golden/g9_traffic_mesh.npz) as drawn by the oracle, and so does
+    the generic dataflow of this framework (generate() -> render_frame)."""
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    from torchdrivesim_amd.traffic_controls import StopSignControl, TrafficLightControl, YieldControl
+    from torchdrivesim_amd.utils import Resolution
+    g = load_golden('g9_traffic_mesh.npz')
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    B, A = g['state'].shape[:2]
+    road = BirdviewMesh(verts=d(g['bg_verts'])[None], faces=d(g['bg_faces'].astype(np.int64))[None], categories=['right_lane', 'left_lane', 'road'],
+                        colors={}, zs={}, vert_category=d(g['bg_vert_category'].astype(np.int64))[None]).expand(B)
+    tl = TrafficLightControl(d(g['tl_pos']), mask=d(g['tl_mask']))
+    tl.set_state(d(g['tl_state']))
+    controls = dict(stop_sign=StopSignControl(d(g['ss_pos'])), traffic_light=tl, yield_sign=YieldControl(d(g['ys_pos'])))
+    sim = make_sim(g['state'], g['size'], g['present'], road, traffic_controls=controls)
+    s = sim.get_state()
+    cam_sc = torch.stack([torch.sin(s[..., 2]), torch.cos(s[..., 2])], -1)
+    for res, fov in ((128, 35.0), (96, 60.0)):
+        ref = oracle.render_rgb_mesh(g['rgb_verts'], g['rgb_attrs'], g['rgb_faces'], s[..., :2].reshape(-1, 2).cpu().numpy(),
+                                     cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / fov, res)                      # n x H x W x 3
+        ref = np.transpose(ref, (0, 3, 1, 2)).reshape(B, A, 3, res, res)
+        img = sim.render_egocentric(res=Resolution(res, res), fov=fov)
+        np.testing.assert_array_equal(img.cpu().numpy(), ref)
+        assert any((ref[:, :, 0] == c[0]).any() for c in ((224, 53, 49), (240, 189, 39), (81, 179, 100)))       # a light is in view
+        mask = d(np.ascontiguousarray(np.broadcast_to(g['present'][:, None, :], (B, A, A))))
+        rgb = sim.birdview_mesh_generator.generate(A, agent_state=s[:, None].expand(-1, A, -1, -1), present_mask=mask,
+                                                   traffic_lights=controls['traffic_light'].extend(A, in_place=False))
+        np.testing.assert_array_equal(rgb.faces.cpu().numpy(), g['rgb_faces'])
+        np.testing.assert_allclose(rgb.verts.cpu().numpy(), g['rgb_verts'], atol=2e-5, rtol=0)     # device sin / cos differ from the CPU's by an ulp
+        np.testing.assert_allclose(rgb.attrs.cpu().numpy(), g['rgb_attrs'], atol=1e-6, rtol=0)     # colour / 255 on the device
+        img2 = sim.renderer.render_frame(rgb, s[..., :2], cam_sc, res=Resolution(res, res), fov=fov).reshape(img.shape)
+        ref2 = oracle.render_rgb_mesh(rgb.verts.cpu().numpy(), rgb.attrs.cpu().numpy(), rgb.faces.cpu().numpy().astype(np.int32),
+                                      s[..., :2].reshape(-1, 2).cpu().numpy(), cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / fov, res)
+        np.testing.assert_array_equal(img2.cpu().numpy(), np.transpose(ref2, (0, 3, 1, 2)).reshape(img.shape))
+        assert (img2.cpu().numpy() != ref).mean() < 1e-3
+    # a light that changes state changes colour
+    before = sim.render_egocentric(res=Resolution(96, 96), fov=60.0)
+    tl.set_state((tl.state + 1) % 3)
+    assert (sim.render_egocentric(res=Resolution(96, 96), fov=60.0) != before).any()

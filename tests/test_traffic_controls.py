@@ -69,3 +69,27 @@ def test_violation_predicate_restated_with_the_oracle(oracle):
     for t in range(7):
         red = g[f'state_{t}'] == 0
         np.testing.assert_array_equal((overlap & red[:, None]).any(-1), g[f'violation_{t}'])
+
+
+def test_generator_reproduces_the_reference_mesh_with_traffic_controls():
+    """generate() with stop-sign / yield / traffic-light quads against the mesh the reference generated (g9_traffic_mesh.npz)"""
+    from torchdrivesim_amd.mesh import BirdviewMesh, BirdviewRGBMeshGenerator
+    from torchdrivesim_amd.rendering import get_default_color_map, get_default_rendering_levels
+    from torchdrivesim_amd.traffic_controls import StopSignControl, TrafficLightControl, YieldControl
+    g = load_golden('g9_traffic_mesh.npz')
+    t = torch.from_numpy
+    B, A = g['state'].shape[:2]
+    bg = BirdviewMesh(verts=t(g['bg_verts'])[None], faces=t(g['bg_faces'].astype(np.int64))[None], categories=['right_lane', 'left_lane', 'road'],
+                      colors={}, zs={}, vert_category=t(g['bg_vert_category'].astype(np.int64))[None]).expand(B)
+    tl = TrafficLightControl(t(g['tl_pos']), mask=t(g['tl_mask']))
+    tl.set_state(t(g['tl_state']))
+    controls = dict(stop_sign=StopSignControl(t(g['ss_pos'])), traffic_light=tl, yield_sign=YieldControl(t(g['ys_pos'])))
+    gen = BirdviewRGBMeshGenerator(bg, get_default_color_map(), get_default_rendering_levels())
+    gen.initialize_actors_mesh(t(g['size']), torch.zeros(B, A, dtype=torch.long), ['vehicle'])
+    gen.initialize_traffic_controls_mesh(controls)
+    nc = g['rgb_verts'].shape[0] // B
+    rgb = gen.generate(nc, agent_state=t(g['state'])[:, None].expand(-1, nc, -1, -1), present_mask=t(g['present'])[:, None].expand(B, nc, A),
+                       traffic_lights=tl.extend(nc, in_place=False))
+    np.testing.assert_array_equal(rgb.faces.numpy(), g['rgb_faces'])
+    np.testing.assert_allclose(rgb.verts.numpy(), g['rgb_verts'], atol=0, rtol=0)
+    np.testing.assert_array_equal(rgb.attrs.numpy(), g['rgb_attrs'])

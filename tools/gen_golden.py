@@ -549,6 +549,37 @@ def gen_traffic(out):
         d[f'state_{t}'] = npy(ctl.state)
         d[f'violation_{t}'] = npy(ctl.compute_violation(boxes))
     np.savez_compressed(os.path.join(out, 'g8_traffic.npz'), **d)
+
+    # G9: the RGB mesh the reference generates for traffic controls (stop lines as quads, lights coloured by state,
+    # mesh.py:1007-1051,1105-1118,1150-1153) on a small background
+    from torchdrivesim.mesh import BirdviewRGBMeshGenerator
+    from torchdrivesim.rendering.base import get_default_color_map, get_default_rendering_levels
+    from torchdrivesim.traffic_controls import StopSignControl, YieldControl
+    g = seeded(99)
+    town = load_town01()
+    small = crop_mesh(town, (100.0, 2.0), 6.0)
+    B, A, nc = 2, 3, 3
+    state, size, present = random_scene(g, B, A, spread=20.0, centre=(100.0, 2.0))
+    mk = lambda n: torch.cat([torch.tensor([100.0, 2.0]) + (torch.rand(B, n, 2, generator=g) - 0.5) * 24,
+                              torch.rand(B, n, 1, generator=g) * 1.0 + 0.8, torch.rand(B, n, 1, generator=g) * 3 + 3,
+                              (torch.rand(B, n, 1, generator=g) - 0.5) * 2 * math.pi], -1)
+    tl_pos, ss_pos, ys_pos = mk(4), mk(2), mk(1)
+    tl_mask = torch.tensor([[True, True, False, True], [True, True, True, True]])
+    tl_state = torch.randint(0, 3, (B, 4), generator=g)
+    controls = dict(stop_sign=StopSignControl(ss_pos), traffic_light=TrafficLightControl(tl_pos, mask=tl_mask), yield_sign=YieldControl(ys_pos))
+    controls['traffic_light'].set_state(tl_state)
+    gen = BirdviewRGBMeshGenerator(background_mesh=small.expand(B), color_map=get_default_color_map(),
+                                   rendering_levels=get_default_rendering_levels())
+    gen.initialize_actors_mesh(size, torch.zeros(B, A, dtype=torch.long), ['vehicle'])
+    gen.initialize_traffic_controls_mesh(controls)
+    rgb = gen.generate(nc, agent_state=state[:, None].expand(-1, nc, -1, -1), present_mask=present[:, None].expand(B, nc, A),
+                       traffic_lights=controls['traffic_light'].extend(nc, in_place=False))
+    d9 = dict(state=npy(state), size=npy(size), present=npy(present), tl_pos=npy(tl_pos), tl_mask=npy(tl_mask), tl_state=npy(tl_state),
+              ss_pos=npy(ss_pos), ys_pos=npy(ys_pos), bg_verts=npy(small.verts[0]), bg_faces=npy(small.faces[0]).astype(np.int32),
+              bg_vert_category=npy(small.vert_category[0]).astype(np.uint8),
+              rgb_verts=npy(rgb.verts), rgb_faces=npy(rgb.faces).astype(np.int32), rgb_attrs=npy(rgb.attrs))
+    np.savez_compressed(os.path.join(out, 'g9_traffic_mesh.npz'), **d9)
+    print('g9 mesh', tuple(rgb.verts.shape), tuple(rgb.faces.shape))
     print('g8 violations per step', [int(d[f'violation_{t}'].sum()) for t in range(T + 2)], 'of', B * A)
 
 

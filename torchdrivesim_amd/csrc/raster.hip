@@ -759,8 +759,8 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
             const int f = st.f;
             float fx[3] = {f == 0 ? st.sx0 : (f == 1 ? st.sx1 : st.sx4), f == 0 ? st.sx1 : (f == 1 ? st.sx3 : st.sx5), f == 0 ? st.sx3 : (f == 1 ? st.sx2 : st.sx6)};
             float fy[3] = {f == 0 ? st.sy0 : (f == 1 ? st.sy1 : st.sy4), f == 0 ? st.sy1 : (f == 1 ? st.sy3 : st.sy5), f == 0 ? st.sy3 : (f == 1 ? st.sy2 : st.sy6)};
-            acc = st.near && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
             key = f == 2 ? st.kdir : st.kbody;
+            acc = st.near && key != 0u && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);      // key 0: the part does not exist
             edges = edge_mask(f == 1 ? 2u : 0u, ins);      // body faces [0,1,3] and [1,3,2] share the edge 1-3 (edge 1 of the second)
             ++st.f;
         }

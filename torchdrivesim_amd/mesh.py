@@ -390,6 +390,14 @@ def set_colors_with_defaults(mesh: BirdviewMesh, color_map: Dict[str, Tuple[int,
     return mesh.fill_attr()
 
 
+def build_verts_faces_from_bounding_box(bbs: Tensor) -> Tuple[Tensor, Tensor]:
+    """...xAx4x2 corners -> vertices ...x4Ax2 and faces ...x2Ax3, every box cut along the corner 1 - corner 3 diagonal (mesh.py:1274-1290)"""
+    batch, n = bbs.shape[:-3], bbs.shape[-3]
+    quad = torch.tensor([[0, 1, 3], [1, 3, 2]], dtype=torch.long, device=bbs.device)
+    faces = quad + 4 * torch.arange(n, dtype=torch.long, device=bbs.device).reshape(n, 1, 1)
+    return bbs.reshape(*batch, -1, 2), faces.reshape(2 * n, 3).expand(*batch, 2 * n, 3)
+
+
 #: template faces of one actor: body quad as two triangles, then the direction triangle (mesh.py:955, 933-935)
 ACTOR_FACES = ((0, 1, 3), (1, 3, 2), (4, 5, 6))
 ACTOR_VERTS = 7
@@ -426,8 +434,9 @@ class BirdviewRGBMeshGenerator:
         if agent_attributes is not None:
             assert agent_types is not None and agent_type_names is not None
             self.initialize_actors_mesh(agent_attributes, agent_types, agent_type_names, render_agent_direction)
+        self.static_traffic_controls_mesh = self.traffic_lights_mesh = self.traffic_light_colors = None
         if traffic_controls:
-            raise NotImplementedError('traffic-control meshes are outside the MI355X hot path (SURVEY.md 8f N3)')
+            self.initialize_traffic_controls_mesh(traffic_controls)
 
     def initialize_background_mesh(self, background_mesh, world_center: Optional[Tensor] = None):
         if world_center is None:
@@ -482,6 +491,34 @@ class BirdviewRGBMeshGenerator:
                             colors=dict(), zs=dict())
         self.actor_mesh = set_colors_with_defaults(mesh, color_map=self.color_map, rendering_levels=self.rendering_levels)
 
+    # ---- traffic controls (mesh.py:1007-1051): stop lines as quads; lights are coloured by their state at generate() time
+    @classmethod
+    def _create_traffic_controls_mesh(cls, traffic_controls, selected: List[str]) -> BirdviewMesh:
+        batch_size = max([c.corners.shape[0] for c in traffic_controls.values()], default=1)
+        meshes = []
+        for kind, control in traffic_controls.items():
+            if kind not in selected or control.corners.shape[-3] == 0:
+                continue
+            verts, faces = build_verts_faces_from_bounding_box(control.corners)
+            if kind == 'traffic_light':
+                meshes.append(BirdviewMesh(verts=verts, faces=faces, categories=[f'{kind}_{st}' for st in control.allowed_states],
+                                           vert_category=control.state.unsqueeze(-1).expand(control.state.shape + (4,)).flatten(-2, -1),
+                                           zs=dict(), colors=dict()))
+            else:
+                meshes.append(rendering_mesh(BaseMesh(verts=verts, faces=faces), category=kind))
+        return BirdviewMesh.concat(meshes) if meshes else BirdviewMesh.empty(dim=2, batch_size=batch_size)
+
+    def initialize_traffic_controls_mesh(self, traffic_controls) -> None:
+        mk = lambda sel: set_colors_with_defaults(self._create_traffic_controls_mesh(traffic_controls, sel), color_map=self.color_map,
+                                                  rendering_levels=self.rendering_levels)
+        self.static_traffic_controls_mesh = mk(['stop_sign', 'yield_sign'])
+        self.traffic_lights_mesh = mk(['traffic_light'])
+        self.traffic_light_colors = None
+        if 'traffic_light' in traffic_controls:
+            tl = traffic_controls['traffic_light']
+            cols = torch.stack([tensor_color(self.color_map[f'traffic_light_{st}'], device=self.traffic_lights_mesh.device) for st in tl.allowed_states])
+            self.traffic_light_colors = cols.reshape(1, 1, -1, 3).expand(self.traffic_lights_mesh.batch_size, tl.state.shape[1], -1, -1)
+
     # ---- batch plumbing
     def to(self, device):
         self.background_mesh = self.background_mesh.to(device)
@@ -489,6 +526,9 @@ class BirdviewRGBMeshGenerator:
         if self.actor_mesh is not None:
             self.actor_mesh = self.actor_mesh.to(device)
             self.actor_lenwid, self.actor_types = self.actor_lenwid.to(device), self.actor_types.to(device)
+        for name in ('static_traffic_controls_mesh', 'traffic_lights_mesh', 'traffic_light_colors'):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, getattr(self, name).to(device))
         return self
 
     def _clone_with(self, f, bg_f):
@@ -501,6 +541,9 @@ class BirdviewRGBMeshGenerator:
         other.actor_lenwid = f(self.actor_lenwid) if self.actor_lenwid is not None else None
         other.actor_types = f(self.actor_types) if self.actor_types is not None else None
         other.actor_type_names = self.actor_type_names
+        other.static_traffic_controls_mesh = bg_f(self.static_traffic_controls_mesh) if self.static_traffic_controls_mesh is not None else None
+        other.traffic_lights_mesh = bg_f(self.traffic_lights_mesh) if self.traffic_lights_mesh is not None else None
+        other.traffic_light_colors = f(self.traffic_light_colors) if self.traffic_light_colors is not None else None
         return other
 
     def copy(self):
@@ -518,8 +561,8 @@ class BirdviewRGBMeshGenerator:
                  custom_agent_colors: Optional[Tensor] = None) -> RGBMesh:
         """Explicit (B*Nc)-batched RGB mesh = background expanded per camera || posed actors (mesh.py:1053-1157).
         Faces of masked agents are zeroed before the concat, hence alias the first actor vertex."""
-        if traffic_lights is not None or waypoints is not None:
-            raise NotImplementedError('traffic lights / waypoints are outside the MI355X hot path (SURVEY.md 8f N3)')
+        if waypoints is not None:
+            raise NotImplementedError('waypoint meshes are outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
         meshes = [self.background_mesh.expand(num_cameras)]
         if agent_state is not None and self.actor_mesh is not None:
             assert agent_state.shape[1] == num_cameras
@@ -541,4 +584,13 @@ class BirdviewRGBMeshGenerator:
                 for i in range(4):
                     attrs[:, i::step] = cc
             meshes.append(dataclasses.replace(actor, verts=verts, faces=faces, attrs=attrs))
+        if self.static_traffic_controls_mesh is not None:
+            meshes.append(self.static_traffic_controls_mesh.expand(num_cameras))
+        if traffic_lights is not None and self.traffic_lights_mesh is not None and self.traffic_lights_mesh.faces_count > 0:
+            # colour of every light = colour of its current state, on its four vertices (mesh.py:1105-1118)
+            lights = self.traffic_lights_mesh.expand(num_cameras)
+            assert traffic_lights.state.shape[0] == lights.batch_size
+            table = self.traffic_light_colors[:, None].repeat_interleave(num_cameras, dim=1).flatten(0, 1)
+            cur = torch.gather(table, 2, traffic_lights.state[..., None, None].expand(-1, -1, -1, 3))
+            meshes.append(dataclasses.replace(lights, attrs=cur.expand(-1, -1, 4, -1).reshape(lights.batch_size, -1, 3)))
         return RGBMesh.concat(meshes)

@@ -212,6 +212,8 @@ class Simulator:
             self.birdview_mesh_generator.initialize_actors_mesh(self.get_all_agent_size(), self.get_all_agent_type(), self.agent_types)
         else:
             self.birdview_mesh_generator = birdview_mesh_generator
+        if self.traffic_controls and getattr(self.birdview_mesh_generator, 'traffic_lights_mesh', None) is None:
+            self.birdview_mesh_generator.initialize_traffic_controls_mesh(self.traffic_controls)      # simulator.py:373-374
         self._scene_cache = None        # device-resident static maps + actor templates/keys, rebuilt lazily
 
     # ------------------------------------------------------------------------------------------------- properties
@@ -448,7 +450,8 @@ class Simulator:
         `to` / `extend` / `select_batch_elements` or when sizes / types tensors are replaced."""
         gen = self.birdview_mesh_generator
         sizes, types = self.get_all_agent_size(), self.get_all_agent_type()
-        stamp = (sizes.data_ptr(), tuple(sizes.shape), types.data_ptr(), gen.background_mesh.verts.data_ptr(), str(sizes.device), self.batch_size)
+        stamp = (sizes.data_ptr(), tuple(sizes.shape), types.data_ptr(), gen.background_mesh.verts.data_ptr(), str(sizes.device), self.batch_size,
+                 tuple((k, v.pos.data_ptr(), v.mask.data_ptr()) for k, v in (self.traffic_controls or {}).items()))
         if self._scene_cache is not None and self._scene_cache['stamp'] == stamp:
             return self._scene_cache
         if not isinstance(self.renderer, HipRenderer):
@@ -459,6 +462,12 @@ class Simulator:
         lv, cm = self.renderer.rendering_levels, self.renderer.color_map
         actor_levels = [float(lv[n]) for n in names] + [float(lv['direction'])]
         B = self.batch_size
+        # traffic controls are drawn like actors without a direction triangle: one quad per stop line (mesh.py:1007-1035)
+        controls = self.traffic_controls or {}
+        ctrl_kinds = [k for k in controls if controls[k].pos.shape[1] > 0]
+        for kind in ctrl_kinds:
+            cats = [f'{kind}_{st}' for st in controls[kind].allowed_states] if kind == 'traffic_light' else [kind]
+            actor_levels += [float(lv[c]) for c in cats]
         same = B == 1 or (bg.verts.stride(0) == 0 and bg.faces.stride(0) == 0) or \
             (bool((bg.verts == bg.verts[:1]).all()) and bool((bg.faces == bg.faces[:1]).all()) and bool((bg.attrs == bg.attrs[:1]).all()))
         if same:
@@ -474,8 +483,44 @@ class Simulator:
             k = torch.stack([body[types.long()], torch.full_like(types.long(), dkey)], dim=-1)
             keys.append(k.to(torch.int32).contiguous())             # bit pattern of the uint32 key
             key_tables.append(sorted(set(body.tolist()) | {dkey}))   # distinct actor keys, known on the host (bit-plane kernel)
-        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables)
+        ctrl = None
+        if ctrl_kinds:
+            q = lambda name: int(_ops.quantise_colors(torch.tensor(cm[name], dtype=torch.float32) / 255.0))
+            st_q, tm_q, static_keys, light_tables = [], [], [], []
+            for kind in ctrl_kinds:
+                c = controls[kind]
+                pos, m = c.pos.to(dev).to(sizes.dtype), c.mask.to(dev)[..., None]
+                # padding elements sit at (-1000, -1000) with all four corners there (traffic_controls.py:31-33)
+                xy = torch.where(m, pos[..., :2], torch.full_like(pos[..., :2], -1000.0))
+                st_q.append(torch.cat([xy, torch.where(m, pos[..., 4:5], torch.zeros_like(pos[..., 4:5])), torch.zeros_like(pos[..., :1])], dim=-1))
+                sx = torch.tensor([0.5, -0.5, -0.5, 0.5], dtype=pos.dtype, device=dev) * pos[..., 2:3]      # box2corners_th corner order
+                sy = torch.tensor([0.5, 0.5, -0.5, -0.5], dtype=pos.dtype, device=dev) * pos[..., 3:4]
+                quad = torch.stack([sx, sy], dim=-1) * m[..., None].to(pos.dtype)
+                tm_q.append(torch.cat([quad, torch.zeros(quad.shape[:2] + (3, 2), dtype=pos.dtype, device=dev)], dim=-2))
+                per_map = []
+                for smap, _ in maps:
+                    if kind == 'traffic_light':
+                        per_map.append(torch.tensor([(smap.rank_of(lv[f'{kind}_{s_}']) << 24) | q(f'{kind}_{s_}') for s_ in c.allowed_states],
+                                                    dtype=torch.int64, device=dev))
+                    else:
+                        per_map.append(torch.full((1,), (smap.rank_of(lv[kind]) << 24) | q(kind), dtype=torch.int64, device=dev))
+                static_keys.append(per_map)
+            ctrl = dict(kinds=ctrl_kinds, state=torch.cat(st_q, dim=1).contiguous(), tmpl=torch.cat(tm_q, dim=1).contiguous(), key_lut=static_keys)
+            for i in range(len(maps)):
+                key_tables[i] = sorted(set(key_tables[i]) | {int(v) for per_map in static_keys for v in per_map[i].tolist()})
+        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables, ctrl=ctrl)
         return self._scene_cache
+
+    def _control_keys(self, scene, i_map: int, sl) -> Tensor:
+        """(b, Nq, 2) int32 keys of the control quads of the scenes in `sl`: (colour of the current state, 0 = no direction part)"""
+        out = []
+        for kind, per_map in zip(scene['ctrl']['kinds'], scene['ctrl']['key_lut']):
+            c = self.traffic_controls[kind]
+            lut = per_map[i_map]
+            idx = c.state[sl].to(lut.device).long() if kind == 'traffic_light' else torch.zeros_like(c.state[sl].to(lut.device).long())
+            out.append(lut[idx])
+        body = torch.cat(out, dim=1)
+        return torch.stack([body, torch.zeros_like(body)], dim=-1).to(torch.int32)
 
     # ------------------------------------------------------------------------------------------------- rendering
     def render(self, camera_xy: Tensor, camera_psi: Tensor, res: Optional[Resolution] = None, rendering_mask: Optional[Tensor] = None,
@@ -500,9 +545,15 @@ class Simulator:
                 self.renderer.out_dtype == torch.float32
             if not diff:
                 state, camera_xy, camera_sc = state.detach(), camera_xy.detach(), camera_sc.detach()
+            tmpl_all = scene['tmpl']
+            ctrl = scene['ctrl']
+            if ctrl is not None:                                    # stop lines ride along as extra quads
+                state = torch.cat([state, ctrl['state'].to(state.dtype)], dim=1)
+                tmpl_all = torch.cat([tmpl_all, ctrl['tmpl'].to(tmpl_all.dtype)], dim=1)
+                mask = torch.cat([mask, torch.ones(mask.shape[:-1] + (ctrl['state'].shape[1],), dtype=torch.bool, device=mask.device)], dim=-1)
             agent_sc = _ops.heading_sc(state[..., 2])
             out = []
-            for (smap, b), keys, ktab in zip(scene['maps'], scene['keys'], scene['key_tables']):
+            for i_map, ((smap, b), keys, ktab) in enumerate(zip(scene['maps'], scene['keys'], scene['key_tables'])):
                 sl = slice(None) if b is None else slice(b, b + 1)
                 k = keys[sl]
                 if custom_agent_colors is not None:
@@ -513,12 +564,17 @@ class Simulator:
                     kc = k[:, None].expand(-1, n_cam, -1, -1).clone()
                     kc[..., 0] = (kc[..., 0] & ~0xFFFFFF) | rgb
                     k, ktab = kc.contiguous(), None
-                out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], scene['tmpl'][sl], k, mask[sl].contiguous(),
+                if ctrl is not None:
+                    kq = self._control_keys(scene, i_map, sl)
+                    k = torch.cat([k, kq[:, None].expand(-1, n_cam, -1, -1) if k.dim() == 4 else kq], dim=-2).contiguous()
+                out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], tmpl_all[sl], k, mask[sl].contiguous(),
                                                       camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
         # any other BirdviewRenderer: the reference's generic dataflow (explicit per-camera mesh)
         rgb_mesh = self.birdview_mesh_generator.generate(n_cam, agent_state=self.get_all_agent_state()[:, None].expand(-1, n_cam, -1, -1),
-                                                         present_mask=mask, custom_agent_colors=custom_agent_colors)
+                                                         present_mask=mask, custom_agent_colors=custom_agent_colors,
+                                                         traffic_lights=self.traffic_controls['traffic_light'].extend(n_cam, in_place=False)
+                                                         if self.traffic_controls and 'traffic_light' in self.traffic_controls else None)
         img = self.renderer.render_frame(rgb_mesh, camera_xy, camera_sc, res=res, fov=fov)
         return img.reshape((self.batch_size, n_cam) + img.shape[1:])
 
