@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Large randomised parity run of the K3 scene rasteriser against the oracle (not part of the test suite: minutes of CPU time).
+   python tools/fuzz_raster.py [--seeds 8] [--batch 8] [--agents 24] [--res 256]"""
+import argparse, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from test_gpu_parity import dev, make_map, oracle_static, render_both, sc_np    # noqa: E402
+from torchdrivesim_amd import _ops as ops                                        # noqa: E402
+from oracle import oracle                                                        # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--seeds', type=int, default=8); ap.add_argument('--batch', type=int, default=8); ap.add_argument('--agents', type=int, default=24)
+ap.add_argument('--res', type=int, default=256); ap.add_argument('--fov', type=float, default=35.0)
+a = ap.parse_args()
+t = np.load(os.path.join(ROOT, 'tests', 'golden', 'town01_mesh.npz'))
+town = dict(verts=t['verts'], faces=t['faces'], vert_category=t['vert_category'], categories=[str(c) for c in t['categories']])
+smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
+static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
+road = town['verts'][town['vert_category'] == town['categories'].index('road')]
+bad_total = n_img = 0
+t0 = time.time()
+for seed in range(a.seeds):
+    gen = np.random.default_rng(1000 + seed)
+    B, A = a.batch, a.agents
+    anchor = road[gen.integers(0, len(road), (B, 1))]
+    xy = anchor + gen.uniform(-25, 25, (B, A, 2))
+    state = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), gen.uniform(0, 10, (B, A, 1))], -1).astype(np.float32)
+    size = np.concatenate([gen.uniform(3.5, 12, (B, A, 1)), gen.uniform(1.6, 3.0, (B, A, 1))], -1).astype(np.float32)
+    present = gen.uniform(size=(B, A)) < 0.85
+    mask = np.ascontiguousarray(present[:, None, :] & (gen.uniform(size=(B, A, A)) < 0.95))
+    cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
+    img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, a.fov, a.res)
+    bad = (img != ref)
+    per_img = bad.reshape(B * A, -1).any(1).sum()
+    bad_total += int(bad.sum()); n_img += B * A
+    print(f'seed {seed}: {B * A} images, {int(bad.sum())} differing values in {int(per_img)} images ({time.time() - t0:.0f} s)', flush=True)
+print('TOTAL', n_img, 'images,', bad_total, 'differing values')
+sys.exit(1 if bad_total else 0)
