@@ -620,10 +620,8 @@ __device__ __forceinline__ void drain(WaveCtx &w, bool acc, uint32_t key, const 
 // ---- scene producer: actors, then the masked-agent dot, then the static map cells under a pixel window --------------
 constexpr int SCAN_EMPTY_ROW = (int)0xffff7fffu;     // cell range lo = 0x7fff, hi = -1
 struct ScanState {
-    int phase, a0, f;
-    bool masked_seen, near;
-    float sx0, sx1, sx2, sx3, sx4, sx5, sx6, sy0, sy1, sy2, sy3, sy4, sy5, sy6;
-    uint32_t kbody, kdir;
+    int phase, a0;
+    bool masked_seen;
     int cx0, cx1, cy0, nrows, row, chunk, prev_rw;       // wave-uniform: cell rectangle, grid rows to scan, position
     int rw, re0, re1, rfe;                               // lane r: grid row (block start + r): cell range lo | hi << 16, entry range, end of its first cell
 };
@@ -681,10 +679,7 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, con
     const MapView &m = a.map;
     const int res = c.res;
     st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map
-    st.a0 = 0; st.f = 0; st.masked_seen = false; st.near = false;
-    st.sx0 = st.sx1 = st.sx2 = st.sx3 = st.sx4 = st.sx5 = st.sx6 = 0.0f;
-    st.sy0 = st.sy1 = st.sy2 = st.sy3 = st.sy4 = st.sy5 = st.sy6 = 0.0f;
-    st.kbody = st.kdir = 0;
+    st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
     if (m.nx > 0 && !(c.debug & 1)) {
@@ -724,51 +719,41 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
     key = 0;
     if (st.phase == 0) {
         // actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3],[1,3,2] (body), [4,5,6] (direction).
-        // Agents are dealt to the 4 waves (agent = 4*lane + wave) and culled by distance before anything else is loaded.
-        if (st.f == 0) {
-            const float view_r = 1.05f * 1.41421356f / c.scale;            // half diagonal of the trim polygon
-            int ag = st.a0 + lane * NW + wave;
-            st.near = false;
-            if (ag < a.N) {
-                int64_t ia = b * a.N + ag;
-                bool on = a.mask[img * a.N + ag] != 0;
-                st.masked_seen = st.masked_seen || !on;
-                if (on) {
-                    float4 s = a.state[ia];
-                    float2 t0 = a.tmpl[ia * 7];                          // (l/2, w/2): the farthest template vertex
-                    float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y);
-                    reach = reach * 1.01f + 0.01f;
-                    float ddx = s.x - cam.cx, ddy = s.y - cam.cy;
-                    st.near = !(ddx * ddx + ddy * ddy > reach * reach);  // NaNs are kept
-                    if (st.near) {
-                        float2 sc = a.agent_sc[ia];
-                        const int64_t ik = a.key_per_cam ? img * a.N + ag : ia;
-                        st.kbody = a.actor_key[2 * ik]; st.kdir = a.actor_key[2 * ik + 1];
+        // One lane per (agent, face): 21 agents per wave and step (lane 63 idles), dealt round-robin to the cooperating waves;
+        // agents are culled by distance before anything else is loaded.
+        const int slot = lane / 3, f = lane - 3 * slot;
+        const int ag = st.a0 + slot * NW + wave;
+        if (lane < 63 && ag < a.N) {
+            const int64_t ia = b * a.N + ag;
+            const bool on = a.mask[img * a.N + ag] != 0;
+            st.masked_seen = st.masked_seen || !on;
+            if (on) {
+                const float view_r = 1.05f * 1.41421356f / c.scale;        // half diagonal of the trim polygon
+                const float4 s = a.state[ia];
+                const float2 t0 = a.tmpl[ia * 7];                          // (l/2, w/2): the farthest template vertex
+                float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y);
+                reach = reach * 1.01f + 0.01f;
+                const float ddx = s.x - cam.cx, ddy = s.y - cam.cy;
+                if (!(ddx * ddx + ddy * ddy > reach * reach)) {            // NaNs are kept
+                    const int64_t ik = a.key_per_cam ? img * a.N + ag : ia;
+                    key = a.actor_key[2 * ik + (f == 2 ? 1 : 0)];
+                    if (key != 0u) {                                       // key 0: the part does not exist
+                        const float2 sc = a.agent_sc[ia];
+                        const int v0 = f == 0 ? 0 : (f == 1 ? 1 : 4), v1 = f == 0 ? 1 : (f == 1 ? 3 : 5), v2 = f == 0 ? 3 : (f == 1 ? 2 : 6);
+                        const float2 ta = a.tmpl[ia * 7 + v0], tb = a.tmpl[ia * 7 + v1], tc = a.tmpl[ia * 7 + v2];
                         // utils.transform :82-96, then mesh.translate(-cameras.xy) cv2.py:29-31
-#define TDS_ACTOR_VERT(K)                                                                                                          \
-    { float2 t = a.tmpl[ia * 7 + K];                                                                                               \
-      st.sx##K = ((sc.y * t.x + (-sc.x) * t.y) + s.x) + (-cam.cx); st.sy##K = ((sc.x * t.x + sc.y * t.y) + s.y) + (-cam.cy); }
-                        TDS_ACTOR_VERT(0) TDS_ACTOR_VERT(1) TDS_ACTOR_VERT(2) TDS_ACTOR_VERT(3) TDS_ACTOR_VERT(4) TDS_ACTOR_VERT(5) TDS_ACTOR_VERT(6)
-#undef TDS_ACTOR_VERT
+                        const float fx[3] = {((sc.y * ta.x + (-sc.x) * ta.y) + s.x) + (-cam.cx), ((sc.y * tb.x + (-sc.x) * tb.y) + s.x) + (-cam.cx),
+                                             ((sc.y * tc.x + (-sc.x) * tc.y) + s.x) + (-cam.cx)};
+                        const float fy[3] = {((sc.x * ta.x + sc.y * ta.y) + s.y) + (-cam.cy), ((sc.x * tb.x + sc.y * tb.y) + s.y) + (-cam.cy),
+                                             ((sc.x * tc.x + sc.y * tc.y) + s.y) + (-cam.cy)};
+                        acc = trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
+                        edges = edge_mask(f == 1 ? 2u : 0u, ins);      // body faces [0,1,3] and [1,3,2] share the edge 1-3 (edge 1 of the second)
                     }
                 }
             }
-            if (__ballot(st.near) == 0) st.f = 3;                        // nobody in sight: skip the three faces
         }
-        if (st.f < 3) {
-            const int f = st.f;
-            float fx[3] = {f == 0 ? st.sx0 : (f == 1 ? st.sx1 : st.sx4), f == 0 ? st.sx1 : (f == 1 ? st.sx3 : st.sx5), f == 0 ? st.sx3 : (f == 1 ? st.sx2 : st.sx6)};
-            float fy[3] = {f == 0 ? st.sy0 : (f == 1 ? st.sy1 : st.sy4), f == 0 ? st.sy1 : (f == 1 ? st.sy3 : st.sy5), f == 0 ? st.sy3 : (f == 1 ? st.sy2 : st.sy6)};
-            key = f == 2 ? st.kdir : st.kbody;
-            acc = st.near && key != 0u && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);      // key 0: the part does not exist
-            edges = edge_mask(f == 1 ? 2u : 0u, ins);      // body faces [0,1,3] and [1,3,2] share the edge 1-3 (edge 1 of the second)
-            ++st.f;
-        }
-        if (st.f >= 3) {
-            st.f = 0;
-            st.a0 += 64 * NW;
-            if (st.a0 >= a.N) st.phase = 1;
-        }
+        st.a0 += 21 * NW;
+        if (st.a0 >= a.N) st.phase = 1;
         return true;
     }
     if (st.phase == 1) {
