@@ -91,6 +91,11 @@ __device__ inline void make_polygon(Camera &cam, float scale, int res) {
         cam.px[k] = mx + (cam.px[k] - mx) * 1.05f;
         cam.py[k] = my + (cam.py[k] - my) * 1.05f;
     }
+    // the camera is the same for the whole workgroup: keep it in scalar registers (the values were computed on the vector ALU)
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cam.px[k] = uni(cam.px[k]); cam.py[k] = uni(cam.py[k]); }
+    cam.cx = uni(cam.cx); cam.cy = uni(cam.cy); cam.s = uni(cam.s); cam.c = uni(cam.c);
 }
 
 // utils.is_inside_polygon :99-122
