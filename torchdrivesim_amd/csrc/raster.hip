@@ -1551,7 +1551,7 @@ constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename 
 
 // one workgroup per (camera, strip); for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
 template <int BWAVES, int NB, typename OutT>
-__global__ void __launch_bounds__(BWAVES * 64, 4) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
+__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
