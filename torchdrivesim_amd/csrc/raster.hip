@@ -629,6 +629,10 @@ struct ScanState {
     bool masked_seen;
     int cx0, cx1, cy0, nrows, row, chunk, prev_rw;       // wave-uniform: cell rectangle, grid rows to scan, position
     int rw, re0, re1, rfe;                               // lane r: grid row (block start + r): cell range lo | hi << 16, entry range, end of its first cell
+    // the chunk of entries in flight (scan_fetch): this lane's entry index (-1: none) and data, uniform facts about its grid row
+    bool have, cur_top;
+    int cur_i, cur_fe, cur_pw;
+    uint4 pu0, pu1;
 };
 
 // Lane r prepares grid row `row0 + r` of the scan: the cells of that row under the window polygon (the pixel window plus a 2 px
@@ -687,6 +691,8 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, con
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
+    st.have = false; st.cur_top = false; st.cur_i = -1; st.cur_fe = 0; st.cur_pw = SCAN_EMPTY_ROW;
+    st.pu0 = st.pu1 = make_uint4(0, 0, 0, 0);
     if (m.nx > 0 && !(c.debug & 1)) {
         // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell rectangle
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
@@ -709,6 +715,36 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, con
         st.nrows = (st.cx0 <= st.cx1 && st.cy0 <= cy1) ? __builtin_amdgcn_readfirstlane(cy1 - st.cy0 + 1) : 0;
         if (st.nrows > 0) scan_load_rows(st, m, c, cam, lane, X0, TWw, 0);
     }
+}
+
+// Move to the next chunk of map entries (if any) and request this lane's entry of it.
+template <int NW>
+__device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, const CommonArgs &c, const Camera &cam, int lane, int X0, int TWw) {
+    while (st.row < st.nrows) {
+        const int rl = st.row & 63;
+        const int e0 = __builtin_amdgcn_readlane(st.re0, rl), e1 = __builtin_amdgcn_readlane(st.re1, rl);
+        const int nchunks = (e1 - e0 + 63) >> 6;
+        if (st.chunk < nchunks) {
+            st.cur_fe = __builtin_amdgcn_readlane(st.rfe, rl);
+            st.cur_pw = rl > 0 ? __builtin_amdgcn_readlane(st.rw, rl > 0 ? rl - 1 : 0) : st.prev_rw;     // cell range of the row above
+            st.cur_top = st.row == 0;
+            const int i = e0 + st.chunk * 64 + lane;
+            st.cur_i = i < e1 ? i : -1;
+            if (i < e1) {
+                const uint4 *ep = (const uint4 *)(m.entries + i);
+                st.pu0 = ep[0]; st.pu1 = ep[1];
+            }
+            st.chunk += NW;
+            return true;
+        }
+        st.chunk -= nchunks;
+        ++st.row;
+        if ((st.row & 63) == 0 && st.row < st.nrows) {            // more than 64 grid rows: prepare the next block
+            st.prev_rw = __builtin_amdgcn_readlane(st.rw, 63);
+            scan_load_rows(st, m, c, cam, lane, X0, TWw, st.row);
+        }
+    }
+    return false;
 }
 
 // one producer step: at most one candidate face per lane; returns false when the producer is exhausted
@@ -777,44 +813,34 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
         return true;
     }
     // static map: the cells of one grid row under the window are ONE contiguous range of entries; chunks of 64 consecutive
-    // entries are dealt round-robin to the waves
-    while (st.row < st.nrows) {
-        const int rl = st.row & 63;
-        const int e0 = __builtin_amdgcn_readlane(st.re0, rl), e1 = __builtin_amdgcn_readlane(st.re1, rl);
-        const int nchunks = (e1 - e0 + 63) >> 6;
-        if (st.chunk < nchunks) {
-            const int first_end = __builtin_amdgcn_readlane(st.rfe, rl);
-            const int pw = rl > 0 ? __builtin_amdgcn_readlane(st.rw, rl > 0 ? rl - 1 : 0) : st.prev_rw;     // cell range of the row above
-            const int plo = pw & 0xffff, phi = pw >> 16;
-            int i = e0 + st.chunk * 64 + lane;
-            if (i < e1) {
-                const uint4 *ep = (const uint4 *)(m.entries + i);
-                uint4 u0 = ep[0], u1 = ep[1];
-                const unsigned own = u1.w;              // see GridEntry::own
-                // Exactly one of the scanned cells emits the face: in its grid row the first scanned cell of the face's bounding
-                // box; among the rows the first one where the bounding box meets the scanned cells (the row above has none).
-                const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
-                const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
-                const bool none_above = !(own & (1u << 27)) || st.row == 0 || bx1 < plo || bx0 > phi;
-                if (first_in_row && none_above) {
-                    float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
-                    float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
-                    key = u1.z;
-                    acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins);
-                    edges = edge_mask(own >> 29, ins);
-                }
+    // entries are dealt round-robin to the waves.  The entries of the NEXT chunk are requested before this one is returned, so
+    // that their latency is hidden behind the rasterisation of the queue.
+    if (!st.have) st.have = scan_fetch<NW>(st, m, c, cam, lane, X0, TWw);
+    if (!st.have) return false;
+    {
+        const int i = st.cur_i;
+        const uint4 u0 = st.pu0, u1 = st.pu1;
+        const int plo = st.cur_pw & 0xffff, phi = st.cur_pw >> 16;
+        const bool top = st.cur_top;
+        const int first_end = st.cur_fe;
+        if (i >= 0) {
+            const unsigned own = u1.w;              // see GridEntry::own
+            // Exactly one of the scanned cells emits the face: in its grid row the first scanned cell of the face's bounding
+            // box; among the rows the first one where the bounding box meets the scanned cells (the row above has none).
+            const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
+            const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
+            const bool none_above = !(own & (1u << 27)) || top || bx1 < plo || bx0 > phi;
+            if (first_in_row && none_above) {
+                float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
+                float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
+                key = u1.z;
+                acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins);
+                edges = edge_mask(own >> 29, ins);
             }
-            st.chunk += NW;
-            return true;
         }
-        st.chunk -= nchunks;
-        ++st.row;
-        if ((st.row & 63) == 0 && st.row < st.nrows) {            // more than 64 grid rows: prepare the next block
-            st.prev_rw = __builtin_amdgcn_readlane(st.rw, 63);
-            scan_load_rows(st, m, c, cam, lane, X0, TWw, st.row);
-        }
+        st.have = scan_fetch<NW>(st, m, c, cam, lane, X0, TWw);
     }
-    return false;
+    return true;
 }
 
 // Fused single-pass kernel: one workgroup per (camera, strip); every strip scans the grid itself.  Used when the caller
