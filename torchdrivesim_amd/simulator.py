@@ -371,6 +371,20 @@ class Simulator:
     def get_all_agent_state(self) -> Tensor:
         return self.get_state() if self.npc_count == 0 else torch.cat([self.get_state(), self.get_npc_state()], dim=-2)
 
+    def _heading_sc(self) -> Tensor:
+        """[sin psi, cos psi] of ALL agents, computed once per state tensor and shared by render / collision / off-road (each of them
+        would otherwise launch its own sin and cos).  Not cached when gradients are being recorded."""
+        state = self.get_all_agent_state()
+        if state.requires_grad and torch.is_grad_enabled():
+            return _ops.heading_sc(state[..., 2])
+        key = (state.data_ptr(), state._version, tuple(state.shape), str(state.device)) if self.npc_count == 0 else None
+        cached = getattr(self, '_sc_cache', None)
+        if key is not None and cached is not None and cached[0] == key:
+            return cached[1]
+        sc = _ops.heading_sc(state[..., 2].detach())
+        self._sc_cache = (key, sc)
+        return sc
+
     def get_all_agent_size(self) -> Tensor:
         return self.get_agent_size() if self.npc_count == 0 else torch.cat([self.get_agent_size(), self.get_npc_size()], dim=-2)
 
@@ -525,11 +539,11 @@ class Simulator:
     # ------------------------------------------------------------------------------------------------- rendering
     def render(self, camera_xy: Tensor, camera_psi: Tensor, res: Optional[Resolution] = None, rendering_mask: Optional[Tensor] = None,
                fov: Optional[float] = None, waypoints: Optional[Tensor] = None, waypoints_rendering_mask: Optional[Tensor] = None,
-               custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False) -> Tensor:
+               custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None) -> Tensor:
         """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992)."""
         if waypoints is not None or noisy_perception:
             raise NotImplementedError('waypoints / noisy perception are outside the scope of torchdrivesim_amd')
-        camera_sc = torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
+        camera_sc = _camera_sc if _camera_sc is not None else torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
         if camera_xy.dim() == 2:
             camera_xy, camera_sc = camera_xy.unsqueeze(1), camera_sc.unsqueeze(1)
         n_cam = camera_xy.shape[-2]
@@ -551,7 +565,7 @@ class Simulator:
                 state = torch.cat([state, ctrl['state'].to(state.dtype)], dim=1)
                 tmpl_all = torch.cat([tmpl_all, ctrl['tmpl'].to(tmpl_all.dtype)], dim=1)
                 mask = torch.cat([mask, torch.ones(mask.shape[:-1] + (ctrl['state'].shape[1],), dtype=torch.bool, device=mask.device)], dim=-1)
-            agent_sc = _ops.heading_sc(state[..., 2])
+            agent_sc = self._heading_sc() if (ctrl is None and not diff) else _ops.heading_sc(state[..., 2])
             out = []
             for i_map, ((smap, b), keys, ktab) in enumerate(zip(scene['maps'], scene['keys'], scene['key_tables'])):
                 sl = slice(None) if b is None else slice(b, b + 1)
@@ -591,8 +605,11 @@ class Simulator:
             # the reference builds eye(2) here regardless of A; the intended eye(A) over all agents is used
             A, total = self.agent_count, self.agent_count + self.npc_count
             rendering_mask = torch.eye(A, total, dtype=torch.bool, device=state.device).unsqueeze(0).expand(self.batch_size, -1, -1)
+        cam_sc = None
+        if ego_rotate and not (state.requires_grad and torch.is_grad_enabled()):
+            cam_sc = self._heading_sc()[..., :self.agent_count, :]          # the cameras ARE the exposed agents
         return self.render(camera_xy, camera_psi, rendering_mask=rendering_mask, res=res, fov=fov, custom_agent_colors=custom_agent_colors,
-                           noisy_perception=noisy_perception)
+                           noisy_perception=noisy_perception, _camera_sc=cam_sc)
 
     # ------------------------------------------------------------------------------------------------- infractions
     def compute_offroad(self) -> Tensor:
@@ -604,10 +621,12 @@ class Simulator:
         from torchdrivesim_amd.infractions import _static_maps_for
         maps = _static_maps_for(self.road_mesh, state.device)      # geometry-only device map(s), cached on the mesh
         size, present = self.get_agent_size(), self.get_present_mask()
+        sc_all = None if (state.requires_grad and torch.is_grad_enabled()) else self._heading_sc()[..., :self.agent_count, :]
         out = []
         for smap, b in maps:
             sl = slice(None) if b is None else slice(b, b + 1)
-            out.append(_ops.offroad(smap, state[sl], size[sl], threshold=self.cfg.offroad_threshold, present=present[sl]))
+            out.append(_ops.offroad(smap, state[sl], size[sl], threshold=self.cfg.offroad_threshold, present=present[sl],
+                                    sc=None if sc_all is None else sc_all[sl]))
         return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 
     def compute_wrong_way(self) -> Tensor:
@@ -643,7 +662,10 @@ class Simulator:
         if A == 0:
             return torch.zeros_like(self.get_state()[..., 0])
         if metric in (CollisionMetric.iou, CollisionMetric.discs):
-            return _ops.collision(self._all_boxes(), self._collision_mask(agent_types), n_exposed=A, metric=metric.value)
+            boxes = self._all_boxes()
+            # a NaN heading is scrubbed inside the kernel, so the shared [sin, cos] of the raw headings serves the IoU metric
+            sc = self._heading_sc() if (metric == CollisionMetric.iou and not (boxes.requires_grad and torch.is_grad_enabled())) else None
+            return _ops.collision(boxes, self._collision_mask(agent_types), n_exposed=A, metric=metric.value, sc=sc)
         if metric == CollisionMetric.nograd:
             assert agent_types is None, 'The argument `agent_types` is not supported by the selected collision metric.'
             # count of other present exposed agents whose rectangle overlaps (simulator.py:1111-1149, shapely); here the
