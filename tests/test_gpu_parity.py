@@ -354,6 +354,29 @@ def test_k3_large_resolutions_use_strips(ops, oracle, town, res):
     assert (ref > 0).mean() > 0.05
 
 
+def test_k3_faces_far_outside_the_packed_coordinate_range(ops, oracle):
+    """a ground quad of 1 km seen at 51 px / m puts its vertices 25 000 pixels away from the image: such faces cannot be packed into
+    16-bit coordinates and take the sequential exact path (fill_generic / fill_generic_bits), on every kernel family"""
+    verts = np.array([[-500, -500], [500, -500], [500, 500], [-500, 500], [3, 3], [400, 3.5], [400, 9]], np.float32)
+    faces = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6]], np.int32)
+    vc = np.array([0, 0, 0, 0, 1, 1, 1], np.int64)
+    cats = ['road', 'left_lane']
+    smap = make_map(ops, verts, faces, vc, cats)
+    static = oracle_static(oracle, verts, faces, vc, cats)
+    state = np.array([[[1.0, 2.0, 0.4, 0.0], [4.0, -1.0, 2.0, 0.0]]], np.float32)
+    size = np.array([[[4.5, 2.0], [4.5, 2.0]]], np.float32)
+    mask = np.ones((1, 2, 2), bool)
+    cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
+    for ws, bits in ((True, True), (True, False), (False, False)):
+        ops.use_workspace, ops.use_bitplanes = ws, bits
+        try:
+            img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 5.0, 256)
+        finally:
+            ops.use_workspace, ops.use_bitplanes = True, True
+        assert not (img != ref).any(), f'workspace={ws} bitplanes={bits}: {(img != ref).sum()} values differ'
+    assert len(np.unique(ref.reshape(-1, 3, 256 * 256).transpose(0, 2, 1).reshape(-1, 3), axis=0)) >= 3
+
+
 def test_k3_generic_mesh_path(ops, oracle, town):
     """BirdviewRenderer.render_rgb_mesh on an explicit per-camera RGB mesh (the reference's own dataflow)."""
     g = load_golden('g45_mesh_preraster.npz')

@@ -3,16 +3,20 @@
 // which concatenates the WHOLE static map per camera) -> BirdviewRenderer.render_frame (rendering/base.py:167-204) ->
 // CV2Renderer.render_rgb_mesh (rendering/cv2.py:27-70: shift, trim, z-sort, project + int truncation, cv2.fillConvexPoly).
 //
-// Design (gfx950): one 256-thread workgroup owns a strip of TW image rows-of-the-output (OpenCV x range) of one camera.
-// The strip lives in LDS as one packed u32 per pixel: key = rank << 24 | 0x00RRGGBB, where rank orders rendering
-// levels (painter order: lower level drawn later = larger rank).  Painting = ds_max_u32, so the result is independent
-// of the order in which faces are processed.  Candidate faces come from the map's uniform grid (only the cells under
-// the strip are scanned), pass the reference's trim test, are projected with the reference's fp32 operation order and
-// truncated to int; survivors are compacted into a per-wave LDS queue and rasterised 64 at a time with the work split
-// per (face,row) and per (face,outline edge) across the wave.  The fill reproduces OpenCV's FillConvexPoly + 8-connected
-// Line + clipLine in closed form (16.16 fixed-point edge stepping; see oracle/tds_oracle.c for the restatement).
-// Finally the strip is converted and streamed to HBM as a flat, fully coalesced copy (the LDS layout [x][y] IS the
-// output layout out[img][ch][x][y]).  Roofline: HBM write, 3*H*W*4 B per camera (fp32) -- DESIGN.md.
+// Common to every path (gfx950): candidate faces come from the map's uniform grid (only the cells under the view are scanned) and
+// from the actors' templates, pass the reference's trim test, are projected with the reference's fp32 operation order and truncated
+// to int; survivors are compacted into a per-wave LDS queue and rasterised 64 at a time.  The fill reproduces OpenCV's
+// FillConvexPoly + 8-connected Line + clipLine in closed form (16.16 fixed-point edge stepping; oracle/tds_oracle.c restates it
+// sequentially).  "Later wins" of the painter's algorithm is made order-independent: key = rank << 24 | 0x00RRGGBB, where rank orders
+// the rendering levels (lower level drawn later = larger rank).
+//
+// Two families of kernels, same pixels:
+//   * bit planes (the fast path, second half of this file): one bit per pixel and key in LDS, a whole camera per workgroup,
+//     spans painted with ds_or_b32, the planes resolved and streamed out at the end;
+//   * packed keys (any number of keys): a strip of TW output rows as one u32 per pixel in LDS, painted with ds_max_u32 -- fused
+//     (every strip scans the grid) or binned (K3a bins faces per strip, K3b rasterises the lists) -- and the generic kernel for an
+//     explicit per-camera RGB mesh.
+// Roofline: HBM write, 3*H*W*4 B per camera (fp32) -- DESIGN.md.
 #include "tds_common.h"
 #include <type_traits>
 
