@@ -172,7 +172,7 @@ int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
  * (rendering/pytorch3d.py:57-119) for policy learning through the renderer.
  *   image, grad_out  B x Nc x 3 x H x W float32: the forward output (TDS_OUT_F32) and the incoming gradient
  *   grad_agent       B x Nc x N x 4   [d/dx, d/dy, d/dsin(psi), d/dcos(psi)] of actor n as seen by camera c (caller sums over c)
- *   grad_cam         B x Nc x 4       [d/dcx, d/dcy, d/dsin, d/dcos] of the camera, through the actors' outlines only
+ *   grad_cam         B x Nc x 4       [d/dcx, d/dcy, d/dsin, d/dcos] of the camera: every colour boundary of the image moves with it
  * Both outputs are overwritten. */
 int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                              const float *cam_sc, const float *image, const float *grad_out, int64_t B, int64_t Nc, int64_t N,

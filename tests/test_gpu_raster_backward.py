@@ -9,6 +9,7 @@ from test_gpu_parity import DEV, actor_keys, dev, make_map
 pytestmark = pytest.mark.gpu
 
 SIDE_IN, SIDE_OUT = 0.25, 1.25
+MAP_VC, MAP_CATS = np.array([0] * 4 + [1] * 4 + [2] * 4, np.int64), ['road', 'left_lane', 'right_lane']
 
 
 @pytest.fixture(scope='module')
@@ -65,16 +66,26 @@ def numpy_backward(state, sc, tmpl, mask, cam_xy, cam_sc, image, gout, fov, res)
                         A0 += D * dl * (1 - u)
                         A1 += D * dl * u
                     nM = lambda qx, qy: -k * (n[0] * (cc * qx + cs * qy) + n[1] * (-cs * qx + cc * qy))
-                    T, V = A0 * t[ia] + A1 * t[ib], A0 * va + A1 * vb
+                    T = A0 * t[ia] + A1 * t[ib]
                     g = np.array([(A0 + A1) * nM(1, 0), (A0 + A1) * nM(0, 1), nM(-T[1], T[0]), nM(T[0], T[1])])
                     g_agent[b, c, j] += g
-                    g_cam[b, c] += [-g[0], -g[1], -k * (n[0] * V[1] - n[1] * V[0]), -k * (n[0] * V[0] + n[1] * V[1])]
+            # camera: every colour boundary of the image moves rigidly (neighbouring pixel pairs)
+            ii, jj = np.meshgrid(np.arange(res, dtype=np.float64), np.arange(res, dtype=np.float64), indexing='ij')
+            Dx = (0.5 * (G[:, :-1] + G[:, 1:]) * (I[:, 1:] - I[:, :-1])).sum(0)           # pairs (i, j) - (i + 1, j)
+            Dy = (0.5 * (G[:, :, :-1] + G[:, :, 1:]) * (I[:, :, 1:] - I[:, :, :-1])).sum(0)
+            dxx, dyx = ii[1:] - half, jj[1:] + 0.5 - half
+            dxy, dyy = ii[:, 1:] + 0.5 - half, jj[:, 1:] - half
+            Sx, Sy = Dx.sum(), Dy.sum()
+            Cc = (Dx * (cc * dxx - cs * dyx)).sum() + (Dy * (cs * dxy + cc * dyy)).sum()
+            Cs = (Dx * (cs * dxx + cc * dyx)).sum() - (Dy * (cc * dxy - cs * dyy)).sum()
+            g_cam[b, c] = [-k * (cc * Sx - cs * Sy), -k * (cs * Sx + cc * Sy), -Cs, -Cc]
     return g_agent, g_cam
 
 
 def scene(gen, B=2, N=5, Nc=3, big=False):
-    verts = np.array([[-60, -60], [60, -60], [60, 60], [-60, 60]], np.float32)
-    faces = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    # a ground quad with two lane stripes on it: the static map has colour boundaries of its own
+    verts = np.array([[-60, -60], [60, -60], [60, 60], [-60, 60], [-60, -7], [60, -5], [60, -1], [-60, -3], [-9, -60], [-2, -60], [4, 60], [-3, 60]], np.float32)
+    faces = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11]], np.int32)
     state = np.concatenate([gen.uniform(-8, 8, (B, N, 2)), gen.uniform(-np.pi, np.pi, (B, N, 1)), gen.uniform(0, 5, (B, N, 1))], -1).astype(np.float32)
     size = (np.array([12.0, 3.0]) if big else np.array([4.5, 2.0])) * gen.uniform(0.9, 1.1, (B, N, 2))
     cam_xy = gen.uniform(-3, 3, (B, Nc, 2)).astype(np.float32)
@@ -105,7 +116,7 @@ def render(ops, smap, oracle, state_t, size, mask, cam_xy_t, cam_sc_t, fov, res,
 def test_kernel_matches_numpy_definition(ops, oracle):
     gen = np.random.default_rng(5)
     verts, faces, state, size, cam_xy, cam_psi, mask = scene(gen)
-    smap = make_map(ops, verts, faces, np.zeros(4, np.int64), ['road'])
+    smap = make_map(ops, verts, faces, MAP_VC, MAP_CATS)
     fov, res = 35.0, 96
     st = dev(state).requires_grad_(True)
     cxy = dev(cam_xy).requires_grad_(True)
@@ -154,7 +165,7 @@ def test_gradient_follows_finite_differences(ops, oracle, param):
     state[0, :, 2] = [0.3, 0.7, 2.1]
     cam_xy[:] = 0.25
     cam_psi[:] = 0.9
-    smap = make_map(ops, verts, faces, np.zeros(4, np.int64), ['road'])
+    smap = make_map(ops, verts, faces, MAP_VC, MAP_CATS)
     fov, res, ss = 35.0, 256, 4
 
     def loss_of(r, state_np, cam_xy_np, cam_psi_np, diff=False):
@@ -182,7 +193,7 @@ def test_gradient_follows_finite_differences(ops, oracle, param):
             vals.append(loss_of(res * ss, s2, c2, p2)[0].item())
         fd[i] = (vals[0] - vals[1]) / (2 * h)
     g = grads[param].cpu().numpy().astype(np.float64)
-    # (the static map here is one uniform quad filling the view, so the camera's whole derivative comes from the actors)
+    # (a camera move shifts the static map as well: its lane stripes contribute to the camera gradient)
     scale = max(np.abs(fd).max(), np.abs(g).max())
     assert scale > 1.0, 'degenerate test'
     assert np.abs(g - fd).max() <= 0.3 * scale, (param, g, fd)

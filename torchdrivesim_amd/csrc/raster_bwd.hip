@@ -12,8 +12,9 @@
 // just inside / just outside the drawn edge, f = the incoming gradient averaged over the same two pixels.  Occlusion needs no special
 // case: where another actor covers the edge both sides show the same colour and the term vanishes.
 // Gradients produced: actor position (x, y) and heading (through [sin, cos], the form the forward consumes) per (camera, actor) --
-// the host sums over cameras -- and camera position / heading through the actors' outlines.  NOT produced: the part of the camera
-// gradient that comes from the static map moving under the camera, and gradients with respect to actor sizes (templates).
+// the host sums over cameras -- and camera position / heading: a camera move shifts the WHOLE image rigidly, so that gradient is the
+// same integral over every colour boundary of the image (neighbouring pixel pairs), static map included.  NOT produced: gradients
+// with respect to actor sizes (templates) and colours.
 #include "tds_common.h"
 
 namespace {
@@ -109,14 +110,10 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
                     auto nM = [&](float qx, float qy) { return -k * (nx * (cc * qx + cs * qy) + ny * (-cs * qx + cc * qy)); };
                     const float At = A0 + A1;
                     const float Tx = A0 * ta.x + A1 * tb.x, Ty = A0 * ta.y + A1 * tb.y;       // weighted template point
-                    const float Vx = A0 * va.x + A1 * vb.x, Vy = A0 * va.y + A1 * vb.y;       // weighted camera-relative point
                     g[0] = At * nM(1.0f, 0.0f);
                     g[1] = At * nM(0.0f, 1.0f);
                     g[2] = nM(-Ty, Tx);                 // d w / d sin_j = (-ty, tx)
                     g[3] = nM(Tx, Ty);                  // d w / d cos_j = ( tx, ty)
-                    gcam[0] -= g[0]; gcam[1] -= g[1];
-                    gcam[2] += -k * (nx * Vy - ny * Vx);        // d p / d sin_c = -k ( vy, -vx)
-                    gcam[3] += -k * (nx * Vx + ny * Vy);        // d p / d cos_c = -k ( vx,  vy)
                 }
             }
         }
@@ -126,6 +123,37 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
             g[q] += __shfl_xor(g[q], 1); g[q] += __shfl_xor(g[q], 2); g[q] += __shfl_xor(g[q], 4);
         }
         if (j < a.N && sub == 0) *(float4 *)(a.grad_agent + (img * a.N + j) * 4) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    // Camera: when the camera moves, EVERYTHING in the image moves rigidly (static map and actors alike), so its gradient is the
+    // same boundary integral taken over every colour boundary of the image, i.e. over neighbouring pixel pairs:
+    //   dL/dtheta = - sum_pairs f (I_B - I_A) (n . dp/dtheta),   dp/dcx = k (cc, -cs),  dp/dcy = k (cs, cc),
+    //   dp/dcos = Rc^T (p - centre),  dp/dsin = (rot -90) of it      (p = -k Rc (w - cam) + centre)
+    {
+        float Sx = 0.0f, Sy = 0.0f, Cc = 0.0f, Cs = 0.0f;
+        for (int idx = tid; idx < res * res; idx += BW_BLOCK) {
+            const int i = idx / res, j = idx - i * res;                       // out[ch][i][j]: i = pixel x, j = pixel y
+            const int64_t o0 = (int64_t)i * res + j;
+            if (i + 1 < res) {
+                const int64_t o1 = o0 + res;
+                float D = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) D += 0.5f * (G[ch * plane + o0] + G[ch * plane + o1]) * (I[ch * plane + o1] - I[ch * plane + o0]);
+                const float dx = (float)(i + 1) - half, dy = (float)j + 0.5f - half;
+                Sx += D; Cc += D * (cc * dx - cs * dy); Cs += D * (cs * dx + cc * dy);
+            }
+            if (j + 1 < res) {
+                const int64_t o1 = o0 + 1;
+                float D = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) D += 0.5f * (G[ch * plane + o0] + G[ch * plane + o1]) * (I[ch * plane + o1] - I[ch * plane + o0]);
+                const float dx = (float)i + 0.5f - half, dy = (float)(j + 1) - half;
+                Sy += D; Cc += D * (cs * dx + cc * dy); Cs += -D * (cc * dx - cs * dy);
+            }
+        }
+        gcam[0] = -k * (cc * Sx - cs * Sy);
+        gcam[1] = -k * (cs * Sx + cc * Sy);
+        gcam[2] = -Cs;
+        gcam[3] = -Cc;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
