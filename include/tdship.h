@@ -97,6 +97,13 @@ int tds_pairwise_overlap_f32(const float *box1, const float *sc1, const float *b
 /* box2corners_th (_iou_utils.py:270-299): box n x 5, sc n x 2 -> corners n x 4 x 2 */
 int tds_box2corners_f32(const float *box, const float *sc, float *corners, int64_t n, void *stream);
 
+/* StandardSensingObservationNoise.get_noisy_present_mask (observation_noise.py:89-132, utils.line_circle_intersection :139-187):
+ *   state B x E x 4 (exposed agents first, then NPCs), size B x E x 2, present B x E uint8
+ *   out   B x A x E uint8: present[b,e] and no other entity o (o != e, o != a) whose disc of radius width/2 touches the segment
+ *         from ego a to entity e */
+int tds_occlusion_mask_f32(const float *state, const float *size, const uint8_t *present, uint8_t *out, int64_t B, int64_t A, int64_t E,
+                           void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Static map handle: triangle mesh + uniform grid, built once per map and per device.
  * Replaces the per-call `mesh.expand(...)` / `RGBMesh.concat([background.expand(Nc), ...])` dataflow of

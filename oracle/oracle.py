@@ -230,6 +230,16 @@ def render_scenes(state, size, mask, cam_xy, cam_sc, sverts, sattrs, sfaces, fov
     return (out, tris, cols, cnt) if record else out
 
 
+def occlusion_mask(state, size, present, n_exposed):
+    """StandardSensingObservationNoise.get_noisy_present_mask: state (B,E,4), size (B,E,2), present (B,E) -> (B,A,E) bool"""
+    state, size = _f(state), _f(size)
+    present = np.ascontiguousarray(present, dtype=np.uint8)
+    B, E = present.shape
+    out = np.zeros((B, int(n_exposed), E), dtype=np.uint8)
+    lib().orc_occlusion_mask(_p(state, c_f), _p(size, c_f), _p(present, c_u8), _p(out, c_u8), _i64(B), _i64(n_exposed), _i64(E))
+    return out.astype(bool)
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(ctypes.c_int(int(n)))
 

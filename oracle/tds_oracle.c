@@ -784,6 +784,46 @@ ORC_API void orc_render_scenes(const float *state, const float *agent_sc, const 
     }
 }
 
+/* ---- observation model -------------------------------------------------------------------------------------------- */
+
+/* utils.line_circle_intersection :139-187: does the segment p1-p2 touch the disc (centre c, radius r)?  One rounding per operation,
+ * sums over the last dimension (2 elements) as x + y. */
+static int line_circle(float p1x, float p1y, float p2x, float p2y, float cx, float cy, float r) {
+    float dx = p2x - p1x, dy = p2y - p1y;
+    float fx = p1x - cx, fy = p1y - cy;
+    float a = dx * dx + dy * dy;
+    float b = 2.0f * (fx * dx + fy * dy);
+    float c = (fx * fx + fy * fy) - (r * r);
+    float disc = b * b - (4.0f * a) * c;
+    int has = disc >= 0.0f;
+    float sq = sqrtf(disc < 0.0f ? 0.0f : disc);                 /* clamp(min=0) keeps NaN */
+    if (disc != disc) sq = disc;
+    float a_safe = (fabsf(a) < (float)1e-8) ? (float)1e-8 : a;
+    float t1 = (-b - sq) / (2.0f * a_safe), t2 = (-b + sq) / (2.0f * a_safe);
+    float tmin = t1 < t2 ? t1 : t2, tmax = t1 > t2 ? t1 : t2;
+    if (t1 != t1 || t2 != t2) { tmin = tmax = t1 + t2; }        /* torch.min / max propagate NaN */
+    return has && (tmin <= 1.0f) && (tmax >= 0.0f);
+}
+
+/* StandardSensingObservationNoise.get_noisy_present_mask, observation_noise.py:89-132.
+ * state B x E x 4 (exposed agents first, then NPCs), size B x E x 2, present B x E; out B x A x E:
+ * out[b,a,e] = present[b,e] and no entity o (o != e, o != a) whose disc of radius width/2 touches the sight line ego_a -> e. */
+ORC_API void orc_occlusion_mask(const float *state, const float *size, const uint8_t *present, uint8_t *out, int64_t B, int64_t A, int64_t E) {
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t a = 0; a < A; ++a)
+            for (int64_t e = 0; e < E; ++e) {
+                const float *ego = state + (b * E + a) * 4, *tg = state + (b * E + e) * 4;
+                int occluded = 0;
+                for (int64_t o = 0; o < E && !occluded; ++o) {
+                    if (o == e || o == a) continue;
+                    const float *oc = state + (b * E + o) * 4;
+                    float r = size[(b * E + o) * 2 + 1] / 2.0f;
+                    occluded = line_circle(ego[0], ego[1], tg[0], tg[1], oc[0], oc[1], r);
+                }
+                out[(b * A + a) * E + e] = (uint8_t)(present[b * E + e] && !occluded);
+            }
+}
+
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -226,3 +226,20 @@ def test_traffic_controls_are_rendered_like_the_reference_mesh(oracle):
     before = sim.render_egocentric(res=Resolution(96, 96), fov=60.0)
     tl.set_state((tl.state + 1) % 3)
     assert (sim.render_egocentric(res=Resolution(96, 96), fov=60.0) != before).any()
+
+
+def test_standard_sensing_occlusion_matches_reference():
+    """tds_occlusion_mask_f32 through StandardSensingObservationNoise / Simulator.get_noisy_present_mask against the reference's
+    masks (g10_observation.npz), and the shape / statistics of the noisy states"""
+    from test_observation import sim_of
+    from torchdrivesim_amd.observation_noise import StandardSensingObservationNoise
+    g = load_golden('g10_observation.npz')
+    for tag in 'abc':
+        sim = sim_of(g, tag, device=DEV, noise=StandardSensingObservationNoise())
+        np.testing.assert_array_equal(sim.get_noisy_present_mask().cpu().numpy(), g[f'{tag}_mask'])
+        ns = sim.get_noisy_state()
+        assert ns.shape == g[f'{tag}_noisy_absolute'].shape[:3] + (4,)
+        A = sim.agent_count
+        idx = torch.arange(A, device=DEV)
+        assert torch.equal(ns[:, idx, idx], sim.get_state())                     # an agent perceives itself exactly (distance 0)
+        assert sim.get_noisy_all_agents_relative().shape[2] == sim.agent_count + sim.npc_count - 1

@@ -64,7 +64,7 @@ def test_out_of_scope_arguments_are_refused():
     with pytest.raises(NotImplementedError):
         Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, waypoint_goals=object())
     with pytest.raises(NotImplementedError):
-        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, observation_noise_model=object())
+        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lane_features=object())
 
 
 def test_kinematic_bookkeeping_and_fit_action():

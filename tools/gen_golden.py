@@ -583,6 +583,42 @@ def gen_traffic(out):
     print('g8 violations per step', [int(d[f'violation_{t}'].sum()) for t in range(T + 2)], 'of', B * A)
 
 
+# --------------------------------------------------------------------------------------
+# G10: observation model for non-visual policies: occlusion mask of StandardSensingObservationNoise, the distance-dependent
+#      standard deviation of its state noise, and get_noisy_all_agents_relative with the noise-free base model
+# --------------------------------------------------------------------------------------
+def gen_observation(out):
+    from torchdrivesim.observation_noise import ObservationNoise, ObservationNoiseConfig, StandardSensingObservationNoise, \
+        StandardSensingObservationNoiseConfig
+    g = seeded(606)
+    d = {}
+    for tag, (B, A, P, spread) in dict(a=(3, 6, 4, 40.0), b=(2, 12, 0, 120.0), c=(2, 1, 5, 30.0)).items():
+        state, size, present = random_scene(g, B, A + P, spread=spread)
+        # put some agents exactly in line behind others (certain occlusions) and two at the same place
+        state[0, 2, :2] = state[0, 0, :2] + 2.0 * (state[0, 1, :2] - state[0, 0, :2])
+        if A + P > 4:
+            state[1, 3, :2] = state[1, 4, :2]
+        npc = dict(state=state[:, A:].clone(), size=size[:, A:].clone(), present=present[:, A:].clone()) if P else None
+        sim = make_sim(state[:, :A].clone(), size[:, :A].clone(), present[:, :A].clone(), npc=npc)
+        std = StandardSensingObservationNoise(StandardSensingObservationNoiseConfig())
+        d[f'{tag}_state'], d[f'{tag}_size'], d[f'{tag}_present'] = npy(state), npy(size), npy(present)
+        d[f'{tag}_n_exposed'] = np.array(A)
+        d[f'{tag}_mask'] = npy(std.get_noisy_present_mask(sim))
+        # the deterministic part of get_noisy_state: standard deviation per (ego, entity)
+        torch.manual_seed(0)
+        noisy = std.get_noisy_state(sim)
+        torch.manual_seed(0)
+        base = ObservationNoise(ObservationNoiseConfig()).get_noisy_state(sim)
+        eps = torch.randn_like(base)
+        dev_ = ((noisy - base) / eps)
+        d[f'{tag}_deviation'] = npy(dev_[..., 0])
+        sim.observation_noise_model = ObservationNoise(ObservationNoiseConfig())
+        d[f'{tag}_noisy_relative'] = npy(sim.get_noisy_all_agents_relative())
+        d[f'{tag}_noisy_absolute'] = npy(sim.get_noisy_all_agents_absolute())
+    np.savez_compressed(os.path.join(out, 'g10_observation.npz'), **d)
+    print('g10 occluded fraction', {t: float(1 - d[f'{t}_mask'].mean()) for t in 'abc'})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -601,6 +637,7 @@ def main():
     gen_mesh_and_preraster(args.out, cv2, town)
     gen_grads(args.out, town)
     gen_traffic(args.out)
+    gen_observation(args.out)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

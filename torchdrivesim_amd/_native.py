@@ -35,6 +35,7 @@ _SIGNATURES = {
     'tds_collision_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     'tds_pairwise_overlap_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     'tds_box2corners_f32': [_vp, _vp, _vp, _i64, _vp],
+    'tds_occlusion_mask_f32': [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     'tds_map_create': [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _f32, ctypes.POINTER(_vp)],
     'tds_map_destroy': [_vp],
     'tds_map_info': [_vp, ctypes.POINTER(_i64)],

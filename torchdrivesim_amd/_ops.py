@@ -208,6 +208,18 @@ def box2corners(box, sc=None):
 # ---------------------------------------------------------------------------------------------------------------
 # static map handle, K2b offroad
 # ---------------------------------------------------------------------------------------------------------------
+def occlusion_mask(state, size, present, n_exposed):
+    """StandardSensingObservationNoise.get_noisy_present_mask (observation_noise.py:89-132): state (B,E,4), size (B,E,2),
+    present (B,E) -> (B,A,E) bool, True = present and in line of sight of ego a"""
+    B, E = present.shape
+    state, size = _c(state.detach()), _c(size.detach())
+    p8 = present.contiguous().view(u8) if present.dtype == torch.bool else _c(present, u8)
+    out = torch.empty((B, int(n_exposed), E), dtype=u8, device=state.device)
+    nat.call('tds_occlusion_mask_f32', state.device, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(size, f32, 'size'), nat.dev_ptr(p8, u8, 'present'),
+             nat.dev_ptr(out, u8, 'out'), B, int(n_exposed), E, nat.stream_ptr(state.device))
+    return out.view(torch.bool)
+
+
 def quantise_colors(attrs):
     """cv2.py:50: floor(attr * (1 - 1e-3) * 256) as uint8, packed 0x00RRGGBB.  attrs (...,3) float32 cpu tensor -> int64"""
     q = (attrs.to(f32) * (1.0 - 1e-3) * 256).floor().to(torch.uint8).to(torch.int64)

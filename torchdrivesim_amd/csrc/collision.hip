@@ -385,3 +385,62 @@ TDS_EXPORT int tds_box2corners_f32(const float *box, const float *sc, float *cor
     TDS_LAUNCH_CHECK("box2corners_kernel");
     return TDS_OK;
 }
+
+// -----------------------------------------------------------------------------------------------------------------------------
+// Occlusion mask of the standard sensing model (observation_noise.py:89-132, utils.line_circle_intersection :139-187):
+// entity e is hidden from ego a when the disc (radius = width / 2) of another entity o touches the sight line a -> e.
+// One wave per (scene, ego); lanes = targets, loop over occluders.  Same operation order as the reference, one rounding each.
+// -----------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ bool line_circle(float p1x, float p1y, float p2x, float p2y, float cx, float cy, float r) {
+    float dx = p2x - p1x, dy = p2y - p1y;
+    float fx = p1x - cx, fy = p1y - cy;
+    float a = dx * dx + dy * dy;
+    float b = 2.0f * (fx * dx + fy * dy);
+    float c = (fx * fx + fy * fy) - (r * r);
+    float disc = b * b - (4.0f * a) * c;
+    bool has = disc >= 0.0f;
+    float sq = sqrtf(disc < 0.0f ? 0.0f : disc);
+    if (disc != disc) sq = disc;
+    float a_safe = (fabsf(a) < (float)1e-8) ? (float)1e-8 : a;
+    float t1 = (-b - sq) / (2.0f * a_safe), t2 = (-b + sq) / (2.0f * a_safe);
+    float tmin = t1 < t2 ? t1 : t2, tmax = t1 > t2 ? t1 : t2;
+    if (t1 != t1 || t2 != t2) { tmin = tmax = t1 + t2; }
+    return has && (tmin <= 1.0f) && (tmax >= 0.0f);
+}
+
+__global__ void __launch_bounds__(256) occlusion_kernel(const float4 *__restrict__ state, const float2 *__restrict__ size, const uint8_t *__restrict__ present,
+                                                        uint8_t *__restrict__ out, int64_t n_ego, int A, int E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // (scene, ego)
+    if (w >= n_ego) return;
+    const int64_t b = w / A;
+    const int a = (int)(w - b * A);
+    const float4 ego = state[b * E + a];
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        const int e = e0 + lane;
+        bool occluded = false;
+        float4 tg = e < E ? state[b * E + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 0; o < E; ++o) {                                         // wave-uniform
+            const float4 oc = state[b * E + o];
+            const float r = size[b * E + o].y / 2.0f;
+            if (o != e && o != a && !occluded) occluded = line_circle(ego.x, ego.y, tg.x, tg.y, oc.x, oc.y, r);
+        }
+        if (e < E) out[(b * A + a) * E + e] = (uint8_t)((present[b * E + e] != 0) && !occluded);
+    }
+}
+
+}  // namespace
+
+TDS_EXPORT int tds_occlusion_mask_f32(const float *state, const float *size, const uint8_t *present, uint8_t *out, int64_t B, int64_t A,
+                                      int64_t E, void *stream) {
+    TDS_CHECK_ARG(B >= 0 && A >= 0 && E >= A && E < (1 << 20), "tds_occlusion_mask_f32: bad sizes");
+    if (B * A == 0 || E == 0) return TDS_OK;
+    TDS_CHECK_ARG(state && size && present && out, "tds_occlusion_mask_f32: null pointer");
+    const int64_t n = B * A;
+    hipLaunchKernelGGL(occlusion_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float4 *)state,
+                       (const float2 *)size, present, out, n, (int)A, (int)E);
+    TDS_LAUNCH_CHECK("occlusion_kernel");
+    return TDS_OK;
+}

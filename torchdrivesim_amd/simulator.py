@@ -156,7 +156,7 @@ class Simulator:
                  npc_controller: Optional[NPCController] = None, agent_lr: Optional[Tensor] = None, lane_features=None,
                  observation_noise_model=None, action_model_extras: Optional[Dict[str, Any]] = None):
         for name, val in (('lanelet_map', lanelet_map), ('waypoint_goals', waypoint_goals),
-                          ('lane_features', lane_features), ('observation_noise_model', observation_noise_model)):
+                          ('lane_features', lane_features)):
             if val is not None and not (name == 'lanelet_map' and all(m is None for m in val)):
                 raise NotImplementedError(f'`{name}` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
         self.road_mesh = road_mesh
@@ -169,6 +169,10 @@ class Simulator:
         self.traffic_controls = traffic_controls        # Dict[str, BaseTrafficControl]: state and violations; not rendered by the fused path
         self.waypoint_goals = None
         self.lane_features = None
+        if observation_noise_model is None:
+            from torchdrivesim_amd.observation_noise import ObservationNoise
+            observation_noise_model = ObservationNoise()
+        self.observation_noise_model = observation_noise_model
 
         if not agent_type_names:
             agent_type_names = ['vehicle']
@@ -258,7 +262,8 @@ class Simulator:
             initial_present_mask=self.present_mask, cfg=self.cfg, renderer=self.renderer.copy(), lanelet_map=self.lanelet_map,
             birdview_mesh_generator=self.birdview_mesh_generator.copy(), recenter_offset=self.recenter_offset, internal_time=self.internal_time,
             agent_types=self.agent_type, agent_type_names=self.agent_types, agent_lr=self.agent_lr, npc_controller=self.npc_controller.copy(),
-            traffic_controls={k: v.copy() for k, v in self.traffic_controls.items()} if self.traffic_controls is not None else None)
+            traffic_controls={k: v.copy() for k, v in self.traffic_controls.items()} if self.traffic_controls is not None else None,
+            observation_noise_model=self.observation_noise_model)
         other._scene_cache = self._scene_cache          # static maps are immutable and can be shared
         return other
 
@@ -419,6 +424,47 @@ class Simulator:
                 rel = torch.cat([own, npc], dim=-2)
                 assert rel.shape[-2] == total - 1
         return rel
+
+    # ---- what the exposed agents perceive (simulator.py:663-679, 740-746, 784-821)
+    def get_noisy_state(self) -> Tensor:
+        """BxAx(A+Npc)x4: the state of every agent as perceived by each exposed agent"""
+        return self.observation_noise_model.get_noisy_state(self)
+
+    def get_noisy_agent_size(self) -> Tensor:
+        return self.observation_noise_model.get_noisy_agent_size(self)
+
+    def get_noisy_present_mask(self) -> Tensor:
+        return self.observation_noise_model.get_noisy_present_mask(self)
+
+    def get_noisy_all_agents_absolute(self) -> Tensor:
+        """BxAx(A+Npc)x6 [x, y, psi, length, width, present] in world coordinates, per observer"""
+        return torch.cat([self.get_noisy_state()[..., :3], self.get_noisy_agent_size(), self.get_noisy_present_mask()[..., None]], dim=-1)
+
+    def get_noisy_all_agents_relative(self, exclude_self: bool = True) -> Tensor:
+        """BxAx(A+Npc [-1])x6 in the frame of each observer's OWN perceived pose; `exclude_self` drops the observer from its own list"""
+        ab = self.get_noisy_all_agents_absolute()
+        A, total = self.agent_count, self.agent_count + self.npc_count
+        idx = torch.arange(A, device=ab.device)
+        own = ab[:, idx, idx, :]
+        rel_xy, rel_psi = relative(origin_xy=own[..., :2].unsqueeze(-2), origin_psi=own[..., 2:3].unsqueeze(-2), target_xy=ab[..., :2],
+                                   target_psi=ab[..., 2:3])
+        rel = torch.cat([rel_xy, rel_psi, ab[..., 3:]], dim=-1)
+        if exclude_self:
+            if A == 1:
+                return rel[..., 1:, :]
+            # drop column a of row a without boolean indexing (no device synchronisation): column j of the result is j + (j >= a)
+            col = torch.arange(total - 1, device=ab.device)[None, :] + (torch.arange(total - 1, device=ab.device)[None, :] >= idx[:, None]).long()
+            rel = torch.gather(rel, 2, col[None, :, :, None].expand(rel.shape[0], -1, -1, rel.shape[-1]))
+        return rel
+
+    def get_noisy_traffic_controls(self):
+        return self.observation_noise_model.get_noisy_traffic_controls(self)
+
+    def get_noisy_road_mesh(self):
+        return self.observation_noise_model.get_noisy_road_mesh(self)
+
+    def get_noisy_background_mesh(self):
+        return self.observation_noise_model.get_noisy_background_mesh(self)
 
     def get_traffic_controls(self):
         return self.traffic_controls
