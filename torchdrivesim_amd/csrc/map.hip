@@ -256,16 +256,22 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
         float cd = (ddx * ddx + ddy * ddy) * 0.998f - 1e-3f;
         if (cd >= best) return;
         int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
-        for (int i = s; i < e && best > stop; ++i) {
-            GridEntry ge = m.entries[i];
+        auto consider = [&](const GridEntry &ge) {
             // the face cannot beat `best` if even its bounding box is farther (same safety shrink as for the cell)
             float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
             float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
             float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
-            if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) continue;
+            if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) return;
             float d = tri_d2(px, py, ge);
             best = (d < best) ? d : best;
+        };
+        // four entries in flight at a time: the walk is a chain of dependent loads otherwise
+        int i = s;
+        for (; i + 4 <= e && best > stop; i += 4) {
+            const GridEntry g0 = m.entries[i], g1 = m.entries[i + 1], g2 = m.entries[i + 2], g3 = m.entries[i + 3];
+            consider(g0); consider(g1); consider(g2); consider(g3);
         }
+        for (; i < e && best > stop; ++i) consider(m.entries[i]);
     };
     int k = max(max(0, max(-cx, cx - (m.nx - 1))), max(-cy, cy - (m.ny - 1)));
     for (;; ++k) {
