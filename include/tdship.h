@@ -123,6 +123,13 @@ int tds_map_destroy(tds_map_t *map);
 /* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, reserved */
 int tds_map_info(const tds_map_t *map, int64_t *info);
 
+/* Map sets: batches whose scenes have DIFFERENT meshes (the reference supports them as a collated, padded mesh batch, mesh.py:69,
+ * 113-123).  A set is a device array of the views of several maps of ONE device that were created with the SAME `levels` table; the
+ * maps must outlive the set.  `scene_map` (device, B int32) of the *_multi entry points says which map of the set scene b uses. */
+typedef struct tds_mapset tds_mapset_t;
+int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset_t **out);
+int tds_mapset_destroy(tds_mapset_t *set);
+
 /* ------------------------------------------------------------------------------------------------------------
  * K2b  offroad              simulator.py:1035-1044; infractions.py:86-229 (pure-torch path, squared distances)
  *   state B x A x 4, lenwid B x A x 2, sc B x A x 2 ([sin,cos] of psi), present B x A uint8 or NULL,
@@ -134,6 +141,13 @@ int tds_offroad_f32(const tds_map_t *map, const float *state, const float *lenwi
 int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, const float *lenwid, const float *sc,
                         const uint8_t *present, const float *grad_out, float *grad_state, float *grad_lenwid,
                         float *grad_sc, int64_t n_agents, float threshold, void *stream);
+
+/* the same for scenes with different maps: agent a belongs to scene a / agents_per_scene, which uses map scene_map[scene] of the set */
+int tds_offroad_multi_f32(const tds_mapset_t *set, const int32_t *scene_map, int64_t agents_per_scene, const float *state, const float *lenwid,
+                          const float *sc, const uint8_t *present, float *out, int64_t n_agents, float threshold, void *stream);
+int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map, int64_t agents_per_scene, const float *state,
+                              const float *lenwid, const float *sc, const uint8_t *present, const float *grad_out, float *grad_state,
+                              float *grad_lenwid, float *grad_sc, int64_t n_agents, float threshold, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K3  bird's-eye-view rasteriser, CV2 semantics
@@ -170,6 +184,11 @@ int tds_raster_scene(const tds_map_t *map, const float *state, const float *agen
                      const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc,
                      int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
+/* tds_raster_scene for scenes with different maps: scene b is drawn over map scene_map[b] of the set (one launch for the batch) */
+int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, const float *state, const float *agent_sc, const float *tmpl,
+                           const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc,
+                           int64_t N, float scale, int res, int out_mode, void *out, void *workspace, int64_t workspace_bytes,
+                           const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 

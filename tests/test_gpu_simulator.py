@@ -277,3 +277,20 @@ def test_scenes_with_different_maps(oracle):
         ref_off = oracle.offroad(state[b:b + 1], size[b:b + 1], v, f, threshold=0.5, present=np.ones((1, A), bool), sc=sc[b:b + 1])
         np.testing.assert_allclose(off[b:b + 1], ref_off, rtol=1e-5, atol=1e-6)
     assert (img[0] != img[1]).any()
+    # off-road gradients through the map set equal those through one map per scene
+    from torchdrivesim_amd import _ops
+    st = sim.get_state().detach().clone()
+    st[..., :2] += torch.tensor([30.0, 25.0], device=DEV)             # off the road: non-zero losses
+    sz = sim.get_agent_size()
+    s1 = st.clone().requires_grad_(True)
+    sim.kinematic_model.set_state(s1)
+    loss = sim.compute_offroad()
+    assert (loss > 0).any()
+    loss.sum().backward()
+    for b, m in enumerate((crop, part)):
+        single = _ops.StaticMap(m.verts[0], m.faces[0], device=DEV)
+        s2 = st[b:b + 1].clone().requires_grad_(True)
+        l2 = _ops.offroad(single, s2, sz[b:b + 1], threshold=0.5, present=torch.ones(1, A, dtype=torch.bool, device=DEV))
+        np.testing.assert_allclose(loss[b:b + 1].detach().cpu().numpy(), l2.detach().cpu().numpy(), rtol=1e-6)
+        l2.sum().backward()
+        np.testing.assert_allclose(s1.grad[b:b + 1].cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)

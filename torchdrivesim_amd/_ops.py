@@ -273,6 +273,55 @@ class StaticMap:
             pass
 
 
+class StaticMapSet:
+    """Several StaticMaps of one device (created with the same level table) + which of them every scene of a batch uses: lets one
+    launch serve a batch whose scenes have different meshes (tds_mapset_t).  `scene_map`: (B,) int32 device tensor of indices."""
+
+    def __init__(self, maps, scene_map):
+        assert len(maps) > 0
+        self.maps = list(maps)                       # keeps the maps alive
+        self.device = self.maps[0].device
+        self.levels = self.maps[0].levels
+        self.n_faces = sum(m.n_faces for m in self.maps)
+        self.scene_map = _c(torch.as_tensor(scene_map).to(self.device), i32)
+        arr = (ctypes.c_void_p * len(self.maps))(*[m.handle for m in self.maps])
+        handle = ctypes.c_void_p()
+        nat.call('tds_mapset_create', self.device, arr, len(self.maps), ctypes.byref(handle))
+        self._h = handle
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError('StaticMapSet was destroyed')
+        return self._h
+
+    def rank_of(self, level):
+        return self.maps[0].rank_of(level)
+
+    def select(self, idx):
+        """the same maps for a sub-batch / re-ordered batch"""
+        return StaticMapSet(self.maps, self.scene_map[idx])
+
+    def close(self):
+        if getattr(self, '_h', None) is not None:
+            h, self._h = self._h, None
+            nat.call('tds_mapset_destroy', self.device, h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _agents_per_scene(smap, state):
+    n_scenes = smap.scene_map.shape[0]
+    n = state.numel() // 4
+    if state.dim() < 2 or state.shape[0] != n_scenes or n % n_scenes:
+        raise RuntimeError(f'a StaticMapSet for {n_scenes} scenes needs agent tensors of shape ({n_scenes}, A, ...), got {tuple(state.shape)}')
+    return n // n_scenes
+
+
 def offroad_forward(smap, state, lenwid, sc, present, threshold):
     state, lenwid, sc = _c(state), _c(lenwid), _c(sc)
     n = state.numel() // 4
@@ -280,6 +329,11 @@ def offroad_forward(smap, state, lenwid, sc, present, threshold):
     pres = None
     if present is not None:
         pres = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
+    if isinstance(smap, StaticMapSet):
+        nat.call('tds_offroad_multi_f32', state.device, smap.handle, nat.dev_ptr(smap.scene_map, i32, 'scene_map'), _agents_per_scene(smap, state),
+                 nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(lenwid, f32, 'lenwid'), nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(pres, u8, 'present'),
+                 nat.dev_ptr(out, f32, 'out'), n, float(threshold), nat.stream_ptr(state.device))
+        return out
     nat.call('tds_offroad_f32', state.device, smap.handle, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(lenwid, f32, 'lenwid'),
              nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(pres, u8, 'present'), nat.dev_ptr(out, f32, 'out'), n, float(threshold),
              nat.stream_ptr(state.device))
@@ -304,6 +358,12 @@ class _Offroad(torch.autograd.Function):
         if present is not None:
             pres = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
         gs, gl, gsc = torch.empty_like(state), torch.empty_like(lenwid), torch.empty_like(sc)
+        if isinstance(smap, StaticMapSet):
+            nat.call('tds_offroad_multi_bwd_f32', state.device, smap.handle, nat.dev_ptr(smap.scene_map, i32, 'scene_map'), _agents_per_scene(smap, state),
+                     nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(lenwid, f32, 'lenwid'), nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(pres, u8, 'present'),
+                     nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gs, f32, 'gs'), nat.dev_ptr(gl, f32, 'gl'), nat.dev_ptr(gsc, f32, 'gsc'),
+                     state.numel() // 4, float(threshold), nat.stream_ptr(state.device))
+            return None, gs, gl, gsc, None, None
         nat.call('tds_offroad_bwd_f32', state.device, smap.handle, nat.dev_ptr(state, f32, 'state'), nat.dev_ptr(lenwid, f32, 'lenwid'),
                  nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(pres, u8, 'present'), nat.dev_ptr(gout, f32, 'grad_out'), nat.dev_ptr(gs, f32, 'gs'),
                  nat.dev_ptr(gl, f32, 'gl'), nat.dev_ptr(gsc, f32, 'gsc'), state.numel() // 4, float(threshold), nat.stream_ptr(state.device))
@@ -373,7 +433,11 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     if raster_events is not None:          # bench.py: HIP events on the launch stream, right around the kernel
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(dev))
-    nat.call('tds_raster_scene', dev, smap.handle, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
+    multi = isinstance(smap, StaticMapSet)
+    if multi and smap.scene_map.shape[0] != B:
+        raise RuntimeError(f'the StaticMapSet is for {smap.scene_map.shape[0]} scenes, the cameras for {B}')
+    head = ('tds_raster_scene_multi', dev, smap.handle, nat.dev_ptr(smap.scene_map, i32, 'scene_map')) if multi else ('tds_raster_scene', dev, smap.handle)
+    nat.call(*head, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
              p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
              B, Nc, N, float(2.0 / fov), int(res), mode, nat.dev_ptr(out, out_dtype, 'out'),
              None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(),

@@ -352,11 +352,13 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
 __global__ void __launch_bounds__(GBLOCK) offroad_bwd_kernel(MapView m, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
                                                              const float2 *__restrict__ sc, const uint8_t *__restrict__ present,
                                                              const float *__restrict__ gout, float4 *__restrict__ gstate,
-                                                             float2 *__restrict__ glenwid, float2 *__restrict__ gsc, int64_t n, float threshold) {
+                                                             float2 *__restrict__ glenwid, float2 *__restrict__ gsc, int64_t n, float threshold,
+                                                             const MapView *__restrict__ views, const int32_t *__restrict__ scene_map, int agents_per_scene) {
     int64_t t = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
     int64_t a = t >> 2;
     int k = (int)(t & 3);
     float gx = 0, gy = 0, gl = 0, gw = 0, gs = 0, gc = 0;
+    if (a < n && views != nullptr) m = views[scene_map[a / agents_per_scene]];
     if (a < n && m.n_faces > 0) {
         float go = gout[a] * ((present && !present[a]) ? 0.0f : 1.0f);
         if (go != 0.0f) {
@@ -423,7 +425,23 @@ TDS_EXPORT int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, con
     int64_t threads = n_agents * 4;
     hipLaunchKernelGGL(offroad_bwd_kernel, dim3((unsigned)((threads + GBLOCK - 1) / GBLOCK)), dim3(GBLOCK), 0, (hipStream_t)stream, map->view,
                        (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, grad_out, (float4 *)grad_state,
-                       (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold);
+                       (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)nullptr, (const int32_t *)nullptr, 1);
+    TDS_LAUNCH_CHECK("offroad_bwd_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map, int64_t agents_per_scene, const float *state,
+                                         const float *lenwid, const float *sc, const uint8_t *present, const float *grad_out, float *grad_state,
+                                         float *grad_lenwid, float *grad_sc, int64_t n_agents, float threshold, void *stream) {
+    TDS_CHECK_ARG(set && set->n > 0 && scene_map, "tds_offroad_multi_bwd_f32: null map set or scene index array");
+    TDS_CHECK_ARG(agents_per_scene > 0 && agents_per_scene < (1 << 30), "tds_offroad_multi_bwd_f32: bad number of agents per scene");
+    TDS_CHECK_ARG(n_agents >= 0, "tds_offroad_multi_bwd_f32: bad agent count");
+    if (n_agents == 0) return TDS_OK;
+    TDS_CHECK_ARG(state && lenwid && sc && grad_out, "tds_offroad_multi_bwd_f32: null pointer");
+    int64_t threads = n_agents * 4;
+    hipLaunchKernelGGL(offroad_bwd_kernel, dim3((unsigned)((threads + GBLOCK - 1) / GBLOCK)), dim3(GBLOCK), 0, (hipStream_t)stream, tds::MapView{},
+                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, grad_out, (float4 *)grad_state,
+                       (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)set->d_views, scene_map, (int)agents_per_scene);
     TDS_LAUNCH_CHECK("offroad_bwd_kernel");
     return TDS_OK;
 }

@@ -297,11 +297,13 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
 // one thread per agent corner (4 consecutive lanes = one agent)
 __global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
                                                          const float2 *__restrict__ sc, const uint8_t *__restrict__ present,
-                                                         float *__restrict__ out, int64_t n, float threshold) {
+                                                         float *__restrict__ out, int64_t n, float threshold, const MapView *__restrict__ views,
+                                                         const int32_t *__restrict__ scene_map, int agents_per_scene) {
     int64_t t = (int64_t)blockIdx.x * OBLOCK + threadIdx.x;
     int64_t a = t >> 2;
     int k = (int)(t & 3);
     float v = 0.0f;
+    if (a < n && views != nullptr) m = views[scene_map[a / agents_per_scene]];      // one map per scene (tds_offroad_multi_f32)
     if (a < n && m.n_faces > 0) {
         float4 s = state[a];
         float2 lw = lenwid[a];
@@ -334,7 +336,76 @@ TDS_EXPORT int tds_offroad_f32(const tds_map_t *map, const float *state, const f
     TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_f32: null pointer");
     int64_t threads = n_agents * 4;
     hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, map->view,
-                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold);
+                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold,
+                       (const MapView *)nullptr, (const int32_t *)nullptr, 1);
     TDS_LAUNCH_CHECK("offroad_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_offroad_multi_f32(const tds_mapset_t *set, const int32_t *scene_map, int64_t agents_per_scene, const float *state, const float *lenwid,
+                                     const float *sc, const uint8_t *present, float *out, int64_t n_agents, float threshold, void *stream) {
+    TDS_CHECK_ARG(set && set->n > 0 && scene_map, "tds_offroad_multi_f32: null map set or scene index array");
+    TDS_CHECK_ARG(agents_per_scene > 0 && agents_per_scene < (1 << 30), "tds_offroad_multi_f32: bad number of agents per scene");
+    TDS_CHECK_ARG(n_agents >= 0 && n_agents < ((int64_t)1 << 36), "tds_offroad_multi_f32: bad agent count");
+    if (n_agents == 0) return TDS_OK;
+    TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_multi_f32: null pointer");
+    int64_t threads = n_agents * 4;
+    hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, MapView{},
+                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold,
+                       (const MapView *)set->d_views, scene_map, (int)agents_per_scene);
+    TDS_LAUNCH_CHECK("offroad_kernel");
+    return TDS_OK;
+}
+
+// ---- map sets: device array of the views of several maps, for launches whose scenes have different maps ----------------------------
+TDS_EXPORT int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset_t **out) {
+    TDS_CHECK_ARG(out, "tds_mapset_create: null output");
+    *out = nullptr;
+    TDS_CHECK_ARG(maps && n > 0 && n < (1 << 24), "tds_mapset_create: need at least one map");
+    std::vector<MapView> views((size_t)n);
+    tds_mapset *s = new (std::nothrow) tds_mapset();
+    if (!s) { tds::set_error("tds_mapset_create: out of host memory"); return TDS_ENOMEM; }
+    s->n = n; s->device = maps[0] ? maps[0]->device : 0; s->n_levels = maps[0] ? maps[0]->n_levels : 0; s->n_uniq = 0; s->d_views = nullptr;
+    for (int i = 0; i < n; ++i) {
+        if (!maps[i] || maps[i]->device != s->device || maps[i]->n_levels != s->n_levels) {
+            delete s;
+            tds::set_error("tds_mapset_create: map %d is null, lives on another device or was created with a different level table", i);
+            return TDS_EINVAL;
+        }
+        views[(size_t)i] = maps[i]->view;
+        if (maps[i]->n_uniq < 0) s->n_uniq = -1;
+        for (int k = 0; s->n_uniq >= 0 && k < maps[i]->n_uniq; ++k) {
+            bool seen = false;
+            for (int j = 0; j < s->n_uniq && !seen; ++j) seen = s->uniq_keys[j] == maps[i]->uniq_keys[k];
+            if (seen) continue;
+            if (s->n_uniq == 64) { s->n_uniq = -1; break; }
+            s->uniq_keys[s->n_uniq++] = maps[i]->uniq_keys[k];
+        }
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != s->device) (void)hipSetDevice(s->device);
+    hipError_t e = hipMalloc((void **)&s->d_views, views.size() * sizeof(MapView));
+    if (e == hipSuccess) e = hipMemcpy(s->d_views, views.data(), views.size() * sizeof(MapView), hipMemcpyHostToDevice);
+    if (cur != s->device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) {
+        if (s->d_views) (void)hipFree(s->d_views);
+        delete s;
+        tds::set_error("tds_mapset_create: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
+    }
+    *out = s;
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_mapset_destroy(tds_mapset_t *set) {
+    if (!set) return TDS_OK;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != set->device) (void)hipSetDevice(set->device);
+    hipError_t e = hipFree(set->d_views);
+    if (cur != set->device) (void)hipSetDevice(cur);
+    delete set;
+    if (e != hipSuccess) { tds::set_error("tds_mapset_destroy: hipFree failed"); return TDS_EHIP; }
     return TDS_OK;
 }

@@ -35,7 +35,9 @@ constexpr int NO_SWITCH = 0x7fffffff;
 constexpr int COORD_LIMIT = 16000;                // |pixel coordinate| below this: int16 packing and int32 16.16 slopes are exact
 
 struct SceneArgs {
-    MapView map;
+    MapView map;                // the one map of the launch, or (views != nullptr) ...
+    const MapView *views;       // ... one map per scene: views[scene_map[b]] (tds_raster_scene_multi)
+    const int32_t *scene_map;   // B
     const float4 *state;        // B x N
     const float2 *agent_sc;     // B x N   [sin, cos]
     const float2 *tmpl;         // B x N x 7
@@ -637,6 +639,7 @@ struct ScanState {
     bool have, cur_top;
     int cur_i, cur_fe, cur_pw;
     uint4 pu0, pu1;
+    MapView map;                                         // the map of this camera's scene (wave-uniform)
 };
 
 // Lane r prepares grid row `row0 + r` of the scan: the cells of that row under the window polygon (the pixel window plus a 2 px
@@ -688,8 +691,11 @@ __device__ __forceinline__ void scan_load_rows(ScanState &st, const MapView &m, 
 }
 
 // window = pixel columns [X0, X0 + TWw) of the image (the whole image when binning)
-__device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int lane, int wave, int X0, int TWw) {   // wave = index among the cooperating waves
-    const MapView &m = a.map;
+__device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane, int wave, int X0,
+                                          int TWw) {   // wave = index among the cooperating waves
+    st.map = a.map;
+    if (a.views != nullptr) st.map = a.views[a.scene_map[img / a.Nc]];
+    const MapView &m = st.map;
     const int res = c.res;
     st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map
     st.a0 = 0; st.masked_seen = false;
@@ -755,7 +761,7 @@ __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, cons
 template <int NW = RWAVES>
 __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane,
                                           int wave, int X0, int TWw, bool &acc, uint32_t &key, int (&px)[3], int (&py)[3], unsigned &edges) {
-    const MapView &m = a.map;
+    const MapView &m = st.map;
     unsigned ins = 0;
     edges = 7u;
     const int res = c.res;
@@ -853,7 +859,7 @@ template <int TW, typename OutT>
 __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgs a, CommonArgs c) {
     TDS_RASTER_PROLOGUE()
     ScanState st;
-    scan_init(st, a, c, cam, lane, wave, X0, TW);
+    scan_init(st, a, c, cam, img, lane, wave, X0, TW);
     for (;;) {
         bool acc;
         uint32_t key;
@@ -895,7 +901,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgs a, 
     wave_sync();
     uint4 *mine = lists + (size_t)img * strips * caps;
     ScanState st;
-    scan_init(st, a, c, cam, lane, 0, 0, W);
+    scan_init(st, a, c, cam, img, lane, 0, 0, W);
     for (;;) {
         bool acc;
         uint32_t key;
@@ -936,7 +942,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs 
         }
     } else {
         ScanState st;
-        scan_init(st, a, c, cam, lane, wave, X0, TW);
+        scan_init(st, a, c, cam, img, lane, wave, X0, TW);
         for (;;) {
             bool acc;
             uint32_t key;
@@ -1629,7 +1635,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
     }
     __syncthreads();
     ScanState st;
-    scan_init(st, a, c, cam, lane, wave, X0, TWp);
+    scan_init(st, a, c, cam, img, lane, wave, X0, TWp);
     for (;;) {
         bool acc;
         uint32_t key;
@@ -1783,13 +1789,52 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
     return TDS_OK;
 }
 
+namespace {
+// what the scene kernels need to know about the static map(s) of a launch
+struct MapSource {
+    MapView one;                    // the single map, or ...
+    const MapView *views;           // ... device array of per-scene maps
+    const int32_t *scene_map;       // device, B indices into `views`
+    const uint32_t *uniq_keys;      // host: distinct face keys (union over the maps)
+    int n_uniq;                     // -1: too many for the bit-plane path
+    bool renders;                   // created with rendering data
+};
+int raster_scene_impl(const MapSource &ms, const float *state, const float *agent_sc, const float *tmpl, const uint32_t *actor_key, const uint8_t *mask,
+                      const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out,
+                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
+}  // namespace
+
 TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                                 const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                 int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
                                 int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
     TDS_CHECK_ARG(map, "tds_raster_scene: null map");
+    MapSource ms;
+    ms.one = map->view; ms.views = nullptr; ms.scene_map = nullptr; ms.uniq_keys = map->uniq_keys; ms.n_uniq = map->n_uniq;
+    ms.renders = map->n_levels > 0 || map->view.nx == 0;
+    return raster_scene_impl(ms, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, B, Nc, N, scale, res, out_mode, out, workspace, workspace_bytes,
+                             actor_keys, n_actor_keys, actor_key_per_camera, stream);
+}
+
+TDS_EXPORT int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, const float *state, const float *agent_sc, const float *tmpl,
+                                      const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
+                                      int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
+                                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
+    TDS_CHECK_ARG(set && set->n > 0, "tds_raster_scene_multi: null or empty map set");
+    TDS_CHECK_ARG(scene_map || B == 0, "tds_raster_scene_multi: null scene -> map index array");
+    MapSource ms;
+    ms.one = tds::MapView{}; ms.views = set->d_views; ms.scene_map = scene_map; ms.uniq_keys = set->uniq_keys; ms.n_uniq = set->n_uniq;
+    ms.renders = set->n_levels > 0;
+    return raster_scene_impl(ms, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, B, Nc, N, scale, res, out_mode, out, workspace, workspace_bytes,
+                             actor_keys, n_actor_keys, actor_key_per_camera, stream);
+}
+
+namespace {
+int raster_scene_impl(const MapSource &ms, const float *state, const float *agent_sc, const float *tmpl, const uint32_t *actor_key, const uint8_t *mask,
+                      const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out,
+                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
-    TDS_CHECK_ARG(map->n_levels > 0 || map->view.nx == 0, "tds_raster_scene: the map was created without rendering data");
+    TDS_CHECK_ARG(ms.renders, "tds_raster_scene: the map was created without rendering data");
     int64_t n_img = B * Nc;
     int tw = 0;
     int rc = common_checks("tds_raster_scene", n_img, res, out_mode, out, tw);
@@ -1800,13 +1845,13 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene: scale must be positive");
     TDS_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "tds_raster_scene: bad workspace");
     SceneArgs a;
-    a.map = map->view; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
+    a.map = ms.one; a.views = ms.views; a.scene_map = ms.scene_map; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
     a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc; a.key_per_cam = actor_key_per_camera ? 1 : 0;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
     // fastest path: bit planes, when the scene uses at most MAX_KEYS distinct keys and the caller listed the actors' keys
-    if ((N == 0 || (actor_keys && n_actor_keys > 0)) && map->n_uniq >= 0 && !(g_debug & 64)) {
+    if ((N == 0 || (actor_keys && n_actor_keys > 0)) && ms.n_uniq >= 0 && !(g_debug & 64)) {
         KeyTable kt;
         kt.n = 0;
         bool ok = true;
@@ -1815,7 +1860,7 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
             if (kt.n == MAX_KEYS) { ok = false; return; }
             kt.key[kt.n++] = key;
         };
-        for (int i = 0; i < map->n_uniq; ++i) add(map->uniq_keys[i]);
+        for (int i = 0; i < ms.n_uniq; ++i) add(ms.uniq_keys[i]);
         for (int i = 0; i < (N > 0 ? n_actor_keys : 0); ++i) add(actor_keys[i]);
         for (int i = kt.n; i < 16; ++i) kt.key[i] = 0xffffffffu;
         if (ok && kt.n > 0) {
@@ -1881,6 +1926,7 @@ TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const 
     TDS_LAUNCH_CHECK("raster_scene_kernel");
     return TDS_OK;
 }
+}  // namespace
 
 TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces, int64_t n_img, int64_t V, int64_t F,
                                const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,

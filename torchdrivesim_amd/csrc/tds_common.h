@@ -69,6 +69,14 @@ __host__ __device__ inline int cell_coord(float v, float origin, float inv_cell)
 
 }  // namespace tds
 
+// several maps of one device for launches whose scenes have different maps (tds_mapset_create)
+struct tds_mapset {
+    tds::MapView *d_views;      // device array [n]
+    int n, device, n_levels;
+    uint32_t uniq_keys[64];     // union of the maps' distinct face keys
+    int n_uniq;                 // -1: more than 64
+};
+
 struct tds_map {
     tds::MapView view;
     void *d_entries;

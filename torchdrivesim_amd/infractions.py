@@ -53,7 +53,8 @@ def _static_maps_for(mesh: BaseMesh, device) -> List:
     if same:
         maps = [(_ops.StaticMap(verts[0], faces[0], device=device, cell_size=OFFROAD_CELL_SIZE), None)]
     else:
-        maps = [(_ops.StaticMap(verts[b], faces[b], device=device, cell_size=OFFROAD_CELL_SIZE), b) for b in range(B)]
+        per_scene = [_ops.StaticMap(verts[b], faces[b], device=device, cell_size=OFFROAD_CELL_SIZE) for b in range(B)]
+        maps = [(_ops.StaticMapSet(per_scene, torch.arange(B, dtype=torch.int32)), None)]           # one launch for the batch
     try:
         object.__setattr__(mesh, '_tds_offroad_maps', (key, maps))
     except Exception:

@@ -533,7 +533,11 @@ class Simulator:
         if same:
             maps = [(self.renderer.make_static_map(bg[0:1], actor_levels, device=dev), None)]
         else:
-            maps = [(self.renderer.make_static_map(bg[b:b + 1], actor_levels, device=dev), b) for b in range(B)]
+            # scenes with different meshes: one device map per scene, all with the same level table (the union over the batch), served
+            # by ONE launch through a map set
+            all_levels = actor_levels + [float(z) for z in torch.unique(bg.verts[..., 2]).tolist()]
+            per_scene = [self.renderer.make_static_map(bg[b:b + 1], all_levels, device=dev) for b in range(B)]
+            maps = [(_ops.StaticMapSet(per_scene, torch.arange(B, dtype=torch.int32)), None)]
         tmpl = actor_template(sizes).contiguous()                   # B x N x 7 x 2
         keys, key_tables = [], []
         for smap, _ in maps:
