@@ -304,6 +304,68 @@ __global__ void __launch_bounds__(CBLOCK) collision_kernel(const float *__restri
     }
 }
 
+// IoU metric, whole scene per workgroup: most of the A x N pairs are far apart (bounding circles disjoint -> overlap exactly 0, see
+// iou_pair) and every row contains its own box, so instead of running the Rotated-IoU pipeline once per row for a handful of live
+// lanes, the near pairs of the scene are first gathered into an LDS list and then evaluated on full waves.  Same arithmetic per pair
+// and the same summation order per row as collision_kernel.  LDS: boxes N x 6, O = A x N overlaps, the pair list, 4 x scratch.
+__global__ void __launch_bounds__(CBLOCK) collision_scene_iou_kernel(const float *__restrict__ boxes, const float *__restrict__ sc,
+                                                                     const uint8_t *__restrict__ present, float *__restrict__ out,
+                                                                     uint64_t *__restrict__ overlap, int32_t *__restrict__ partner, int A, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int n_near;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x;
+    float *scr = smem + wave * (16 * 64);
+    float *bx = smem + (CBLOCK / 64) * (16 * 64);          // N x 6
+    float *O = bx + N * 6;                                  // A x N
+    uint32_t *list = (uint32_t *)(O + A * N);               // A x N at most
+    if (tid == 0) n_near = 0;
+    for (int j = tid; j < N; j += CBLOCK) {
+        const Box q = load_box(boxes, sc, b * N + j);
+        bx[6 * j] = q.x; bx[6 * j + 1] = q.y; bx[6 * j + 2] = q.l; bx[6 * j + 3] = q.w; bx[6 * j + 4] = q.s; bx[6 * j + 5] = q.c;
+    }
+    __syncthreads();
+    auto box_at = [&](int j) { Box q; q.x = bx[6 * j]; q.y = bx[6 * j + 1]; q.l = bx[6 * j + 2]; q.w = bx[6 * j + 3]; q.s = bx[6 * j + 4]; q.c = bx[6 * j + 5]; return q; };
+    for (int p = tid; p < A * N; p += CBLOCK) {
+        const int i = p / N, j = p - i * N;
+        const Box b1 = box_at(i), b2 = box_at(j);
+        // the test of iou_pair: pairs that fail it have overlap 0 (scrubbed) whatever else happens
+        const float dx = b1.x - b2.x, dy = b1.y - b2.y;
+        const float r1 = 0.5f * sqrtf(b1.l * b1.l + b1.w * b1.w), r2 = 0.5f * sqrtf(b2.l * b2.l + b2.w * b2.w);
+        const float reach = r1 + r2 + 0.05f + 1e-5f * fmaxf(fmaxf(fabsf(b1.x), fabsf(b1.y)), fmaxf(fabsf(b2.x), fabsf(b2.y)));
+        O[p] = 0.0f;
+        if (!(dx * dx + dy * dy > reach * reach)) list[atomicAdd(&n_near, 1)] = (uint32_t)p;
+    }
+    __syncthreads();
+    const int total = n_near;
+    for (int q = tid; q < total; q += CBLOCK) {
+        const int p = (int)list[q], i = p / N, j = p - i * N;
+        const Box b1 = box_at(i), b2 = box_at(j);
+        const Corners c1 = corners_of(b1), c2 = corners_of(b2);
+        float o = iou_pair(b1, c1, b2, c2, scr, lane);
+        O[p] = scrub(o) * (present[b * N + j] ? 1.0f : 0.0f);       // simulator.py:1103-1104
+    }
+    __syncthreads();
+    // sum_j o_ij in index order and max_j (simulator.py:1105-1108), one thread per row
+    for (int i = tid; i < A; i += CBLOCK) {
+        float sum = 0.0f, mx = -__builtin_inff(), best = 0.0f;
+        int arg = -1;
+        uint64_t bits = 0;
+        for (int j = 0; j < N; ++j) {
+            const float o = O[i * N + j];
+            sum = sum + o;
+            mx = fmaxf(mx, o);
+            if (j != i && o > 0.0f) {
+                if (j < 64) bits |= (uint64_t)1 << j;
+                if (o > best) { best = o; arg = j; }
+            }
+        }
+        out[b * A + i] = sum - mx;
+        if (overlap) overlap[b * A + i] = bits;
+        if (partner) partner[b * A + i] = arg;
+    }
+}
+
 template <int METRIC>
 __global__ void __launch_bounds__(CBLOCK) pairwise_kernel(const float *__restrict__ box1, const float *__restrict__ sc1,
                                                           const float *__restrict__ box2, const float *__restrict__ sc2,
@@ -348,6 +410,14 @@ TDS_EXPORT int tds_collision_f32(const float *boxes, const float *sc, const uint
     TDS_CHECK_ARG(boxes && sc && present && out, "tds_collision_f32: null pointer");
     TDS_CHECK_ARG(!overlap || N <= 64, "tds_collision_f32: overlap bit masks need N <= 64 (got %lld)", (long long)N);
     TDS_CHECK_ARG(N <= 8192 && B < 65536 * 32768ll, "tds_collision_f32: N=%lld too large", (long long)N);
+    if (metric == TDS_METRIC_IOU && A * N <= 4096) {
+        // whole scene per workgroup: near pairs gathered first (see collision_scene_iou_kernel)
+        const size_t lds_scene = ((size_t)(CBLOCK / 64) * 16 * 64 + (size_t)N * 6 + 2 * (size_t)A * N) * sizeof(float);
+        hipLaunchKernelGGL(collision_scene_iou_kernel, dim3((unsigned)B), dim3(CBLOCK), lds_scene, (hipStream_t)stream, boxes, sc, present, out,
+                           overlap, partner, (int)A, (int)N);
+        TDS_LAUNCH_CHECK("collision_scene_iou_kernel");
+        return TDS_OK;
+    }
     const int rows_per_block = (CBLOCK / 64) * ROWS_PER_WAVE;
     dim3 grid((unsigned)B, (unsigned)((A + rows_per_block - 1) / rows_per_block));
     size_t lds = (size_t)(CBLOCK / 64) * (16 * 64 + ((N + 63) & ~63)) * sizeof(float);
