@@ -1557,8 +1557,9 @@ __device__ inline void write_out_bits(const uint32_t *planes, const typename Pai
                         for (int ch = 0; ch < 3; ++ch) {
                             const E lo = tab[ch * P + i01], hi = tab[ch * P + i23];
                             char *dst = (char *)(ch == 0 ? ob0 : (ch == 1 ? ob1 : ob2)) + off;
-                            if constexpr (sizeof(OutT) == 4) *(float4 *)dst = make_float4(lo.x, lo.y, hi.x, hi.y);
-                            else *(uint32_t *)dst = lo | (hi << 16);
+                            // streamed out, never read again by this kernel: non-temporal, so that the grid entries keep their place in L2
+                            if constexpr (sizeof(OutT) == 4) { typedef float vf4 __attribute__((ext_vector_type(4))); const vf4 v = {lo.x, lo.y, hi.x, hi.y}; __builtin_nontemporal_store(v, (vf4 *)dst); }
+                            else __builtin_nontemporal_store(lo | (hi << 16), (uint32_t *)dst);
                         }
                     }
                 }
