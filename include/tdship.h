@@ -179,16 +179,22 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  * LDS, a whole camera per workgroup, spans painted with one ds_or.  Same pixels as the other paths.
  *
  * actor_key_per_camera != 0: `actor_key` is B x Nc x N x 2 -- every camera sees its own colours, the fused form of generate()'s
- * custom_agent_colors (mesh.py:1092-1099; only the body faces take the custom colour there). */
+ * custom_agent_colors (mesh.py:1092-1099; only the body faces take the custom colour there).
+ *
+ * extra_tri / extra_key / n_extra: optional per-camera triangles, B x Nc x n_extra x 3 x 2 float32 WORLD coordinates and
+ * B x Nc x n_extra uint32 keys (0 = no triangle) -- the fused form of generate()'s waypoint discs (mesh.py:1120-1145), which differ
+ * from camera to camera.  Their keys must be listed in `actor_keys` for the bit-plane kernel to be used. */
 int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                      const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc,
                      int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                     int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
+                     int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera,
+                     const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream);
 /* tds_raster_scene for scenes with different maps: scene b is drawn over map scene_map[b] of the set (one launch for the batch) */
 int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, const float *state, const float *agent_sc, const float *tmpl,
                            const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc,
                            int64_t N, float scale, int res, int out_mode, void *out, void *workspace, int64_t workspace_bytes,
-                           const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
+                           const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera,
+                           const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream);
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 

@@ -294,3 +294,53 @@ def test_scenes_with_different_maps(oracle):
         np.testing.assert_allclose(loss[b:b + 1].detach().cpu().numpy(), l2.detach().cpu().numpy(), rtol=1e-6)
         l2.sum().backward()
         np.testing.assert_allclose(s1.grad[b:b + 1].cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_waypoint_goals_are_drawn_by_the_fused_path(oracle):
+    """render_egocentric with waypoint goals (simulator.py:1013-1029 -> mesh.py:1120-1145): the fused path draws the discs as per-camera
+    triangles; same pixels as the reference's dataflow (explicit mesh from generate(), render_frame) and as the oracle fed with that mesh,
+    whose call list is pinned to the reference's in tests/test_waypoints.py.  Includes masked waypoints (a dot at the centre of the
+    camera's first waypoint) and a window of collections that runs past the end."""
+    from test_waypoints import sim_with_goals
+    from torchdrivesim_amd.utils import Resolution
+    g = load_golden('g11_waypoints.npz')
+    sim = sim_with_goals(g, device=DEV)
+    s = sim.get_state()
+    B, A = s.shape[:2]
+    mask = sim.get_present_mask()[:, None].expand(B, A, A)
+    cam_sc = torch.stack([torch.sin(s[..., 2]), torch.cos(s[..., 2])], -1)
+    res = Resolution(96, 96)
+    sim.waypoint_goals, goals = None, sim.waypoint_goals
+    plain = sim.render_egocentric(res=res, fov=35.0)
+    sim.waypoint_goals = goals
+    imgs = {}
+    for count in (1, 2):
+        img = imgs[count] = sim.render_egocentric(res=res, fov=35.0, n_subsequent_waypoints=count)
+        assert (img != plain).any()
+        rgb = sim.birdview_mesh_generator.generate(A, agent_state=s[:, None].expand(-1, A, -1, -1), present_mask=mask,
+                                                   waypoints=sim.get_waypoints(count), waypoints_rendering_mask=sim.get_waypoints_mask(count))
+        img2 = sim.renderer.render_frame(rgb, s[..., :2], cam_sc, res=res, fov=35.0).reshape(img.shape)
+        ref = oracle.render_rgb_mesh(rgb.verts.cpu().numpy(), rgb.attrs.cpu().numpy(), rgb.faces.cpu().numpy().astype(np.int32),
+                                     s[..., :2].reshape(-1, 2).cpu().numpy(), cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / 35.0, 96)
+        ref = np.transpose(ref, (0, 3, 1, 2)).reshape(img.shape)
+        np.testing.assert_array_equal(img2.cpu().numpy(), ref)
+        np.testing.assert_array_equal(img.cpu().numpy(), ref)
+        wp_col = torch.tensor([139.0, 64.0, 0.0], device=DEV).view(1, 1, 3, 1, 1)
+        assert int((img == wp_col).all(2).sum()) > 50
+    # explicit waypoints through render(), without a rendering mask, on the packed-key kernels too (no key table -> no bit planes)
+    from torchdrivesim_amd import _ops
+    wp = sim.get_waypoints(1)
+    a = sim.render(s[..., :2], s[..., 2:3], res=res, fov=35.0, waypoints=wp)
+    _ops.use_bitplanes = False
+    try:
+        b = sim.render(s[..., :2], s[..., 2:3], res=res, fov=35.0, waypoints=wp)
+    finally:
+        _ops.use_bitplanes = True
+    assert torch.equal(a, b) and (a != plain).any()
+    # the differentiable wrapper carries the discs along
+    st = s.detach().clone().requires_grad_(True)
+    sim.kinematic_model.set_state(st)
+    c = sim.render_egocentric(res=res, fov=35.0)
+    assert c.requires_grad and torch.equal(c.detach(), imgs[1])
+    c.sum().backward()
+    assert torch.isfinite(st.grad).all()

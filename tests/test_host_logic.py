@@ -62,7 +62,7 @@ def test_out_of_scope_arguments_are_refused():
     from torchdrivesim_amd.simulator import Simulator
     sim = make_sim()
     with pytest.raises(NotImplementedError):
-        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, waypoint_goals=object())
+        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lanelet_map=[object(), object()])
     with pytest.raises(NotImplementedError):
         Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lane_features=object())
 

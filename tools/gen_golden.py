@@ -619,9 +619,85 @@ def gen_observation(out):
     print('g10 occluded fraction', {t: float(1 - d[f'{t}_mask'].mean()) for t in 'abc'})
 
 
+# --------------------------------------------------------------------------------------
+# G11: waypoint goals ("waypoint meshes in the renderer"): WaypointGoal bookkeeping over a trajectory, the disc mesh,
+#      generate() with per-camera waypoints, and the call list of render_egocentric with waypoint goals at the OpenCV boundary
+# --------------------------------------------------------------------------------------
+def gen_waypoints(out, cv2, town):
+    from torchdrivesim.goals import WaypointGoal
+    from torchdrivesim.mesh import BirdviewRGBMeshGenerator, generate_disc_mesh
+    from torchdrivesim.rendering import CV2RendererConfig, renderer_from_config
+    from torchdrivesim.rendering.base import get_default_color_map, get_default_rendering_levels
+    g = seeded(808)
+    d = {}
+    # ---- bookkeeping: agents drive along x; waypoint collections are strung along their way, some off to the side (never reached)
+    B, A, N, M, T = 2, 3, 4, 2, 12
+    start = torch.cat([(torch.rand(B, A, 2, generator=g) - 0.5) * 10, torch.zeros(B, A, 2)], -1)
+    wps = start[:, :, None, None, :2] + torch.stack([torch.arange(1, N + 1) * 6.0, torch.zeros(N)], -1)[None, None, :, None, :] \
+        + (torch.rand(B, A, N, M, 2, generator=g) - 0.5) * torch.tensor([2.0, 6.0])
+    mask = torch.rand(B, A, N, M, generator=g) < 0.8
+    mask[0, 0] = True
+    mask[1, 2, 1] = False                                     # a collection made of padding only
+    goal = WaypointGoal(wps.clone(), mask.clone())
+    d['wp'], d['wp_mask'] = npy(wps), npy(mask)
+    traj = []
+    for t in range(T):
+        st = start.clone()
+        st[..., 0] += 2.5 * (t + 1)
+        st[..., 1] += 0.3 * math.sin(t)
+        traj.append(st)
+        goal.step(st, t + 1, threshold=2.0)
+        d[f'state_{t}'], d[f'mask_{t}'] = npy(goal.state), npy(goal.mask)
+        for c in (1, 3):
+            d[f'get_wp_{c}_{t}'], d[f'get_mask_{c}_{t}'] = npy(goal.get_waypoints(c)), npy(goal.get_masks(c))
+    d['traj'] = npy(torch.stack(traj))
+    ext = goal.extend(2, in_place=False)
+    d['ext_state'], d['ext_wp'] = npy(ext.state), npy(ext.waypoints)
+    # ---- disc meshes
+    for r, n in ((2.0, 10), (1.5, 6), (3.0, 2)):
+        v, f = generate_disc_mesh(radius=r, num_triangles=n)
+        d[f'disc_{n}_verts'], d[f'disc_{n}_faces'] = npy(v), npy(f).astype(np.int32)
+    # ---- generate() with waypoints
+    small = crop_mesh(town, (100.0, 2.0), 6.0)
+    Bm, Am, Mw = 2, 3, 3
+    state, size, present = random_scene(g, Bm, Am, spread=20.0, centre=(100.0, 2.0))
+    gen = BirdviewRGBMeshGenerator(background_mesh=small.expand(Bm), color_map=get_default_color_map(), rendering_levels=get_default_rendering_levels())
+    gen.initialize_actors_mesh(size, torch.zeros(Bm, Am, dtype=torch.long), ['vehicle'])
+    wp = torch.tensor([100.0, 2.0]) + (torch.rand(Bm, Am, Mw, 2, generator=g) - 0.5) * 30
+    wm = torch.rand(Bm, Am, Mw, generator=g) < 0.6
+    wm[0, 0, 0] = False
+    rgb = gen.generate(Am, agent_state=state[:, None].expand(-1, Am, -1, -1), present_mask=present[:, None].expand(Bm, Am, Am),
+                       waypoints=wp, waypoints_rendering_mask=wm)
+    nv0, nf0 = small.verts_count + 7 * Am, small.faces_count + 3 * Am
+    d['m_state'], d['m_size'], d['m_present'], d['m_wp'], d['m_wmask'] = npy(state), npy(size), npy(present), npy(wp), npy(wm)
+    d['m_bg_verts'], d['m_bg_faces'], d['m_bg_vert_category'] = npy(small.verts[0]), npy(small.faces[0]).astype(np.int32), npy(small.vert_category[0]).astype(np.uint8)
+    d['m_wp_verts'], d['m_wp_faces'], d['m_wp_attrs'] = npy(rgb.verts[:, nv0:]), npy(rgb.faces[:, nf0:]).astype(np.int32), npy(rgb.attrs[:, nv0:])
+    # ---- render_egocentric with waypoint goals, up to the OpenCV boundary
+    crop = crop_mesh(town, (100.0, 2.0), 40.0)
+    B2, A2 = 2, 4
+    st2, sz2, pr2 = random_scene(g, B2, A2, spread=24.0, centre=(100.0, 2.0))
+    pr2[:, 0] = True
+    w2 = st2[:, :, None, None, :2] + (torch.rand(B2, A2, 3, 2, 2, generator=g) - 0.5) * 30
+    m2 = torch.rand(B2, A2, 3, 2, generator=g) < 0.7
+    r = renderer_from_config(CV2RendererConfig())
+    sim = make_sim(st2.clone(), sz2.clone(), pr2.clone(), road_mesh=crop.expand(B2), renderer=r)
+    sim.waypoint_goals = WaypointGoal(w2.clone(), m2.clone())
+    sim.waypoint_goals.state[1, 2] = 2                          # the window of two collections runs past the end for this agent
+    d['r_state'], d['r_size'], d['r_present'], d['r_wp'], d['r_wmask'] = npy(st2), npy(sz2), npy(pr2), npy(w2), npy(m2)
+    d['r_goal_state'] = npy(sim.waypoint_goals.state)
+    d['r_road_verts'], d['r_road_faces'], d['r_road_vert_category'] = npy(crop.verts[0]), npy(crop.faces[0]).astype(np.int32), npy(crop.vert_category[0]).astype(np.uint8)
+    for count in (1, 2):
+        tris, cols, shape = render_record(cv2, sim, 96, 35.0, n_subsequent_waypoints=count)
+        d[f'r_tris_{count}'], d[f'r_cols_{count}'] = tris, cols
+        print('g11 render', count, tris.shape, 'waypoint-coloured calls', int((cols == np.array([139, 64, 0], np.uint8)).all(-1).sum()))
+    np.savez_compressed(os.path.join(out, 'g11_waypoints.npz'), **d)
+    print('g11 goal states', d[f'state_{T - 1}'].reshape(-1).tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--only', default=None, help='regenerate one group only (e.g. waypoints)')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     cv2 = install_stubs()
@@ -629,6 +705,9 @@ def main():
     torch.set_num_threads(1)
     import torchdrivesim  # noqa: F401  (the reference)
     assert os.path.realpath(torchdrivesim.__path__[0]).startswith(os.path.realpath(REF))
+    if args.only == 'waypoints':
+        gen_waypoints(args.out, cv2, load_town01())
+        return
     gen_kinematic(args.out)
     gen_collision(args.out)
     gen_scene_collision(args.out)
@@ -638,6 +717,7 @@ def main():
     gen_grads(args.out, town)
     gen_traffic(args.out)
     gen_observation(args.out)
+    gen_waypoints(args.out, cv2, town)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

@@ -400,10 +400,12 @@ def _raster_workspace(dev, n_img, res):
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
 raster_events = None
 
-def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None):
+def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None,
+                 extra_tri=None, extra_key=None):
     """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns -- or (B,Nc,N,2)
     when every camera sees its own colours (custom_agent_colors) --, mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2)
-    -> (B,Nc,3,res,res) float32 [0,255] or uint8."""
+    -> (B,Nc,3,res,res) float32 [0,255] or uint8.  extra_tri (B,Nc,K,3,2) world-space triangles with keys extra_key (B,Nc,K) int32
+    (0 = none) are drawn per camera (waypoint discs); their keys belong into `key_table` too."""
     B, Nc = cam_xy.shape[:2]
     N = state.shape[1]
     dev = cam_xy.device
@@ -422,8 +424,14 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     mode = nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8
     # distinct actor keys (host side): enables the bit-plane kernel.  Callers that know them (Simulator) pass `key_table`;
     # otherwise they are read back from the device tensor (a synchronisation -- fine for tests and one-off calls)
-    if key_table is None and N > 0 and use_bitplanes:
-        key_table = torch.unique(actor_key).cpu().tolist()
+    K = 0
+    if extra_tri is not None and extra_tri.shape[2] > 0:
+        K = extra_tri.shape[2]
+        assert tuple(extra_tri.shape) == (B, Nc, K, 3, 2) and tuple(extra_key.shape) == (B, Nc, K), 'extra_tri must be (B,Nc,K,3,2), extra_key (B,Nc,K)'
+        extra_tri, extra_key = _c(extra_tri), _c(extra_key, i32)
+    if key_table is None and (N > 0 or K > 0) and use_bitplanes:
+        parts = ([actor_key.flatten()] if N > 0 else []) + ([extra_key.flatten()] if K > 0 else [])
+        key_table = [v for v in torch.unique(torch.cat(parts)).cpu().tolist() if v != 0]
     kt = None
     if key_table is not None and use_bitplanes:
         vals = [int(v) & 0xffffffff for v in key_table]
@@ -442,7 +450,9 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
              B, Nc, N, float(2.0 / fov), int(res), mode, nat.dev_ptr(out, out_dtype, 'out'),
              None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(),
              None if kt is None else ctypes.cast(kt, ctypes.c_void_p), 0 if kt is None else len(key_table),
-             1 if (N > 0 and actor_key.dim() == 4) else 0, nat.stream_ptr(dev))
+             1 if (N > 0 and actor_key.dim() == 4) else 0,
+             nat.dev_ptr(extra_tri, f32, 'extra_tri') if K > 0 else None, nat.dev_ptr(extra_key, i32, 'extra_key') if K > 0 else None, K,
+             nat.stream_ptr(dev))
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         raster_events.append(ev)
@@ -455,8 +465,9 @@ class _RasterScene(torch.autograd.Function):
     heading (DESIGN.md "K3 backward"); the reference's CV2 backend has none (rendering/cv2.py:27-70)."""
 
     @staticmethod
-    def forward(ctx, state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, fov, res, key_table):
-        out = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table)
+    def forward(ctx, state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key):
+        out = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table, extra_tri=extra_tri,
+                           extra_key=extra_key)
         ctx.save_for_backward(state, agent_sc, cam_xy, cam_sc, tmpl, mask, out)
         ctx.fov, ctx.res = fov, res
         return out
@@ -482,12 +493,12 @@ class _RasterScene(torch.autograd.Function):
             g_state = torch.zeros_like(state)
             g_state[..., :2] = ga[..., :2]
             g_sc = ga[..., 2:].contiguous()
-        return g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), None, None, None, None, None, None, None
+        return g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), None, None, None, None, None, None, None, None, None
 
 
-def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None):
-    """raster_scene with a backward pass (float32 output only)"""
-    return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, float(fov), int(res), key_table)
+def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None, extra_tri=None, extra_key=None):
+    """raster_scene with a backward pass (float32 output only; the per-camera triangles get no gradient)"""
+    return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, float(fov), int(res), key_table, extra_tri, extra_key)
 
 
 def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32):

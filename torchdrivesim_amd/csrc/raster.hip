@@ -46,6 +46,15 @@ struct SceneArgs {
     int N, Nc;
     int key_per_cam;            // custom_agent_colors (mesh.py:1092-1099): the actors' keys differ from camera to camera
 };
+// ... plus per-camera triangles.  A separate type so that the kernels of scenes without them keep their argument layout and
+// register budget (the bit-plane kernel sits exactly at its VGPR limit).
+struct SceneArgsEx : SceneArgs {
+    const float *extra_tri;     // B x Nc x K x 3 x 2: per-camera triangles in world coordinates (waypoint discs, mesh.py:1120-1145)
+    const uint32_t *extra_key;  // B x Nc x K, 0 = no triangle
+    int K;
+};
+template <typename SA> struct has_extras { static constexpr bool value = false; };
+template <> struct has_extras<SceneArgsEx> { static constexpr bool value = true; };
 
 struct MeshArgs {
     const float *verts;         // n_img x V x 3
@@ -691,13 +700,15 @@ __device__ __forceinline__ void scan_load_rows(ScanState &st, const MapView &m, 
 }
 
 // window = pixel columns [X0, X0 + TWw) of the image (the whole image when binning)
-__device__ __forceinline__ void scan_init(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane, int wave, int X0,
+template <typename SA>
+__device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane, int wave, int X0,
                                           int TWw) {   // wave = index among the cooperating waves
     st.map = a.map;
     if (a.views != nullptr) st.map = a.views[a.scene_map[img / a.Nc]];
     const MapView &m = st.map;
     const int res = c.res;
-    st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 2 static map
+    st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 3 per-camera triangles, 2 static map
+    if constexpr (has_extras<SA>::value) { if (st.phase == 2 && a.K > 0) st.phase = 3; }
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
@@ -758,8 +769,8 @@ __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, cons
 }
 
 // one producer step: at most one candidate face per lane; returns false when the producer is exhausted
-template <int NW = RWAVES>
-__device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane,
+template <int NW = RWAVES, typename SA = SceneArgsEx>      // SceneArgsEx: the per-camera triangle phase is compiled in
+__device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane,
                                           int wave, int X0, int TWw, bool &acc, uint32_t &key, int (&px)[3], int (&py)[3], unsigned &edges) {
     const MapView &m = st.map;
     unsigned ins = 0;
@@ -820,6 +831,24 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
             key = a.actor_key[2 * (a.key_per_cam ? img * a.N : b * a.N)];
         }
         st.phase = 2;
+        if constexpr (has_extras<SA>::value) { st.a0 = 0; if (a.K > 0) st.phase = 3; }
+        return true;
+    }
+    if constexpr (has_extras<SA>::value) if (st.phase == 3) {
+        // per-camera triangles, already in world coordinates (the host applies generate()'s transform, mesh.py:1120-1145): one lane each
+        const int t = st.a0 + wave * 64 + lane;
+        if (t < a.K) {
+            key = a.extra_key[img * a.K + t];
+            if (key != 0u) {
+                const float2 *v = (const float2 *)a.extra_tri + (img * a.K + t) * 3;
+                const float2 va = v[0], vb = v[1], vc = v[2];
+                const float fx[3] = {va.x + (-cam.cx), vb.x + (-cam.cx), vc.x + (-cam.cx)}, fy[3] = {va.y + (-cam.cy), vb.y + (-cam.cy), vc.y + (-cam.cy)};
+                acc = trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
+                edges = edge_mask(0u, ins);
+            }
+        }
+        st.a0 += 64 * NW;
+        if (st.a0 >= a.K) st.phase = 2;
         return true;
     }
     // static map: the cells of one grid row under the window are ONE contiguous range of entries; chunks of 64 consecutive
@@ -856,7 +885,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SceneArgs &a, con
 // Fused single-pass kernel: one workgroup per (camera, strip); every strip scans the grid itself.  Used when the caller
 // gives no workspace; also the semantics reference for the binned kernel below.
 template <int TW, typename OutT>
-__global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgs a, CommonArgs c) {
+__global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgsEx a, CommonArgs c) {
     TDS_RASTER_PROLOGUE()
     ScanState st;
     scan_init(st, a, c, cam, img, lane, wave, X0, TW);
@@ -883,7 +912,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgs a, Co
 constexpr int BIN_WAVES = 4;          // cameras per workgroup of K3a
 constexpr int MAX_STRIPS = 128;
 
-__global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgs a, CommonArgs c, int tw, uint32_t *__restrict__ counts,
+__global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgsEx a, CommonArgs c, int tw, uint32_t *__restrict__ counts,
                                                                      uint4 *__restrict__ lists, int caps) {
     __shared__ uint32_t cnt_s[BIN_WAVES][MAX_STRIPS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -926,7 +955,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) bin_faces_kernel(SceneArgs a, 
 }
 
 template <int TW, typename OutT>
-__global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgs a, CommonArgs c, const uint32_t *__restrict__ counts,
+__global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgsEx a, CommonArgs c, const uint32_t *__restrict__ counts,
                                                                        const uint4 *__restrict__ lists, int caps) {
     TDS_RASTER_PROLOGUE()
     const uint32_t n = counts[img * c.strips + strip];
@@ -1494,7 +1523,7 @@ template <int NB> struct PairTab<NB, uint8_t> { using E = uint32_t; };        //
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return __builtin_rotateleft32(v, (unsigned)n & 31u); }
 
 template <int BBLOCK, int NB, typename OutT>
-__device__ inline void write_out_bits(const uint32_t *planes, const typename PairTab<NB, OutT>::E *tab, int K, OutT *out, int64_t img, int res,
+__device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typename PairTab<NB, OutT>::E *tab, int K, OutT *out, int64_t img, int res,
                                       int X0, int TWp, int wpr, int tid) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int P = 1 << (2 * NB);
@@ -1587,8 +1616,8 @@ template <int NB, typename OutT>
 constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename PairTab<NB, OutT>::E) / 4; }
 
 // one workgroup per (camera, strip); for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
-template <int BWAVES, int NB, typename OutT>
-__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene_bits_kernel(SceneArgs a, CommonArgs c, KeyTable kt, int TWp) {
+template <int BWAVES, int NB, typename OutT, typename SA>
+__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1642,7 +1671,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
         uint32_t key;
         int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
         unsigned edges;
-        const bool more = scan_step<BWAVES>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
+        const bool more = scan_step<BWAVES, SA>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
         drain_bits(w, lkeys, K, acc, key, edges, px, py, more);
         if (!more) break;
     }
@@ -1802,38 +1831,38 @@ struct MapSource {
 };
 int raster_scene_impl(const MapSource &ms, const float *state, const float *agent_sc, const float *tmpl, const uint32_t *actor_key, const uint8_t *mask,
                       const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out,
-                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream);
+                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream);
 }  // namespace
 
 TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                                 const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                 int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
+                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream) {
     TDS_CHECK_ARG(map, "tds_raster_scene: null map");
     MapSource ms;
     ms.one = map->view; ms.views = nullptr; ms.scene_map = nullptr; ms.uniq_keys = map->uniq_keys; ms.n_uniq = map->n_uniq;
     ms.renders = map->n_levels > 0 || map->view.nx == 0;
     return raster_scene_impl(ms, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, B, Nc, N, scale, res, out_mode, out, workspace, workspace_bytes,
-                             actor_keys, n_actor_keys, actor_key_per_camera, stream);
+                             actor_keys, n_actor_keys, actor_key_per_camera, extra_tri, extra_key, n_extra, stream);
 }
 
 TDS_EXPORT int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, const float *state, const float *agent_sc, const float *tmpl,
                                       const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                       int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
+                                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream) {
     TDS_CHECK_ARG(set && set->n > 0, "tds_raster_scene_multi: null or empty map set");
     TDS_CHECK_ARG(scene_map || B == 0, "tds_raster_scene_multi: null scene -> map index array");
     MapSource ms;
     ms.one = tds::MapView{}; ms.views = set->d_views; ms.scene_map = scene_map; ms.uniq_keys = set->uniq_keys; ms.n_uniq = set->n_uniq;
     ms.renders = set->n_levels > 0;
     return raster_scene_impl(ms, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, B, Nc, N, scale, res, out_mode, out, workspace, workspace_bytes,
-                             actor_keys, n_actor_keys, actor_key_per_camera, stream);
+                             actor_keys, n_actor_keys, actor_key_per_camera, extra_tri, extra_key, n_extra, stream);
 }
 
 namespace {
 int raster_scene_impl(const MapSource &ms, const float *state, const float *agent_sc, const float *tmpl, const uint32_t *actor_key, const uint8_t *mask,
                       const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out,
-                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, void *stream) {
+                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream) {
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
     TDS_CHECK_ARG(ms.renders, "tds_raster_scene: the map was created without rendering data");
     int64_t n_img = B * Nc;
@@ -1845,14 +1874,16 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     TDS_CHECK_ARG(N == 0 || (state && agent_sc && tmpl && actor_key && mask), "tds_raster_scene: null agent arrays");
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene: scale must be positive");
     TDS_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "tds_raster_scene: bad workspace");
-    SceneArgs a;
+    SceneArgsEx a;
     a.map = ms.one; a.views = ms.views; a.scene_map = ms.scene_map; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
     a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc; a.key_per_cam = actor_key_per_camera ? 1 : 0;
+    TDS_CHECK_ARG(n_extra >= 0 && n_extra < (1 << 20) && (n_extra == 0 || (extra_tri && extra_key)), "tds_raster_scene: bad per-camera triangle arrays");
+    a.extra_tri = extra_tri; a.extra_key = extra_key; a.K = (int)n_extra;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
     // fastest path: bit planes, when the scene uses at most MAX_KEYS distinct keys and the caller listed the actors' keys
-    if ((N == 0 || (actor_keys && n_actor_keys > 0)) && ms.n_uniq >= 0 && !(g_debug & 64)) {
+    if (((N == 0 && n_extra == 0) || (actor_keys && n_actor_keys > 0)) && ms.n_uniq >= 0 && !(g_debug & 64)) {
         KeyTable kt;
         kt.n = 0;
         bool ok = true;
@@ -1862,7 +1893,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
             kt.key[kt.n++] = key;
         };
         for (int i = 0; i < ms.n_uniq; ++i) add(ms.uniq_keys[i]);
-        for (int i = 0; i < (N > 0 ? n_actor_keys : 0); ++i) add(actor_keys[i]);
+        for (int i = 0; i < ((N > 0 || n_extra > 0) ? n_actor_keys : 0); ++i) add(actor_keys[i]);
         for (int i = kt.n; i < 16; ++i) kt.key[i] = 0xffffffffu;
         if (ok && kt.n > 0) {
             for (int i = 1; i < kt.n; ++i)                                   // ascending (insertion sort)
@@ -1877,6 +1908,11 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                 CommonArgs cb = cm;
                 cb.strips = (res + twp - 1) / twp;
                 dim3 grid((unsigned)(n_img * cb.strips));
+                const SceneArgs base = a;
+                auto launch_b = [&](auto kern) {            // scenes without per-camera triangles
+                    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, base, cb, kt, twp);
+                };
                 auto launch = [&](auto kern) {
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp);
@@ -1884,8 +1920,9 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                 const int nb = bits_index_bits(kt.n);
 #define TDS_BITS_DISPATCH(T)                                                                                                   \
     do {                                                                                                                       \
-        if (nwv == 4) { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, T>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, T>); else launch(raster_scene_bits_kernel<4, 4, T>); } \
-        else { if (nb == 2) launch(raster_scene_bits_kernel<8, 2, T>); else if (nb == 3) launch(raster_scene_bits_kernel<8, 3, T>); else launch(raster_scene_bits_kernel<8, 4, T>); } \
+        if (nwv == 4 && a.K == 0) { if (nb == 2) launch_b(raster_scene_bits_kernel<4, 2, T, SceneArgs>); else if (nb == 3) launch_b(raster_scene_bits_kernel<4, 3, T, SceneArgs>); else launch_b(raster_scene_bits_kernel<4, 4, T, SceneArgs>); } \
+        else if (nwv == 4) { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, T, SceneArgsEx>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, T, SceneArgsEx>); else launch(raster_scene_bits_kernel<4, 4, T, SceneArgsEx>); } \
+        else { if (nb == 2) launch(raster_scene_bits_kernel<8, 2, T, SceneArgsEx>); else if (nb == 3) launch(raster_scene_bits_kernel<8, 3, T, SceneArgsEx>); else launch(raster_scene_bits_kernel<8, 4, T, SceneArgsEx>); } \
     } while (0)
                 if (out_mode == TDS_OUT_F32) TDS_BITS_DISPATCH(float); else TDS_BITS_DISPATCH(uint8_t);
 #undef TDS_BITS_DISPATCH

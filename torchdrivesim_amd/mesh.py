@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn.utils.rnn import pad_sequence
 
-from torchdrivesim_amd.utils import is_inside_polygon, transform
+from torchdrivesim_amd.utils import is_inside_polygon, rotate, transform
 
 Color = Union[Tensor, Tuple[int, int, int]]
 
@@ -416,6 +416,20 @@ def actor_template(lenwid: Tensor, direction_size: float = 0.3) -> Tensor:
     return torch.cat([body, tri], dim=-2)
 
 
+def generate_disc_mesh(radius: float = 2, num_triangles: int = 10, device='cpu') -> Tuple[Tensor, Tensor]:
+    """A fan of `num_triangles` triangles around the origin: verts (T+1) x 2 = centre, then the rim, every rim point being the
+    previous one rotated by 360/T degrees (the rounding accumulates exactly as in mesh.py:1243-1271); faces T x 3."""
+    T = int(num_triangles)
+    step = torch.deg2rad(torch.tensor([[360 / T]], dtype=torch.float32, device=device))
+    rim = [torch.tensor([[radius, 0]], dtype=torch.float32, device=device)]
+    for _ in range(max(T, 2) - 1):
+        rim.append(rotate(rim[-1], step))
+    verts = torch.cat([torch.zeros(1, 2, dtype=torch.float32, device=device)] + rim, dim=0)
+    k = torch.arange(1, T + 1, dtype=torch.long, device=device)
+    nxt = k % T + 1 if T > 1 else k + 1
+    return verts, torch.stack([torch.zeros_like(k), k, nxt], dim=-1)
+
+
 class BirdviewRGBMeshGenerator:
     """Keeps the static background and the per-agent templates and produces, on request, the explicit per-camera RGB
     mesh the reference's renderers consume (mesh.py:761-1157).  The fused MI355X path does NOT call `generate`: it
@@ -437,6 +451,15 @@ class BirdviewRGBMeshGenerator:
         self.static_traffic_controls_mesh = self.traffic_lights_mesh = self.traffic_light_colors = None
         if traffic_controls:
             self.initialize_traffic_controls_mesh(traffic_controls)
+        self.initialize_waypoint_mesh(waypoint_radius, waypoint_num_triangles)
+
+    def initialize_waypoint_mesh(self, waypoint_radius: float = 2.0, waypoint_num_triangles: int = 10) -> None:
+        """one disc per scene, category `goal_waypoint` (mesh.py:885-909)"""
+        self.waypoint_radius, self.waypoint_num_triangles = waypoint_radius, waypoint_num_triangles
+        B, dev = self.background_mesh.batch_size, self.background_mesh.device
+        verts, faces = generate_disc_mesh(radius=waypoint_radius, num_triangles=waypoint_num_triangles, device=dev)
+        disc = rendering_mesh(BaseMesh(verts=verts[None].expand(B, -1, -1).clone(), faces=faces[None].expand(B, -1, -1).clone()), 'goal_waypoint')
+        self.waypoint_mesh = set_colors_with_defaults(disc, color_map=self.color_map, rendering_levels=self.rendering_levels)
 
     def initialize_background_mesh(self, background_mesh, world_center: Optional[Tensor] = None):
         if world_center is None:
@@ -526,7 +549,7 @@ class BirdviewRGBMeshGenerator:
         if self.actor_mesh is not None:
             self.actor_mesh = self.actor_mesh.to(device)
             self.actor_lenwid, self.actor_types = self.actor_lenwid.to(device), self.actor_types.to(device)
-        for name in ('static_traffic_controls_mesh', 'traffic_lights_mesh', 'traffic_light_colors'):
+        for name in ('static_traffic_controls_mesh', 'traffic_lights_mesh', 'traffic_light_colors', 'waypoint_mesh'):
             if getattr(self, name, None) is not None:
                 setattr(self, name, getattr(self, name).to(device))
         return self
@@ -544,6 +567,8 @@ class BirdviewRGBMeshGenerator:
         other.static_traffic_controls_mesh = bg_f(self.static_traffic_controls_mesh) if self.static_traffic_controls_mesh is not None else None
         other.traffic_lights_mesh = bg_f(self.traffic_lights_mesh) if self.traffic_lights_mesh is not None else None
         other.traffic_light_colors = f(self.traffic_light_colors) if self.traffic_light_colors is not None else None
+        other.waypoint_radius, other.waypoint_num_triangles = self.waypoint_radius, self.waypoint_num_triangles
+        other.waypoint_mesh = bg_f(self.waypoint_mesh)
         return other
 
     def copy(self):
@@ -561,8 +586,6 @@ class BirdviewRGBMeshGenerator:
                  custom_agent_colors: Optional[Tensor] = None) -> RGBMesh:
         """Explicit (B*Nc)-batched RGB mesh = background expanded per camera || posed actors (mesh.py:1053-1157).
         Faces of masked agents are zeroed before the concat, hence alias the first actor vertex."""
-        if waypoints is not None:
-            raise NotImplementedError('waypoint meshes are outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
         meshes = [self.background_mesh.expand(num_cameras)]
         if agent_state is not None and self.actor_mesh is not None:
             assert agent_state.shape[1] == num_cameras
@@ -593,4 +616,19 @@ class BirdviewRGBMeshGenerator:
             table = self.traffic_light_colors[:, None].repeat_interleave(num_cameras, dim=1).flatten(0, 1)
             cur = torch.gather(table, 2, traffic_lights.state[..., None, None].expand(-1, -1, -1, 3))
             meshes.append(dataclasses.replace(lights, attrs=cur.expand(-1, -1, 4, -1).reshape(lights.batch_size, -1, 3)))
+        if waypoints is not None:
+            # one disc per (camera, waypoint), moved to the waypoint; discs of masked waypoints keep their vertices but their faces are
+            # zeroed, so after the concat they alias the first waypoint vertex of the camera (mesh.py:1120-1145)
+            assert waypoints.shape[1] == num_cameras
+            disc = self.waypoint_mesh
+            B, M, nv = disc.batch_size, waypoints.shape[2], disc.verts.shape[1]
+            xy = disc.verts[:, None, None, :, :2] + waypoints[..., None, :].to(disc.verts.dtype)                   # B x Nc x M x nv x 2
+            z = disc.verts[:, None, None, :, 2:3].expand(-1, num_cameras, M, -1, -1)
+            faces = disc.faces[:, None, None] + nv * torch.arange(M, device=disc.device)[None, None, :, None, None]     # B x 1 x M x T x 3
+            faces = faces.expand(-1, num_cameras, -1, -1, -1)
+            if waypoints_rendering_mask is not None:
+                faces = faces * waypoints_rendering_mask.reshape(B, num_cameras, M, 1, 1)
+            attrs = disc.attrs[:, None, None].expand(-1, num_cameras, M, -1, -1)
+            meshes.append(dataclasses.replace(disc, verts=torch.cat([xy, z], dim=-1).reshape(B * num_cameras, M * nv, 3),
+                                              faces=faces.reshape(B * num_cameras, -1, 3), attrs=attrs.reshape(B * num_cameras, M * nv, 3)))
         return RGBMesh.concat(meshes)

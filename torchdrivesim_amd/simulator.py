@@ -9,8 +9,8 @@
     compute_collision  -> K2a, all agents of all scenes in one launch        reference: simulator.py:1064-1194 (A launches)
     compute_offroad    -> K2b over the device-resident map grid              reference: simulator.py:1035-1044
 
-Out of scope: lanelet maps, traffic controls, waypoint goals, observation noise; passing them
-raises NotImplementedError instead of silently ignoring them.
+Also carried: traffic controls, waypoint goals (state + rendering) and observation noise.  Out of scope:
+lanelet maps and lane features; passing them raises NotImplementedError instead of silently ignoring them.
 """
 import logging
 from dataclasses import dataclass, field
@@ -155,8 +155,7 @@ class Simulator:
                  waypoint_goals=None, agent_types: Optional[Tensor] = None, agent_type_names: Optional[List[str]] = None,
                  npc_controller: Optional[NPCController] = None, agent_lr: Optional[Tensor] = None, lane_features=None,
                  observation_noise_model=None, action_model_extras: Optional[Dict[str, Any]] = None):
-        for name, val in (('lanelet_map', lanelet_map), ('waypoint_goals', waypoint_goals),
-                          ('lane_features', lane_features)):
+        for name, val in (('lanelet_map', lanelet_map), ('lane_features', lane_features)):
             if val is not None and not (name == 'lanelet_map' and all(m is None for m in val)):
                 raise NotImplementedError(f'`{name}` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
         self.road_mesh = road_mesh
@@ -167,7 +166,7 @@ class Simulator:
         self.present_mask = initial_present_mask
         self.action_model_extras = action_model_extras
         self.traffic_controls = traffic_controls        # Dict[str, BaseTrafficControl]: state and violations; not rendered by the fused path
-        self.waypoint_goals = None
+        self.waypoint_goals = waypoint_goals             # WaypointGoal: ticked off in step(), drawn as discs by render_egocentric
         self.lane_features = None
         if observation_noise_model is None:
             from torchdrivesim_amd.observation_noise import ObservationNoise
@@ -252,6 +251,7 @@ class Simulator:
         self.npc_controller = self.npc_controller.to(device)
         if self.traffic_controls is not None:
             self.traffic_controls = {k: v.to(device) for k, v in self.traffic_controls.items()}
+        self.waypoint_goals = self.waypoint_goals.to(device) if self.waypoint_goals is not None else None
         self._scene_cache = None
         return self
 
@@ -263,6 +263,7 @@ class Simulator:
             birdview_mesh_generator=self.birdview_mesh_generator.copy(), recenter_offset=self.recenter_offset, internal_time=self.internal_time,
             agent_types=self.agent_type, agent_type_names=self.agent_types, agent_lr=self.agent_lr, npc_controller=self.npc_controller.copy(),
             traffic_controls={k: v.copy() for k, v in self.traffic_controls.items()} if self.traffic_controls is not None else None,
+            waypoint_goals=self.waypoint_goals.copy() if self.waypoint_goals is not None else None,
             observation_noise_model=self.observation_noise_model)
         other._scene_cache = self._scene_cache          # static maps are immutable and can be shared
         return other
@@ -283,6 +284,8 @@ class Simulator:
         self.npc_controller = self.npc_controller.extend(n)
         if self.traffic_controls is not None:
             self.traffic_controls = {k: v.extend(n) for k, v in self.traffic_controls.items()}
+        if self.waypoint_goals is not None:
+            self.waypoint_goals = self.waypoint_goals.extend(n)
         self._scene_cache = None
         return self
 
@@ -302,6 +305,8 @@ class Simulator:
         self.npc_controller = self.npc_controller.select_batch_elements(idx)
         if self.traffic_controls is not None:
             self.traffic_controls = {k: v.select_batch_elements(idx) for k, v in self.traffic_controls.items()}
+        if self.waypoint_goals is not None:
+            self.waypoint_goals = self.waypoint_goals.select_batch_elements(idx)
         self._scene_cache = None
         return self
 
@@ -338,13 +343,14 @@ class Simulator:
         return self.kinematic_model.get_state()
 
     def get_waypoints(self, count: int = 1):
-        return None
+        """B x A x count*M x 2 current waypoints of the agents, or None (simulator.py:589-593)"""
+        return self.waypoint_goals.get_waypoints(count=count) if self.waypoint_goals is not None else None
 
     def get_waypoints_state(self):
-        return None
+        return self.waypoint_goals.state if self.waypoint_goals is not None else None
 
     def get_waypoints_mask(self, count: int = 1):
-        return None
+        return self.waypoint_goals.get_masks(count=count) if self.waypoint_goals is not None else None
 
     def get_agent_size(self) -> Tensor:
         return self.agent_size
@@ -481,6 +487,8 @@ class Simulator:
         if self.traffic_controls is not None:                       # simulator.py:857-859
             for control in self.traffic_controls.values():
                 control.step(self.internal_time)
+        if self.waypoint_goals is not None:                         # simulator.py:860-861
+            self.waypoint_goals.step(self.get_state(), self.internal_time, threshold=self.cfg.waypoint_removal_threshold)
 
     def set_state(self, agent_state: Tensor, mask: Optional[Tensor] = None) -> None:
         if mask is None:
@@ -520,7 +528,7 @@ class Simulator:
         bg = gen.background_mesh                                   # RGBMesh, batch B, (x, y, z) + colour per vertex
         names = list(self.agent_types)
         lv, cm = self.renderer.rendering_levels, self.renderer.color_map
-        actor_levels = [float(lv[n]) for n in names] + [float(lv['direction'])]
+        actor_levels = [float(lv[n]) for n in names] + [float(lv['direction']), float(lv['goal_waypoint'])]
         B = self.batch_size
         # traffic controls are drawn like actors without a direction triangle: one quad per stop line (mesh.py:1007-1035)
         controls = self.traffic_controls or {}
@@ -539,7 +547,7 @@ class Simulator:
             per_scene = [self.renderer.make_static_map(bg[b:b + 1], all_levels, device=dev) for b in range(B)]
             maps = [(_ops.StaticMapSet(per_scene, torch.arange(B, dtype=torch.int32)), None)]
         tmpl = actor_template(sizes).contiguous()                   # B x N x 7 x 2
-        keys, key_tables = [], []
+        keys, key_tables, wp_keys = [], [], []
         for smap, _ in maps:
             body = torch.tensor([(smap.rank_of(lv[n]) << 24) | int(_ops.quantise_colors(torch.tensor(cm[n], dtype=torch.float32) / 255.0)) for n in names],
                                 dtype=torch.int64, device=dev)
@@ -547,6 +555,7 @@ class Simulator:
             k = torch.stack([body[types.long()], torch.full_like(types.long(), dkey)], dim=-1)
             keys.append(k.to(torch.int32).contiguous())             # bit pattern of the uint32 key
             key_tables.append(sorted(set(body.tolist()) | {dkey}))   # distinct actor keys, known on the host (bit-plane kernel)
+            wp_keys.append((smap.rank_of(lv['goal_waypoint']) << 24) | int(_ops.quantise_colors(torch.tensor(cm['goal_waypoint'], dtype=torch.float32) / 255.0)))
         ctrl = None
         if ctrl_kinds:
             q = lambda name: int(_ops.quantise_colors(torch.tensor(cm[name], dtype=torch.float32) / 255.0))
@@ -572,8 +581,22 @@ class Simulator:
             ctrl = dict(kinds=ctrl_kinds, state=torch.cat(st_q, dim=1).contiguous(), tmpl=torch.cat(tm_q, dim=1).contiguous(), key_lut=static_keys)
             for i in range(len(maps)):
                 key_tables[i] = sorted(set(key_tables[i]) | {int(v) for per_map in static_keys for v in per_map[i].tolist()})
-        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables, ctrl=ctrl)
+        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables, ctrl=ctrl, wp_keys=wp_keys)
         return self._scene_cache
+
+    def _waypoint_triangles(self, waypoints: Tensor, rendering_mask: Optional[Tensor]):
+        """B x Nc x M waypoints -> the world-space triangles generate() would add per camera (mesh.py:1120-1145): B x Nc x M*T x 3 x 2.
+        The faces of a masked waypoint are zeroed there and so alias the first waypoint vertex of the camera -- a dot at the centre of
+        waypoint 0, reproduced here by collapsing the triangle onto that point."""
+        disc = self.birdview_mesh_generator.waypoint_mesh
+        B, Nc, M = waypoints.shape[:3]
+        corner = torch.gather(disc.verts[..., :2].unsqueeze(1).expand(-1, disc.faces.shape[1], -1, -1), 2,
+                              disc.faces.long()[..., None].expand(-1, -1, -1, 2))                       # B x T x 3 x 2
+        tri = corner[:, None, None].to(waypoints.dtype) + waypoints[..., None, None, :]                     # B x Nc x M x T x 3 x 2
+        if rendering_mask is not None:
+            first = (disc.verts[:, 0, :2][:, None].to(waypoints.dtype) + waypoints[:, :, 0])[:, :, None, None, None]       # B x Nc x 1 x 1 x 1 x 2
+            tri = torch.where(rendering_mask.to(torch.bool)[..., None, None, None], tri, first.expand_as(tri))
+        return tri.reshape(B, Nc, M * corner.shape[1], 3, 2).contiguous(), None
 
     def _control_keys(self, scene, i_map: int, sl) -> Tensor:
         """(b, Nq, 2) int32 keys of the control quads of the scenes in `sl`: (colour of the current state, 0 = no direction part)"""
@@ -591,8 +614,8 @@ class Simulator:
                fov: Optional[float] = None, waypoints: Optional[Tensor] = None, waypoints_rendering_mask: Optional[Tensor] = None,
                custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None) -> Tensor:
         """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992)."""
-        if waypoints is not None or noisy_perception:
-            raise NotImplementedError('waypoints / noisy perception are outside the scope of torchdrivesim_amd')
+        if noisy_perception:
+            raise NotImplementedError('noisy perception needs lane features, which are outside the scope of torchdrivesim_amd')
         camera_sc = _camera_sc if _camera_sc is not None else torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
         if camera_xy.dim() == 2:
             camera_xy, camera_sc = camera_xy.unsqueeze(1), camera_sc.unsqueeze(1)
@@ -616,6 +639,9 @@ class Simulator:
                 tmpl_all = torch.cat([tmpl_all, ctrl['tmpl'].to(tmpl_all.dtype)], dim=1)
                 mask = torch.cat([mask, torch.ones(mask.shape[:-1] + (ctrl['state'].shape[1],), dtype=torch.bool, device=mask.device)], dim=-1)
             agent_sc = self._heading_sc() if (ctrl is None and not diff) else _ops.heading_sc(state[..., 2])
+            wp_tri = wp_on = None
+            if waypoints is not None and waypoints.shape[2] > 0:
+                wp_tri, wp_on = self._waypoint_triangles(waypoints.to(state.dtype), waypoints_rendering_mask)
             out = []
             for i_map, ((smap, b), keys, ktab) in enumerate(zip(scene['maps'], scene['keys'], scene['key_tables'])):
                 sl = slice(None) if b is None else slice(b, b + 1)
@@ -631,12 +657,18 @@ class Simulator:
                 if ctrl is not None:
                     kq = self._control_keys(scene, i_map, sl)
                     k = torch.cat([k, kq[:, None].expand(-1, n_cam, -1, -1) if k.dim() == 4 else kq], dim=-2).contiguous()
+                extra = dict()
+                if wp_tri is not None:
+                    wk = scene['wp_keys'][i_map]
+                    extra = dict(extra_tri=wp_tri[sl], extra_key=torch.full(wp_tri[sl].shape[:3], wk, dtype=torch.int32, device=state.device))
+                    ktab = None if ktab is None else sorted(set(ktab) | {wk})
                 out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], tmpl_all[sl], k, mask[sl].contiguous(),
-                                                      camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff))
+                                                      camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff, **extra))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
         # any other BirdviewRenderer: the reference's generic dataflow (explicit per-camera mesh)
         rgb_mesh = self.birdview_mesh_generator.generate(n_cam, agent_state=self.get_all_agent_state()[:, None].expand(-1, n_cam, -1, -1),
                                                          present_mask=mask, custom_agent_colors=custom_agent_colors,
+                                                         waypoints=waypoints, waypoints_rendering_mask=waypoints_rendering_mask,
                                                          traffic_lights=self.traffic_controls['traffic_light'].extend(n_cam, in_place=False)
                                                          if self.traffic_controls and 'traffic_light' in self.traffic_controls else None)
         img = self.renderer.render_frame(rgb_mesh, camera_xy, camera_sc, res=res, fov=fov)
@@ -658,8 +690,10 @@ class Simulator:
         cam_sc = None
         if ego_rotate and not (state.requires_grad and torch.is_grad_enabled()):
             cam_sc = self._heading_sc()[..., :self.agent_count, :]          # the cameras ARE the exposed agents
+        waypoints = self.get_waypoints(count=n_subsequent_waypoints)                  # simulator.py:1013-1017
+        waypoints_mask = self.get_waypoints_mask(count=n_subsequent_waypoints) if waypoints is not None else None
         return self.render(camera_xy, camera_psi, rendering_mask=rendering_mask, res=res, fov=fov, custom_agent_colors=custom_agent_colors,
-                           noisy_perception=noisy_perception, _camera_sc=cam_sc)
+                           waypoints=waypoints, waypoints_rendering_mask=waypoints_mask, noisy_perception=noisy_perception, _camera_sc=cam_sc)
 
     # ------------------------------------------------------------------------------------------------- infractions
     def compute_offroad(self) -> Tensor:
