@@ -314,14 +314,18 @@ def test_waypoint_goals_are_drawn_by_the_fused_path(oracle):
     plain = sim.render_egocentric(res=res, fov=35.0)
     sim.waypoint_goals = goals
     imgs = {}
-    for count in (1, 2):
-        img = imgs[count] = sim.render_egocentric(res=res, fov=35.0, n_subsequent_waypoints=count)
+    for count, res, fov in ((1, Resolution(96, 96), 35.0), (2, Resolution(96, 96), 35.0), (3, Resolution(320, 320), 60.0)):   # 320: two strips per camera
+        if res.width != 96:
+            sim.waypoint_goals = None
+            plain = sim.render_egocentric(res=res, fov=fov)
+            sim.waypoint_goals = goals
+        img = imgs[count] = sim.render_egocentric(res=res, fov=fov, n_subsequent_waypoints=count)
         assert (img != plain).any()
         rgb = sim.birdview_mesh_generator.generate(A, agent_state=s[:, None].expand(-1, A, -1, -1), present_mask=mask,
                                                    waypoints=sim.get_waypoints(count), waypoints_rendering_mask=sim.get_waypoints_mask(count))
-        img2 = sim.renderer.render_frame(rgb, s[..., :2], cam_sc, res=res, fov=35.0).reshape(img.shape)
+        img2 = sim.renderer.render_frame(rgb, s[..., :2], cam_sc, res=res, fov=fov).reshape(img.shape)
         ref = oracle.render_rgb_mesh(rgb.verts.cpu().numpy(), rgb.attrs.cpu().numpy(), rgb.faces.cpu().numpy().astype(np.int32),
-                                     s[..., :2].reshape(-1, 2).cpu().numpy(), cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / 35.0, 96)
+                                     s[..., :2].reshape(-1, 2).cpu().numpy(), cam_sc.reshape(-1, 2).cpu().numpy(), 2.0 / fov, res.width)
         ref = np.transpose(ref, (0, 3, 1, 2)).reshape(img.shape)
         np.testing.assert_array_equal(img2.cpu().numpy(), ref)
         np.testing.assert_array_equal(img.cpu().numpy(), ref)
@@ -329,6 +333,10 @@ def test_waypoint_goals_are_drawn_by_the_fused_path(oracle):
         assert int((img == wp_col).all(2).sum()) > 50
     # explicit waypoints through render(), without a rendering mask, on the packed-key kernels too (no key table -> no bit planes)
     from torchdrivesim_amd import _ops
+    res = Resolution(96, 96)
+    sim.waypoint_goals = None
+    plain = sim.render_egocentric(res=res, fov=35.0)
+    sim.waypoint_goals = goals
     wp = sim.get_waypoints(1)
     a = sim.render(s[..., :2], s[..., 2:3], res=res, fov=35.0, waypoints=wp)
     _ops.use_bitplanes = False
