@@ -115,12 +115,13 @@ typedef struct tds_map tds_map_t;
  * face_z F (rendering level of the face's FIRST vertex, cv2.py:44-46), face_rgb F (colour of the first vertex already
  * quantised as cv2.py:50: 0x00RRGGBB), levels: n_levels distinct rendering levels sorted DESCENDING that contain every
  * face_z and every actor level that will be rendered with this map (<= 255).  face_z / face_rgb / levels may be NULL
- * for a map that is only used by tds_offroad_f32.  cell_size <= 0 selects the default (8 m).
+ * for a map that is only used by tds_offroad_f32; such a map also gets per-cell nearest-face candidate lists (exact),
+ * which make the off-road query one short linear walk.  cell_size <= 0 selects the default (8 m).
  * The handle lives on the CURRENT HIP device. */
 int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
                    int64_t F, const float *levels, int n_levels, float cell_size, tds_map_t **out);
 int tds_map_destroy(tds_map_t *map);
-/* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, reserved */
+/* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, number of nearest-face candidates */
 int tds_map_info(const tds_map_t *map, int64_t *info);
 
 /* Map sets: batches whose scenes have DIFFERENT meshes (the reference supports them as a collated, padded mesh batch, mesh.py:69,

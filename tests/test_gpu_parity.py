@@ -242,6 +242,38 @@ def test_k2b_offroad_town01_random(ops, oracle, town):
     assert (out > 0).any() and (out == 0).any()
 
 
+def test_k2b_candidate_lists_equal_the_ring_walk(ops, oracle, town, monkeypatch):
+    """Geometry-only maps answer the off-road query from per-cell nearest-face candidate lists; maps built without them (and points
+    outside the grid) walk grid rings.  Both are the exact minimum over all faces: identical bits, at any distance from the road."""
+    import os
+    m = make_map(ops, town['verts'], town['faces'], None, None, render=False)
+    assert m.info()['near_candidates'] > 0
+    monkeypatch.setenv('TDS_NO_NEAR_LISTS', '1')
+    m0 = make_map(ops, town['verts'], town['faces'], None, None, render=False)
+    monkeypatch.delenv('TDS_NO_NEAR_LISTS')
+    assert m0.info()['near_candidates'] == 0
+    gen = np.random.default_rng(11)
+    lo, hi = town['verts'].min(0), town['verts'].max(0)
+    B, A = 64, 64
+    xy = gen.uniform(lo - 20.0, hi + 20.0, (B, A, 2))                   # anywhere over the map's bounding box and a little beyond
+    road = town['verts'][town['vert_category'] == town['categories'].index('road')]
+    xy[:16] = road[gen.integers(0, len(road), (16, A))] + gen.normal(0, 1.5, (16, A, 2))
+    state = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
+    state[-1, :4, :2] = [[lo[0], lo[1]], [hi[0], hi[1]], [lo[0] - 1e-3, hi[1] + 1e-3], [np.nan, 3.0]]      # grid corners, just outside, NaN
+    lw = np.concatenate([gen.uniform(4, 5, (B, A, 1)), gen.uniform(1.8, 2.2, (B, A, 1))], -1).astype(np.float32)
+    sd = dev(state)
+    sc = ops.heading_sc(sd[..., 2])
+    for thr in (0.5, 0.0, 30.0):
+        a = ops.offroad_forward(m, sd, dev(lw), sc, None, thr)
+        b = ops.offroad_forward(m0, sd, dev(lw), sc, None, thr)
+        assert torch.equal(a, b)
+    sub = slice(0, 20)
+    ref = oracle.offroad(state[sub], lw[sub], town['verts'], town['faces'], 0.5, sc=sc_np(sc)[sub])
+    np.testing.assert_array_equal(ops.offroad_forward(m, sd[sub], dev(lw)[sub], sc[sub], None, 0.5).cpu().numpy(), ref)
+    far = ops.offroad_forward(m, sd, dev(lw), sc, None, 0.5)
+    assert float(far[:-1].max()) > 40.0 ** 2                            # block centres: tens of metres from the nearest face
+
+
 # ---------------------------------------------------------------------------------------------------- K3
 def oracle_static(oracle, verts, faces, vert_category, categories):
     return oracle.static_mesh_arrays(verts, faces, vert_category, categories)

@@ -255,7 +255,7 @@ class StaticMap:
     def info(self):
         buf = (ctypes.c_int64 * 8)()
         nat.call('tds_map_info', self.device, self.handle, buf)
-        return dict(V=buf[0], F=buf[1], nx=buf[2], ny=buf[3], entries=buf[4], bytes=buf[5], n_levels=buf[6])
+        return dict(V=buf[0], F=buf[1], nx=buf[2], ny=buf[3], entries=buf[4], bytes=buf[5], n_levels=buf[6], near_candidates=buf[7])
 
     def rank_of(self, level):
         """1-based painter rank of a rendering level (larger = drawn later = on top)"""

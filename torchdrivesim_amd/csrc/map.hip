@@ -4,6 +4,7 @@
 // (B*A*4, F, 3, 3) tensor; here each corner walks grid rings outwards until the best distance is proven minimal.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -12,6 +13,118 @@
 
 using tds::GridEntry;
 using tds::MapView;
+
+
+namespace {
+// Host: nearest-face candidate lists (tds::NearView).  For a cell C (its box grown by a rounding margin) and the reference's distance
+// d(p, f) (infractions.py:100-170: 0 inside, else the min over the three edges of the clamped point-segment distance):
+//   * d(p, f) <= |p - v0(f)|^2 for every p (the clamped foot point of edge v0-v1 is never farther than its start point), so
+//     U = min_f max_{corner of C} |corner - v0(f)|^2 bounds the nearest-face distance of every point of C from above;
+//   * d(p, f) >= the squared distance between C and the bounding box of f =: lb(C, f).
+// Every face that is nearest to some point of C therefore has lb(C, f) <= U; the list holds exactly those, sorted by lb (then large
+// faces first), so the walk may stop at the first candidate whose lb is not below the best distance found.
+void build_near_lists(const float *verts, const int32_t *faces, int64_t F, float map_ox, float map_oy, float cell, int map_nx, int map_ny,
+                      std::vector<int32_t> &cand_start, std::vector<tds::NearCand> &cand, std::vector<GridEntry> &face_entries, float &ox, float &oy,
+                      int &nx, int &ny) {
+    const float inv = 1.0f / cell;
+    // own grid: the map's, grown by about 48 m on every side (less for huge maps)
+    int pad = (int)std::ceil(48.0f / cell);
+    while (pad > 0 && (int64_t)(map_nx + 2 * pad) * (map_ny + 2 * pad) > (int64_t)(1 << 22)) pad /= 2;
+    ox = map_ox - (float)pad * cell; oy = map_oy - (float)pad * cell;
+    nx = map_nx + 2 * pad; ny = map_ny + 2 * pad;
+    struct FaceBox { double x0, y0, x1, y1, vx, vy, area2; bool ok; };
+    std::vector<FaceBox> fb((size_t)F);
+    face_entries.assign((size_t)F, GridEntry{0, 0, 0, 0, 0, 0, 0, 0});
+    std::vector<int32_t> cs((size_t)nx * ny + 1, 0);
+    auto cells_of = [&](const FaceBox &b, int &cx0, int &cx1, int &cy0, int &cy1) {
+        cx0 = tds::cell_coord((float)b.x0, ox, inv); cx1 = tds::cell_coord((float)b.x1, ox, inv);
+        cy0 = tds::cell_coord((float)b.y0, oy, inv); cy1 = tds::cell_coord((float)b.y1, oy, inv);
+    };
+    for (int64_t f = 0; f < F; ++f) {
+        const float *p0 = verts + 2 * faces[3 * f], *p1 = verts + 2 * faces[3 * f + 1], *p2 = verts + 2 * faces[3 * f + 2];
+        FaceBox &b = fb[(size_t)f];
+        b.ok = std::isfinite(p0[0]) && std::isfinite(p0[1]) && std::isfinite(p1[0]) && std::isfinite(p1[1]) && std::isfinite(p2[0]) && std::isfinite(p2[1]);
+        if (!b.ok) continue;
+        GridEntry &e = face_entries[(size_t)f];
+        e.x0 = p0[0]; e.y0 = p0[1]; e.x1 = p1[0]; e.y1 = p1[1]; e.x2 = p2[0]; e.y2 = p2[1];
+        b.x0 = std::min(p0[0], std::min(p1[0], p2[0])); b.x1 = std::max(p0[0], std::max(p1[0], p2[0]));
+        b.y0 = std::min(p0[1], std::min(p1[1], p2[1])); b.y1 = std::max(p0[1], std::max(p1[1], p2[1]));
+        b.vx = p0[0]; b.vy = p0[1];
+        b.area2 = std::fabs(((double)p1[0] - p0[0]) * ((double)p2[1] - p0[1]) - ((double)p2[0] - p0[0]) * ((double)p1[1] - p0[1]));
+        int cx0, cx1, cy0, cy1;
+        cells_of(b, cx0, cx1, cy0, cy1);
+        for (int cy = cy0; cy <= cy1; ++cy)
+            for (int cx = cx0; cx <= cx1; ++cx) cs[(size_t)cy * nx + cx + 1]++;
+    }
+    for (size_t i = 1; i < cs.size(); ++i) cs[i] += cs[i - 1];
+    std::vector<int32_t> ids((size_t)cs.back()), cur(cs.begin(), cs.end() - 1);
+    for (int64_t f = 0; f < F; ++f) {
+        if (!fb[(size_t)f].ok) continue;
+        int cx0, cx1, cy0, cy1;
+        cells_of(fb[(size_t)f], cx0, cx1, cy0, cy1);
+        for (int cy = cy0; cy <= cy1; ++cy)
+            for (int cx = cx0; cx <= cx1; ++cx) ids[(size_t)cur[(size_t)cy * nx + cx]++] = (int32_t)f;
+    }
+    // a point is assigned to a cell in float arithmetic (cell_coord), so it may lie a hair outside the nominal box
+    const double grow = 1e-3 + 1e-6 * (std::fabs((double)ox) + std::fabs((double)oy) + (double)cell * (nx + ny));
+    std::vector<int32_t> stamp((size_t)F, -1);
+    struct Tmp { double lb, area2; int32_t f; };
+    std::vector<Tmp> tmp;
+    cand_start.assign((size_t)nx * ny + 1, 0);
+    cand.clear();
+    for (int cy = 0; cy < ny; ++cy)
+        for (int cx = 0; cx < nx; ++cx) {
+            const int32_t c = cy * nx + cx;
+            const double bx0 = (double)ox + (double)cx * cell - grow, bx1 = (double)ox + (double)(cx + 1) * cell + grow;
+            const double by0 = (double)oy + (double)cy * cell - grow, by1 = (double)oy + (double)(cy + 1) * cell + grow;
+            double U = INFINITY;
+            for (int k = 0;; ++k) {
+                const int y0 = std::max(cy - k, 0), y1 = std::min(cy + k, ny - 1), x0 = std::max(cx - k, 0), x1 = std::min(cx + k, nx - 1);
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) {
+                        if (std::max(std::abs(x - cx), std::abs(y - cy)) != k) continue;
+                        for (int32_t i = cs[(size_t)y * nx + x]; i < cs[(size_t)y * nx + x + 1]; ++i) {
+                            const FaceBox &b = fb[(size_t)ids[(size_t)i]];
+                            const double dx = std::max(std::fabs(b.vx - bx0), std::fabs(b.vx - bx1)), dy = std::max(std::fabs(b.vy - by0), std::fabs(b.vy - by1));
+                            U = std::min(U, dx * dx + dy * dy);
+                        }
+                    }
+                // faces not met yet lie entirely outside the box grown by k cells
+                const double reach = (double)k * cell;
+                if (U <= reach * reach) break;
+                if (cx - k <= 0 && cx + k >= nx - 1 && cy - k <= 0 && cy + k >= ny - 1) break;
+            }
+            tmp.clear();
+            if (std::isfinite(U)) {
+                const double Um = U * 1.002 + 1e-2, R = std::sqrt(Um);
+                const int x0 = std::max((int)std::floor((bx0 - R - ox) / cell) - 1, 0), x1 = std::min((int)std::floor((bx1 + R - ox) / cell) + 1, nx - 1);
+                const int y0 = std::max((int)std::floor((by0 - R - oy) / cell) - 1, 0), y1 = std::min((int)std::floor((by1 + R - oy) / cell) + 1, ny - 1);
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x)
+                        for (int32_t i = cs[(size_t)y * nx + x]; i < cs[(size_t)y * nx + x + 1]; ++i) {
+                            const int32_t f = ids[(size_t)i];
+                            if (stamp[(size_t)f] == c) continue;
+                            stamp[(size_t)f] = c;
+                            const FaceBox &b = fb[(size_t)f];
+                            const double dx = std::max(std::max(b.x0 - bx1, bx0 - b.x1), 0.0), dy = std::max(std::max(b.y0 - by1, by0 - b.y1), 0.0);
+                            const double lb = dx * dx + dy * dy;
+                            if (lb <= Um) tmp.push_back(Tmp{lb, b.area2, f});
+                        }
+                std::sort(tmp.begin(), tmp.end(), [](const Tmp &a, const Tmp &b) {
+                    if (a.lb != b.lb) return a.lb < b.lb;
+                    if (a.area2 != b.area2) return a.area2 > b.area2;
+                    return a.f < b.f;
+                });
+            }
+            for (const Tmp &t : tmp) {
+                float lb = (float)std::max(t.lb * 0.998 - 1e-3, 0.0);
+                if ((double)lb > t.lb * 0.998 - 1e-3 && lb > 0.0f) lb = std::nextafter(lb, 0.0f);
+                cand.push_back(tds::NearCand{t.f, lb});
+            }
+            cand_start[(size_t)c + 1] = (int32_t)cand.size();
+        }
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
 // host: build + upload
@@ -145,16 +258,45 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
     if (!m) { tds::set_error("tds_map_create: out of host memory"); return TDS_ENOMEM; }
     m->V = V; m->F = F; m->n_entries = (int64_t)entries.size(); m->n_levels = face_z ? n_levels : 0;
     m->d_entries = nullptr; m->d_cell_start = nullptr;
+    m->near = tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}; m->n_cand = 0;
+    // geometry-only maps are the ones K2b queries: give them nearest-face candidate lists
+    std::vector<int32_t> cand_start;
+    std::vector<tds::NearCand> cand;
+    std::vector<GridEntry> face_entries;
+    const bool with_near = !face_z && any && F > 0 && nx > 0 && (int64_t)nx * ny <= (int64_t)(1 << 21) && getenv("TDS_NO_NEAR_LISTS") == nullptr;
+    float near_ox = 0, near_oy = 0;
+    int near_nx = 0, near_ny = 0;
+    if (with_near) {
+        build_near_lists(verts, faces, F, ox, oy, cell, nx, ny, cand_start, cand, face_entries, near_ox, near_oy, near_nx, near_ny);
+        if (cand.size() > ((size_t)1 << 28)) { cand.clear(); cand_start.clear(); }
+    }
     hipError_t e = hipGetDevice(&m->device);
     size_t be = std::max<size_t>(entries.size(), 1) * sizeof(GridEntry), bc = cell_start.size() * sizeof(int32_t);
     if (e == hipSuccess) e = hipMalloc(&m->d_entries, be);
     if (e == hipSuccess) e = hipMalloc(&m->d_cell_start, bc);
     if (e == hipSuccess && !entries.empty()) e = hipMemcpy(m->d_entries, entries.data(), entries.size() * sizeof(GridEntry), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cell_start, cell_start.data(), bc, hipMemcpyHostToDevice);
+    size_t bn = 0;
+    if (e == hipSuccess && !cand.empty()) {
+        void *dc = nullptr, *ds = nullptr, *df = nullptr;
+        const size_t b1 = cand.size() * sizeof(tds::NearCand), b2 = cand_start.size() * sizeof(int32_t), b3 = face_entries.size() * sizeof(GridEntry);
+        e = hipMalloc(&dc, b1);
+        if (e == hipSuccess) e = hipMalloc(&ds, b2);
+        if (e == hipSuccess) e = hipMalloc(&df, b3);
+        if (e == hipSuccess) e = hipMemcpy(dc, cand.data(), b1, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ds, cand_start.data(), b2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(df, face_entries.data(), b3, hipMemcpyHostToDevice);
+        m->near = tds::NearView{(const tds::NearCand *)dc, (const int32_t *)ds, (const GridEntry *)df, near_ox, near_oy, near_nx, near_ny};
+        m->n_cand = (int64_t)cand.size();
+        bn = b1 + b2 + b3;
+    }
     if (e != hipSuccess) {
         tds::set_error("tds_map_create: %s", hipGetErrorString(e));
         if (m->d_entries) (void)hipFree(m->d_entries);
         if (m->d_cell_start) (void)hipFree(m->d_cell_start);
+        if (m->near.cand) (void)hipFree((void *)m->near.cand);
+        if (m->near.cand_start) (void)hipFree((void *)m->near.cand_start);
+        if (m->near.faces) (void)hipFree((void *)m->near.faces);
         delete m;
         return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
     }
@@ -166,7 +308,7 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         if (m->n_uniq == 64) { m->n_uniq = -1; break; }
         m->uniq_keys[m->n_uniq++] = ge.key;
     }
-    m->bytes = (int64_t)(be + bc);
+    m->bytes = (int64_t)(be + bc + bn);
     m->view.entries = (const GridEntry *)m->d_entries;
     m->view.cell_start = (const int32_t *)m->d_cell_start;
     m->view.ox = ox; m->view.oy = oy; m->view.inv_cell = inv; m->view.cell = cell;
@@ -181,6 +323,9 @@ TDS_EXPORT int tds_map_destroy(tds_map_t *map) {
     (void)hipGetDevice(&cur);
     if (cur != map->device) (void)hipSetDevice(map->device);
     hipError_t e1 = hipFree(map->d_entries), e2 = hipFree(map->d_cell_start);
+    if (map->near.cand) (void)hipFree((void *)map->near.cand);
+    if (map->near.cand_start) (void)hipFree((void *)map->near.cand_start);
+    if (map->near.faces) (void)hipFree((void *)map->near.faces);
     if (cur != map->device) (void)hipSetDevice(cur);
     delete map;
     if (e1 != hipSuccess || e2 != hipSuccess) { tds::set_error("tds_map_destroy: hipFree failed"); return TDS_EHIP; }
@@ -190,7 +335,7 @@ TDS_EXPORT int tds_map_destroy(tds_map_t *map) {
 TDS_EXPORT int tds_map_info(const tds_map_t *map, int64_t *info) {
     TDS_CHECK_ARG(map && info, "tds_map_info: null pointer");
     info[0] = map->V; info[1] = map->F; info[2] = map->view.nx; info[3] = map->view.ny;
-    info[4] = map->n_entries; info[5] = map->bytes; info[6] = map->n_levels; info[7] = 0;
+    info[4] = map->n_entries; info[5] = map->bytes; info[6] = map->n_levels; info[7] = map->n_cand;
     return TDS_OK;
 }
 
@@ -294,16 +439,53 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
     return best;
 }
 
+// The same minimum from the candidate list of the point's cell (tds::NearView): one linear walk, four faces in flight, ended by the
+// first candidate whose lower bound is not below the running minimum.  Points outside the grid take the ring walk.
+__device__ __forceinline__ float nearest_face_d2_lists(const MapView &m, const tds::NearView &nv, float px, float py, float stop) {
+    if (nv.cand == nullptr || m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return nearest_face_d2(m, px, py, stop);
+    const float fx = (px - nv.ox) * m.inv_cell, fy = (py - nv.oy) * m.inv_cell;
+    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny)) return nearest_face_d2(m, px, py, stop);
+    const int cx = tds::cell_coord(px, nv.ox, m.inv_cell), cy = tds::cell_coord(py, nv.oy, m.inv_cell);
+    if (cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny) return nearest_face_d2(m, px, py, stop);
+    const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
+    float best = __builtin_inff();
+    auto consider = [&](const tds::NearCand &c, const GridEntry &ge) {
+        if (c.lb >= best) return;
+        float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
+        float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
+        float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
+        if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) return;
+        float d = tri_d2(px, py, ge);
+        best = (d < best) ? d : best;
+    };
+    int i = s;
+    for (; i + 4 <= e && best > stop; i += 4) {
+        const tds::NearCand c0 = nv.cand[i], c1 = nv.cand[i + 1], c2 = nv.cand[i + 2], c3 = nv.cand[i + 3];
+        if (c0.lb >= best) return best;                         // sorted by lb: nothing further can be nearer
+        const GridEntry g0 = nv.faces[c0.face], g1 = nv.faces[c1.face], g2 = nv.faces[c2.face], g3 = nv.faces[c3.face];
+        consider(c0, g0); consider(c1, g1); consider(c2, g2); consider(c3, g3);
+    }
+    for (; i < e && best > stop; ++i) {
+        const tds::NearCand c0 = nv.cand[i];
+        if (c0.lb >= best) break;
+        consider(c0, nv.faces[c0.face]);
+    }
+    return best;
+}
+
 // one thread per agent corner (4 consecutive lanes = one agent)
-__global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
+__global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, tds::NearView nv, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
                                                          const float2 *__restrict__ sc, const uint8_t *__restrict__ present,
                                                          float *__restrict__ out, int64_t n, float threshold, const MapView *__restrict__ views,
-                                                         const int32_t *__restrict__ scene_map, int agents_per_scene) {
+                                                         const tds::NearView *__restrict__ nears, const int32_t *__restrict__ scene_map, int agents_per_scene) {
     int64_t t = (int64_t)blockIdx.x * OBLOCK + threadIdx.x;
     int64_t a = t >> 2;
     int k = (int)(t & 3);
     float v = 0.0f;
-    if (a < n && views != nullptr) m = views[scene_map[a / agents_per_scene]];      // one map per scene (tds_offroad_multi_f32)
+    if (a < n && views != nullptr) {                                                // one map per scene (tds_offroad_multi_f32)
+        const int im = scene_map[a / agents_per_scene];
+        m = views[im]; nv = nears[im];
+    }
     if (a < n && m.n_faces > 0) {
         float4 s = state[a];
         float2 lw = lenwid[a];
@@ -312,7 +494,7 @@ __global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, const float4
         float x4 = sx * lw.x, y4 = sy * lw.y;
         float px = (x4 * scv.y + y4 * (-scv.x)) + s.x;
         float py = (x4 * scv.x + y4 * scv.y) + s.y;
-        float d = nearest_face_d2(m, px, py, fmaxf(threshold, 0.0f));
+        float d = nearest_face_d2_lists(m, nv, px, py, fmaxf(threshold, 0.0f));
         d = (d != d) ? 0.0f : d;                                     // nan_to_num :171
         if (__builtin_isinf(d)) d = 3.4028234663852886e38f;
         v = (d > threshold) ? d : 0.0f;                              // F.threshold(d, thr, 0) :172
@@ -335,9 +517,9 @@ TDS_EXPORT int tds_offroad_f32(const tds_map_t *map, const float *state, const f
     if (n_agents == 0) return TDS_OK;
     TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_f32: null pointer");
     int64_t threads = n_agents * 4;
-    hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, map->view,
+    hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, map->view, map->near,
                        (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold,
-                       (const MapView *)nullptr, (const int32_t *)nullptr, 1);
+                       (const MapView *)nullptr, (const tds::NearView *)nullptr, (const int32_t *)nullptr, 1);
     TDS_LAUNCH_CHECK("offroad_kernel");
     return TDS_OK;
 }
@@ -351,8 +533,8 @@ TDS_EXPORT int tds_offroad_multi_f32(const tds_mapset_t *set, const int32_t *sce
     TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_multi_f32: null pointer");
     int64_t threads = n_agents * 4;
     hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, MapView{},
-                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold,
-                       (const MapView *)set->d_views, scene_map, (int)agents_per_scene);
+                       tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents,
+                       threshold, (const MapView *)set->d_views, (const tds::NearView *)set->d_near, scene_map, (int)agents_per_scene);
     TDS_LAUNCH_CHECK("offroad_kernel");
     return TDS_OK;
 }
@@ -363,9 +545,10 @@ TDS_EXPORT int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset
     *out = nullptr;
     TDS_CHECK_ARG(maps && n > 0 && n < (1 << 24), "tds_mapset_create: need at least one map");
     std::vector<MapView> views((size_t)n);
+    std::vector<tds::NearView> nears((size_t)n);
     tds_mapset *s = new (std::nothrow) tds_mapset();
     if (!s) { tds::set_error("tds_mapset_create: out of host memory"); return TDS_ENOMEM; }
-    s->n = n; s->device = maps[0] ? maps[0]->device : 0; s->n_levels = maps[0] ? maps[0]->n_levels : 0; s->n_uniq = 0; s->d_views = nullptr;
+    s->n = n; s->device = maps[0] ? maps[0]->device : 0; s->n_levels = maps[0] ? maps[0]->n_levels : 0; s->n_uniq = 0; s->d_views = nullptr; s->d_near = nullptr;
     for (int i = 0; i < n; ++i) {
         if (!maps[i] || maps[i]->device != s->device || maps[i]->n_levels != s->n_levels) {
             delete s;
@@ -373,6 +556,7 @@ TDS_EXPORT int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset
             return TDS_EINVAL;
         }
         views[(size_t)i] = maps[i]->view;
+        nears[(size_t)i] = maps[i]->near;
         if (maps[i]->n_uniq < 0) s->n_uniq = -1;
         for (int k = 0; s->n_uniq >= 0 && k < maps[i]->n_uniq; ++k) {
             bool seen = false;
@@ -387,9 +571,12 @@ TDS_EXPORT int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset
     if (cur != s->device) (void)hipSetDevice(s->device);
     hipError_t e = hipMalloc((void **)&s->d_views, views.size() * sizeof(MapView));
     if (e == hipSuccess) e = hipMemcpy(s->d_views, views.data(), views.size() * sizeof(MapView), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_near, nears.size() * sizeof(tds::NearView));
+    if (e == hipSuccess) e = hipMemcpy(s->d_near, nears.data(), nears.size() * sizeof(tds::NearView), hipMemcpyHostToDevice);
     if (cur != s->device) (void)hipSetDevice(cur);
     if (e != hipSuccess) {
         if (s->d_views) (void)hipFree(s->d_views);
+        if (s->d_near) (void)hipFree(s->d_near);
         delete s;
         tds::set_error("tds_mapset_create: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
@@ -404,6 +591,7 @@ TDS_EXPORT int tds_mapset_destroy(tds_mapset_t *set) {
     (void)hipGetDevice(&cur);
     if (cur != set->device) (void)hipSetDevice(set->device);
     hipError_t e = hipFree(set->d_views);
+    if (set->d_near) (void)hipFree(set->d_near);
     if (cur != set->device) (void)hipSetDevice(cur);
     delete set;
     if (e != hipSuccess) { tds::set_error("tds_mapset_destroy: hipFree failed"); return TDS_EHIP; }

@@ -61,6 +61,21 @@ struct MapView {
     int64_t n_faces;
 };
 
+// Nearest-face candidate lists of K2b (maps created without rendering data): for every grid cell the faces that can be the nearest one
+// of SOME point of the cell, sorted by a lower bound of their squared distance to the cell.  The off-road query of a point inside the
+// grid is one linear walk of its cell's list instead of a walk over grid rings.
+struct NearCand {
+    int32_t face;               // index into NearView::faces
+    float lb;                   // lower bound (rounded down, with a safety margin) of the squared distance from any point of the cell
+};
+struct NearView {
+    const NearCand *cand;       // null: no lists (maps with rendering data, empty maps)
+    const int32_t *cand_start;  // nx*ny + 1
+    const GridEntry *faces;     // one entry per face (key / own unused)
+    float ox, oy;               // the lists have their own grid: the map's cell size, grown by a margin around the mesh so that agents
+    int nx, ny;                 // that left the map's bounding box are still served
+};
+
 // the ONE definition of "which cell does this coordinate fall in" -- used by the host builder and by the kernels
 // (IEEE binary32, one rounding per operation on both sides: the library is built with -ffp-contract=off)
 __host__ __device__ inline int cell_coord(float v, float origin, float inv_cell) {
@@ -72,6 +87,7 @@ __host__ __device__ inline int cell_coord(float v, float origin, float inv_cell)
 // several maps of one device for launches whose scenes have different maps (tds_mapset_create)
 struct tds_mapset {
     tds::MapView *d_views;      // device array [n]
+    tds::NearView *d_near;      // device array [n] (entries with null lists fall back to the ring walk)
     int n, device, n_levels;
     uint32_t uniq_keys[64];     // union of the maps' distinct face keys
     int n_uniq;                 // -1: more than 64
@@ -81,6 +97,8 @@ struct tds_map {
     tds::MapView view;
     void *d_entries;
     void *d_cell_start;
+    tds::NearView near;         // K2b candidate lists (device pointers; all null when absent)
+    int64_t n_cand;
     int device;
     int64_t V, F, n_entries, bytes;
     int n_levels;
