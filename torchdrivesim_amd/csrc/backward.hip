@@ -348,17 +348,43 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
     return best;
 }
 
+// the same arg-min from the candidate list of the point's cell (tds::NearView, see nearest_face_d2_lists in map.hip)
+__device__ float nearest_face_d2_grad_lists(const MapView &m, const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop) {
+    if (nv.cand == nullptr || m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py))
+        return nearest_face_d2_grad(m, px, py, gx, gy, stop);
+    const float fx = (px - nv.ox) * m.inv_cell, fy = (py - nv.oy) * m.inv_cell;
+    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny)) return nearest_face_d2_grad(m, px, py, gx, gy, stop);
+    const int cx = tds::cell_coord(px, nv.ox, m.inv_cell), cy = tds::cell_coord(py, nv.oy, m.inv_cell);
+    if (cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny) return nearest_face_d2_grad(m, px, py, gx, gy, stop);
+    const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
+    float best = __builtin_inff();
+    gx = gy = 0.0f;
+    for (int i = s; i < e && best > stop; ++i) {
+        const tds::NearCand c = nv.cand[i];
+        if (c.lb >= best) break;
+        const GridEntry ge = nv.faces[c.face];
+        float tgx, tgy;
+        float d = tri_d2_grad(px, py, ge, tgx, tgy);
+        if (d < best) { best = d; gx = tgx; gy = tgy; }
+    }
+    return best;
+}
+
 // one thread per agent corner; the 4 corners of an agent are reduced with shuffles
-__global__ void __launch_bounds__(GBLOCK) offroad_bwd_kernel(MapView m, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
+__global__ void __launch_bounds__(GBLOCK) offroad_bwd_kernel(MapView m, tds::NearView nv, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
                                                              const float2 *__restrict__ sc, const uint8_t *__restrict__ present,
                                                              const float *__restrict__ gout, float4 *__restrict__ gstate,
                                                              float2 *__restrict__ glenwid, float2 *__restrict__ gsc, int64_t n, float threshold,
-                                                             const MapView *__restrict__ views, const int32_t *__restrict__ scene_map, int agents_per_scene) {
+                                                             const MapView *__restrict__ views, const tds::NearView *__restrict__ nears,
+                                                             const int32_t *__restrict__ scene_map, int agents_per_scene) {
     int64_t t = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
     int64_t a = t >> 2;
     int k = (int)(t & 3);
     float gx = 0, gy = 0, gl = 0, gw = 0, gs = 0, gc = 0;
-    if (a < n && views != nullptr) m = views[scene_map[a / agents_per_scene]];
+    if (a < n && views != nullptr) {
+        const int im = scene_map[a / agents_per_scene];
+        m = views[im]; nv = nears[im];
+    }
     if (a < n && m.n_faces > 0) {
         float go = gout[a] * ((present && !present[a]) ? 0.0f : 1.0f);
         if (go != 0.0f) {
@@ -369,7 +395,7 @@ __global__ void __launch_bounds__(GBLOCK) offroad_bwd_kernel(MapView m, const fl
             float x4 = sx * lw.x, y4 = sy * lw.y;
             float px = (x4 * scv.y + y4 * (-scv.x)) + s.x, py = (x4 * scv.x + y4 * scv.y) + s.y;
             float dgx, dgy;
-            float d = nearest_face_d2_grad(m, px, py, dgx, dgy, fmaxf(threshold, 0.0f));
+            float d = nearest_face_d2_grad_lists(m, nv, px, py, dgx, dgy, fmaxf(threshold, 0.0f));
             if (d == d && !__builtin_isinf(d) && d > threshold) {
                 float ggx = go * dgx, ggy = go * dgy;
                 gx = ggx; gy = ggy;
@@ -424,8 +450,9 @@ TDS_EXPORT int tds_offroad_bwd_f32(const tds_map_t *map, const float *state, con
     TDS_CHECK_ARG(state && lenwid && sc && grad_out, "tds_offroad_bwd_f32: null pointer");
     int64_t threads = n_agents * 4;
     hipLaunchKernelGGL(offroad_bwd_kernel, dim3((unsigned)((threads + GBLOCK - 1) / GBLOCK)), dim3(GBLOCK), 0, (hipStream_t)stream, map->view,
-                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, grad_out, (float4 *)grad_state,
-                       (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)nullptr, (const int32_t *)nullptr, 1);
+                       map->near, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, grad_out, (float4 *)grad_state,
+                       (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)nullptr, (const tds::NearView *)nullptr,
+                       (const int32_t *)nullptr, 1);
     TDS_LAUNCH_CHECK("offroad_bwd_kernel");
     return TDS_OK;
 }
@@ -440,8 +467,9 @@ TDS_EXPORT int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t 
     TDS_CHECK_ARG(state && lenwid && sc && grad_out, "tds_offroad_multi_bwd_f32: null pointer");
     int64_t threads = n_agents * 4;
     hipLaunchKernelGGL(offroad_bwd_kernel, dim3((unsigned)((threads + GBLOCK - 1) / GBLOCK)), dim3(GBLOCK), 0, (hipStream_t)stream, tds::MapView{},
-                       (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, grad_out, (float4 *)grad_state,
-                       (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)set->d_views, scene_map, (int)agents_per_scene);
+                       tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present,
+                       grad_out, (float4 *)grad_state, (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)set->d_views,
+                       (const tds::NearView *)set->d_near, scene_map, (int)agents_per_scene);
     TDS_LAUNCH_CHECK("offroad_bwd_kernel");
     return TDS_OK;
 }
