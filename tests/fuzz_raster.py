@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Large randomised parity run of the K3 scene rasteriser against the oracle (not part of the test suite: minutes of CPU time).
-   python tools/fuzz_raster.py [--seeds 8] [--batch 8] [--agents 24] [--res 256]"""
+"""Large randomised parity run of the K3 scene rasteriser against the oracle (a script, not collected by pytest: minutes of CPU time).
+   python tests/fuzz_raster.py [--seeds 8] [--batch 8] [--agents 24] [--res 256]"""
 import argparse, os, sys, time
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))      # this file lives in tests/: the oracle is test infrastructure
 from test_gpu_parity import dev, make_map, oracle_static, render_both, sc_np    # noqa: E402
 from torchdrivesim_amd import _ops as ops                                        # noqa: E402
 from oracle import oracle                                                        # noqa: E402
