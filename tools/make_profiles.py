@@ -23,7 +23,7 @@ pmc = json.load(open(os.path.join(src, 'raster_pmc.json')))
 key = max(pmc, key=lambda k: pmc[k].get('WRITE_SIZE', {}).get('mean', 0))
 c = {n: v['mean'] for n, v in pmc[key].items()}
 wb, fb = c['WRITE_SIZE'] * 1024, c['FETCH_SIZE'] * 1024
-out = dict(kernel='raster_scene_bits_kernel<4, 3, float>', batch=B, agents=A, res=RES,
+out = dict(kernel='raster_scene_bits_kernel<4, 3, float, SceneArgs>', batch=B, agents=A, res=RES,
            command='tools/collect_profiles.sh: rocprofv3 --pmc <set> --kernel-include-regex raster -- python3 tools/profile_raster.py --batch 1024 '
                    '--iters 2 (one pass per counter set, counters only)',
            counters=c, write_bytes_per_launch=wb, fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch_corrected=2 * fb,
