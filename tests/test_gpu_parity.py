@@ -274,6 +274,45 @@ def test_k2b_candidate_lists_equal_the_ring_walk(ops, oracle, town, monkeypatch)
     assert float(far[:-1].max()) > 40.0 ** 2                            # block centres: tens of metres from the nearest face
 
 
+@pytest.mark.parametrize('cell', [1.0, 3.0, 8.0])
+def test_k2b_candidate_lists_on_adversarial_meshes(ops, oracle, monkeypatch, cell):
+    """random triangle soups with huge faces, slivers (area < 5e-3: never "inside"), repeated vertices, collate-padded [0,0,0] faces and a
+    face with a NaN vertex; queries inside the mesh, in the margin of the candidate grid and far beyond it"""
+    gen = np.random.default_rng(int(cell * 10))
+    for trial in range(3):
+        V = 300
+        verts = gen.uniform(0, 50, (V, 2)).astype(np.float32)
+        faces = []
+        for _ in range(200):
+            a = gen.integers(0, V)
+            near = np.argsort(((verts - verts[a]) ** 2).sum(1))[:12]
+            faces.append([a, *gen.choice(near[1:], 2, replace=False)])
+        faces += [[gen.integers(0, V), gen.integers(0, V), gen.integers(0, V)] for _ in range(6)]      # huge faces
+        verts[10] = verts[11] + np.float32(1e-4)                                                            # slivers / near-degenerate edges
+        faces += [[10, 11, 12], [11, 10, 11], [0, 0, 0], [0, 0, 0], [5, 5, 7]]
+        if trial == 2:
+            verts[20, 0] = np.nan                                                                           # never binned, never nearest
+        faces = np.array(faces, np.int32)
+        m = ops.StaticMap(verts, faces, device=DEV, cell_size=cell)
+        monkeypatch.setenv('TDS_NO_NEAR_LISTS', '1')
+        m0 = ops.StaticMap(verts, faces, device=DEV, cell_size=cell)
+        monkeypatch.delenv('TDS_NO_NEAR_LISTS')
+        assert m.info()['near_candidates'] > 0 and m0.info()['near_candidates'] == 0
+        B, A = 8, 64
+        xy = gen.uniform(-90, 140, (B, A, 2))
+        xy[:3] = gen.uniform(0, 50, (3, A, 2))
+        state = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
+        lw = np.concatenate([gen.uniform(1, 6, (B, A, 1)), gen.uniform(1, 3, (B, A, 1))], -1).astype(np.float32)
+        sd = dev(state)
+        sc = ops.heading_sc(sd[..., 2])
+        for thr in (0.5, 0.0):
+            a = ops.offroad_forward(m, sd, dev(lw), sc, None, thr)
+            assert torch.equal(a, ops.offroad_forward(m0, sd, dev(lw), sc, None, thr))
+            if trial < 2:                                                                                   # the oracle has no NaN-vertex rule to compare with
+                ref = oracle.offroad(state[:4], lw[:4], verts, faces, thr, sc=sc_np(sc)[:4])
+                np.testing.assert_array_equal(a[:4].cpu().numpy(), ref)
+
+
 # ---------------------------------------------------------------------------------------------------- K3
 def oracle_static(oracle, verts, faces, vert_category, categories):
     return oracle.static_mesh_arrays(verts, faces, vert_category, categories)
