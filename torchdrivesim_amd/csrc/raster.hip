@@ -1632,10 +1632,11 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
     block_to_image(c.n_img * c.strips, c.strips, img, strip);
     const int X0 = strip * TWp;
     const int plane_dw = K * H * wpr;
-    uint32_t *planes = smem;
-    E *tab = (E *)(smem + ((plane_dw + 3) & ~3));                     // [3][P] output values of an index pair
+    // LDS: everything of fixed size first (addresses known at compile time), the planes (K * H * wpr words) last
+    E *tab = (E *)smem;                                                  // [3][P] output values of an index pair
+    uint32_t *lkeys = smem + pair_tab_dw<NB, OutT>();                     // [16] ascending key table
+    uint32_t *planes = lkeys + 16 + BWAVES * BITS_WAVE_LDS_DW;
     for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
-    uint32_t *lkeys = (uint32_t *)tab + pair_tab_dw<NB, OutT>();          // [16] ascending key table
     if (tid < 16) {
         uint32_t kv = 0xffffffffu;
 #pragma unroll
