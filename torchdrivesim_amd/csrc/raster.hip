@@ -1020,8 +1020,9 @@ __device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int s0, int s1) 
     atomicOr(rowp + w0, w0 == w1 ? (m0 & m1) : m0);
     if (w1 > w0) {
         atomicOr(rowp + w1, m1);
-        // words in between become all ones: a plain store is as good as an OR whatever else is being OR-ed into them
-        for (int wd = w0 + 1; wd < w1; ++wd) *(volatile uint32_t *)(rowp + wd) = 0xffffffffu;
+        // words in between become all ones (a volatile store through the generic pointer would become a flat store that waits for
+        // every outstanding global load of the wave: the OR stays in the LDS pipe)
+        for (int wd = w0 + 1; wd < w1; ++wd) atomicOr(rowp + wd, 0xffffffffu);
     }
 }
 
