@@ -44,7 +44,7 @@ def synth_agents(B, A, road_verts, seed):
     return state, size, present, actions
 
 
-def build_simulator(B, A, device, seed, metric='iou'):
+def build_simulator(B, A, device, seed, metric='iou', lanelet_map=None):
     from torchdrivesim_amd.kinematic import KinematicBicycle
     from torchdrivesim_amd.mesh import BirdviewMesh
     from torchdrivesim_amd.rendering import HipRendererConfig, renderer_from_config
@@ -59,7 +59,8 @@ def build_simulator(B, A, device, seed, metric='iou'):
     km.set_state(torch.from_numpy(state).to(device))
     cfg = TorchDriveConfig(collision_metric=CollisionMetric(metric), renderer=HipRendererConfig())
     renderer = renderer_from_config(cfg.renderer, res=Resolution(RES, RES), fov=FOV)
-    sim = Simulator(road, km, torch.from_numpy(size).to(device), torch.from_numpy(present).to(device), cfg, renderer=renderer)
+    sim = Simulator(road, km, torch.from_numpy(size).to(device), torch.from_numpy(present).to(device), cfg, renderer=renderer,
+                    lanelet_map=None if lanelet_map is None else [lanelet_map] * B)
     return sim, torch.from_numpy(actions).to(device), (state, size, present, actions, verts, faces, vcat, cats)
 
 

@@ -219,6 +219,50 @@ int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces
                     const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,
                     int out_mode, void *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Wrong-way query           simulator.py:607-630 (compute_wrong_way); infractions.py:232-304 (lanelet_orientation_loss);
+ *                           lanelet2.py:108-180 (find_lanelet_directions, find_direction)
+ * The reference keeps a lanelet2.core.LaneletMap (Lanelet2 C++ objects, not part of the reference's sources) and queries it agent by
+ * agent.  Here a map is flattened once into a LANE TABLE and a batch is one kernel launch.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct tds_lanes tds_lanes_t;
+typedef struct tds_laneset tds_laneset_t;
+
+/* Centre line of one lanelet (`lanelet.centerline`, lanelet2.py:128): HOST arrays, bounds n x 3 float64 in travel order, out must hold
+ * (n_left + n_right + 1) x 3 doubles, *n_out = number of points written (0 when a bound is empty). */
+int tds_lanelet_centerline_f64(const double *left, int n_left, const double *right, int n_right, double *out, int *n_out);
+
+/* HOST inputs: poly_xy P x 2 float64 = outline rings (left bound followed by the reversed right bound), lanelet l owns points
+ * poly_start[l] .. poly_start[l+1]; cl_xyz C x 3 float64 = centre lines, cl_start likewise; flags (n_lanelets, may be NULL): bit 0 =
+ * the lanelet carries one of the tags to exclude (infractions.py:21).  cell_size <= 0 selects the default (8 m).  Queries may use
+ * any lanelet_dist_tolerance up to max_tolerance.  The handle lives on the CURRENT HIP device. */
+int tds_lanes_create(const double *poly_xy, const int32_t *poly_start, const double *cl_xyz, const int32_t *cl_start,
+                     const int32_t *flags, int n_lanelets, float cell_size, float max_tolerance, tds_lanes_t **out);
+int tds_lanes_destroy(tds_lanes_t *lanes);
+/* info[0..3] = lanelets, grid nx, grid ny, device bytes held */
+int tds_lanes_info(const tds_lanes_t *lanes, int64_t *info);
+/* the lane tables of a batch (`lanelet_maps: List[Optional[LaneletMap]]`, infractions.py:232): a device array of views; the tables must
+ * outlive the set */
+int tds_laneset_create(const tds_lanes_t *const *lanes, int n, tds_laneset_t **out);
+int tds_laneset_destroy(tds_laneset_t *set);
+
+/* lanelet_orientation_loss [* present]:
+ *   state n x 4 (x, y, psi, v); agent a belongs to scene a / agents_per_scene, which uses table scene_map[scene] of the set
+ *   (device int32; a negative entry = `None`, loss 0; NULL = table 0 for every scene); recenter_offset (scenes x 2 or NULL) is added to
+ *   the position (infractions.py:271-273); present (n uint8 or NULL) multiplies the result (simulator.py:624).
+ *   out n = min over the lanelets within lanelet_dist_tolerance of -cos(d) * [|d| > direction_angle_threshold],
+ *   d = normalize_angle(lanelet direction - psi); 0 without such a lanelet, when one of them carries an excluded tag, or when
+ *   find_direction fails (LaneletError, infractions.py:290-294). */
+int tds_wrong_way_f32(const tds_laneset_t *set, const int32_t *scene_map, int64_t agents_per_scene, const float *state,
+                      const float *recenter_offset, const uint8_t *present, float *out, int64_t n_agents,
+                      float direction_angle_threshold, float lanelet_dist_tolerance, void *stream);
+/* find_lanelet_directions for a batch of points (xy n x 2 float64, as the reference passes host doubles): dirs / dists n x max_dirs
+ * float64 (direction and distance of the first max_dirs lanelets found, in table order), count n (number found, may exceed max_dirs; 0 when excluded), status n uint8 (bit 0: find_direction
+ * failed for some lanelet, bit 1: a lanelet with an excluded tag is within tolerance) */
+int tds_lanelet_directions_f64(const tds_laneset_t *set, const int32_t *scene_map, int64_t points_per_scene, const double *xy,
+                               double *dirs, double *dists, int32_t *count, uint8_t *status, int max_dirs, int64_t n_points,
+                               float lanelet_dist_tolerance, void *stream);
+
 /* test / tuning hook: force the LDS strip width of K3 (0 = automatic, else 8 .. 128 output rows) */
 int tds_raster_set_strip_width(int tw);
 

@@ -62,9 +62,10 @@ def test_out_of_scope_arguments_are_refused():
     from torchdrivesim_amd.simulator import Simulator
     sim = make_sim()
     with pytest.raises(NotImplementedError):
-        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lanelet_map=[object(), object()])
-    with pytest.raises(NotImplementedError):
         Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lane_features=object())
+    # lanelet maps are in scope (tests/test_lanelet2.py); scenes without one give zeros, as the reference
+    s2 = Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lanelet_map=[None, None])
+    assert s2.compute_wrong_way().shape == (2, 3) and not s2.compute_wrong_way().any()
 
 
 def test_kinematic_bookkeeping_and_fit_action():

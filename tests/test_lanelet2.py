@@ -1,0 +1,298 @@
+"""
+Lane maps and the wrong-way query (torchdrivesim_amd/lanelet2.py, csrc/lanes.hip, oracle/lanelet_oracle.py).
+
+What pins what:
+  * OSM reader + UTM projection + bound alignment + road / lane-marking meshes: the reference ships `carla_Town01_mesh.json`, generated
+    upstream from `carla_Town01.osm` with the real Lanelet2 (map.py:62-72, lanelet2.py:211-377); rebuilding it here from the same
+    `.osm` must give the same vertices and the same ORDERED triangles (tests/golden/town01_mesh.npz is that mesh).
+  * query: the known answers of the reference's tests/simulator/test_util.py:17-44.
+  * HIP kernel vs oracle: same lane tables, seeded agents, through the C ABI (-m gpu).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lanelet_oracle as lo
+from torchdrivesim_amd import lanelet2 as L
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def town01():
+    return L.load_lanelet_map(os.path.join(GOLD, 'carla_Town01.osm.gz'), origin=(0.0, 0.0))       # origin: the map's metadata.json
+
+
+@pytest.fixture(scope='module')
+def town01_mesh():
+    t = np.load(os.path.join(GOLD, 'town01_mesh.npz'))
+    return t['verts'], t['faces'], t['vert_category'], [str(c) for c in t['categories']]
+
+
+def _canon(tris, ordered=True):
+    """triangles (n,3,2) -> sorted list of coordinate tuples on a 0.1 mm lattice (the two builds differ by 1 ulp of float32 in places)"""
+    q = np.round(np.asarray(tris, np.float64) * 1e4).astype(np.int64)
+    if not ordered:
+        idx = np.lexsort((q[..., 1], q[..., 0]), axis=1)
+        q = np.take_along_axis(q, idx[..., None], 1)
+    return sorted(map(tuple, q.reshape(len(q), -1)))
+
+
+# ----------------------------------------------------------------------------------------------------------------- host, CPU
+def test_utm_and_osm_reader_reproduce_the_points_of_the_shipped_mesh(town01, town01_mesh):
+    verts, _, vcat, cats = town01_mesh
+    road = verts[vcat == cats.index('road')]                     # road_mesh_from_lanelet_map: one vertex per map point
+    mine = town01.points[:, :2].astype(np.float32)
+    assert mine.shape == road.shape == (9333, 2)
+    from scipy.spatial import cKDTree
+    d_fwd, i_fwd = cKDTree(road).query(mine)                     # the point layer's order is a hash order upstream: match by position
+    d_bwd, _ = cKDTree(mine).query(road)
+    assert d_fwd.max() < 2e-5 and d_bwd.max() < 2e-5             # 1 ulp of float32 at 400 m is 3e-5
+    assert len(np.unique(np.round(mine * 1e3), axis=0)) == len(np.unique(np.round(road * 1e3), axis=0))
+    assert len(town01.laneletLayer) == 124
+
+
+def test_utm_known_values():
+    # the equator / central meridian of zone 31 maps to (500 km, 0); relative to an origin the origin itself is (0, 0)
+    x, y = L.utm_forward(0.0, 3.0, 31)
+    assert abs(float(x) - 500000.0) < 1e-9 and abs(float(y)) < 1e-9
+    p = L.UtmProjector((49.0, 8.4))                              # Karlsruhe, zone 32
+    assert p.zone == 32
+    x, y = p.forward(np.array([49.0]), np.array([8.4]))
+    assert abs(x[0]) < 1e-9 and abs(y[0]) < 1e-9
+    # one degree of latitude on the central meridian: k0 * meridian arc (111 132.95 m/deg at the equator * 0.9996 -> 110 530 m .. 110 580 m)
+    _, y1 = L.utm_forward(1.0, 9.0, 32)
+    assert 110520.0 < float(y1) < 110560.0
+    assert L._standard_zone(60.0, 5.0) == 32 and L._standard_zone(78.0, 10.0) == 33     # Norway and Svalbard exceptions
+
+
+def test_road_mesh_equals_the_shipped_mesh_triangle_by_triangle(town01, town01_mesh):
+    verts, faces, vcat, cats = town01_mesh
+    fcat = vcat[faces[:, 0]]
+    ref = verts[faces[fcat == cats.index('road')]]
+    rm = L.road_mesh_from_lanelet_map(town01)
+    mine = rm.verts[0].numpy()[rm.faces[0].numpy()]
+    assert mine.shape == ref.shape
+    assert _canon(mine) == _canon(ref)                           # ORDERED triples: pins left / right roles and the bounds' directions
+
+
+def test_lane_marking_mesh_equals_the_shipped_mesh(town01, town01_mesh):
+    verts, faces, vcat, cats = town01_mesh
+    fcat = vcat[faces[:, 0]]
+    lm = L.lanelet_map_to_lane_mesh(town01, left_handed=False)
+    assert sorted(lm.categories) == sorted(c for c in cats if c != 'road')
+    mv, mf, mc = lm.verts[0].numpy(), lm.faces[0].numpy(), lm.vert_category[0].numpy()
+    for ci, name in enumerate(lm.categories):
+        mine = mv[mf[mc[mf[:, 0]] == ci]]
+        ref = verts[faces[fcat == cats.index(name)]]
+        assert _canon(mine) == _canon(ref), name
+
+
+def test_reference_test_map_loads():
+    m = L.load_lanelet_map(os.path.join(GOLD, 'testing_lanelet2map.osm'), origin=(0, 0))
+    assert len(m.laneletLayer) == 3 and m.points.shape == (12, 3)
+    for l in m.laneletLayer:
+        assert len(l.left) == len(l.right) == 3
+        assert L._signed_side(l.left, l.right[0]) < 0 and L._signed_side(l.right, l.left[0]) > 0       # right bound on the right
+    with pytest.raises(FileNotFoundError):
+        L.load_lanelet_map(os.path.join(GOLD, 'no_such_map.osm'))
+
+
+KAT_LEFT = [(0, 0, 10), (1, 1, 10), (2, 1, 10)]                  # tests/simulator/test_util.py:26-31
+KAT_RIGHT = [(0.05, 0, 10), (1, 0.95, 10), (2, 0.95, 10)]
+
+
+def test_native_centerline_equals_the_python_restatement(town01):
+    cases = [(np.array(KAT_LEFT, np.float64), np.array(KAT_RIGHT, np.float64))]
+    cases += [(l.left, l.right) for l in town01.laneletLayer[:12]]
+    m = L.load_lanelet_map(os.path.join(GOLD, 'testing_lanelet2map.osm'))
+    cases += [(l.left, l.right) for l in m.laneletLayer]
+    # a bent lanelet with unbalanced bounds and one with a single-point bound
+    t = np.linspace(0, math.pi / 2, 9)
+    cases.append((np.stack([8 * np.cos(t), 8 * np.sin(t), 0 * t], 1)[::-1].copy(), np.stack([12 * np.cos(t[::2]), 12 * np.sin(t[::2]), 0 * t[::2]], 1)[::-1].copy()))
+    cases.append((np.array([[0, 1, 0], [4, 1, 0.]]), np.array([[2, -1, 0.]])))
+    for left, right in cases:
+        a, b = L.calculate_centerline(left, right), lo.calculate_centerline(left, right)
+        assert a.shape == b.shape and np.array_equal(a, b)
+        assert len(a) >= 2 and np.array_equal(a[0], 0.5 * (left[0] + right[0])) and np.array_equal(a[-1], 0.5 * (left[-1] + right[-1]))
+    assert L.calculate_centerline(np.zeros((0, 3)), np.zeros((2, 3))).shape == (0, 3)
+    full = [len(L.calculate_centerline(l.left, l.right)) == len(l.left) + len(l.right) - 1 for l in town01.laneletLayer]
+    assert all(full)                                             # every bound point of these regular lanelets is paired
+
+
+class _KatMap:
+    def __init__(self, tag=False):
+        self.laneletLayer = [L.make_lanelet(7, KAT_LEFT, KAT_RIGHT, {'parking': ''} if tag else None)]
+
+
+def test_oracle_against_the_reference_tests_known_answers():
+    # test_get_direction_on_linestring (test_util.py:17-24)
+    assert lo.find_direction(np.array(KAT_LEFT, np.float64), np.array([0.5, 0.5, 0.0])) == np.pi / 4
+    # test_get_lanelet_orientation_loss (test_util.py:26-44)
+    state = np.array([[[0.5, 0.5, np.pi / 4, 1], [0.5, 0.5, 5 * np.pi / 4, 1]]] * 2, np.float32)
+    m = _KatMap()
+    np.testing.assert_allclose(lo.lanelet_orientation_loss([m, m], state), [[0.0, 1.0], [0.0, 1.0]], rtol=1e-5, atol=1e-8)
+    m = _KatMap(tag=True)
+    np.testing.assert_allclose(lo.lanelet_orientation_loss([m, m], state), np.zeros((2, 2)), rtol=1e-5, atol=1e-8)
+    np.testing.assert_array_equal(lo.lanelet_orientation_loss([None, None], state), np.zeros((2, 2)))
+    # a line that doubles back: the two vertices closest to the projection are not neighbours
+    with pytest.raises(lo.LaneletError):
+        lo.find_direction(np.array([[0, 0, 0], [10, 0, 0], [10, 0.1, 0], [0, 0.1, 0.]]), np.array([0.2, 0.05, 0.0]))
+
+
+def test_lane_table_layout(town01):
+    t = L.lane_table(town01, ['parking'])
+    n = len(town01.laneletLayer)
+    assert t.poly_start.shape == t.cl_start.shape == (n + 1,) and t.flags.shape == (n,) and not t.flags.any()
+    assert t.poly_xy.shape == (t.poly_start[-1], 2) and t.cl_xyz.shape == (t.cl_start[-1], 3)
+    l = town01.laneletLayer[5]
+    np.testing.assert_array_equal(t.poly_xy[t.poly_start[5]:t.poly_start[6]], np.concatenate([l.left[:, :2], l.right[::-1, :2]]))
+    t2 = L.lane_table(_KatMap(tag=True), ['parking'])
+    assert t2.flags.tolist() == [1]
+
+
+# ----------------------------------------------------------------------------------------------------------------- device
+def _agents(town01, B, A, seed):
+    """agents near the centre lines, half of them heading against the lane, plus strays far from any lanelet"""
+    g = np.random.default_rng(seed)
+    cl = np.concatenate([l.centerline for l in town01.laneletLayer])
+    k = g.integers(0, len(cl) - 1, (B, A))
+    xy = cl[k, :2] + g.normal(0, 1.5, (B, A, 2))
+    psi = g.uniform(-np.pi, np.pi, (B, A))
+    state = np.concatenate([xy, psi[..., None], g.uniform(0, 10, (B, A, 1))], -1).astype(np.float32)
+    state[0, :3, :2] = [[-500, -500], [1e6, 3], [float('nan'), 0]]
+    return state
+
+
+@gpu
+def test_wrong_way_kernel_equals_the_oracle_on_town01(town01):
+    from torchdrivesim_amd.infractions import lanelet_orientation_loss
+    dev = torch.device('cuda', 0)
+    B, A = 2, 48
+    state = _agents(town01, B, A, 3)
+    offset = np.array([[0.5, -0.25], [-1.0, 2.0]], np.float32)
+    for off in (None, offset):
+        for thr, tol in ((np.pi / 2, 1.0), (2.0, 0.25), (np.pi / 2, 0.0)):
+            ref = lo.lanelet_orientation_loss([town01, town01], state, off, thr, tol, centerline_fn=L.calculate_centerline)
+            out = lanelet_orientation_loss([town01, town01], torch.from_numpy(state).to(dev), None if off is None else torch.from_numpy(off).to(dev),
+                                           direction_angle_threshold=thr, lanelet_dist_tolerance=tol)
+            assert out.shape == (B, A) and out.dtype == torch.float32
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-6)
+            assert (ref > 0).sum() > 10 and (ref == 0).sum() > 10       # both outcomes are exercised
+    # scenes without a map, and different maps in one batch
+    kat = _KatMap()
+    kat_map = L.LaneletMap([], np.zeros((0, 3)), kat.laneletLayer)
+    maps = [None, town01, kat_map]
+    st = np.concatenate([state, state[:1]], 0)
+    st[2, :2] = [[0.5, 0.5, np.pi / 4, 1], [0.5, 0.5, 5 * np.pi / 4, 1]]
+    out = lanelet_orientation_loss(maps, torch.from_numpy(st).to(dev)).cpu().numpy()
+    ref = lo.lanelet_orientation_loss(maps, st, centerline_fn=L.calculate_centerline)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+    assert not out[0].any() and out[2, 0] == 0 and abs(out[2, 1] - 1) < 1e-6
+
+
+@gpu
+def test_reference_known_answers_on_the_device():
+    """tests/simulator/test_util.py:17-44 with this framework's API"""
+    from torchdrivesim_amd.infractions import lanelet_orientation_loss
+    dev = torch.device('cuda', 0)
+    assert L.find_direction(KAT_LEFT, (0.5, 0.5, 0)) == np.pi / 4
+    test_map = L.LaneletMap([], np.zeros((0, 3)), [])
+    lanelet = L.make_lanelet(1, KAT_LEFT, KAT_RIGHT)
+    test_map.add(lanelet)
+    state = torch.tensor([[[0.5, 0.5, np.pi / 4, 1], [0.5, 0.5, 5 * np.pi / 4, 1]]] * 2, device=dev)
+    assert torch.all(torch.isclose(lanelet_orientation_loss([test_map, test_map], state), torch.tensor([[0.0, 1.0], [0.0, 1.0]], device=dev)))
+    d = L.find_lanelet_directions(test_map, 0.5, 0.5)
+    assert len(d) == 1 and abs(d[0] - np.pi / 4) < 1e-12
+    assert L.find_lanelet_directions(test_map, 0.5, 3.0) == []
+    lanelet.attributes['parking'] = ''
+    test_map.add(L.make_lanelet(2, [(5, 5), (6, 5)], [(5, 4), (6, 4)]))        # `add` drops the cached tables
+    assert torch.all(lanelet_orientation_loss([test_map, test_map], state) == 0)
+    assert L.find_lanelet_directions(test_map, 0.5, 0.5, tags_to_exclude=['parking']) == []
+    with pytest.raises(L.LaneletError):
+        L.find_direction([[0, 0, 0], [10, 0, 0], [10, 0.1, 0], [0, 0.1, 0.]], (0.2, 0.05, 0.0))
+    with pytest.raises(RuntimeError):                                           # no CPU fallback
+        lanelet_orientation_loss([test_map], state[:1].cpu())
+
+
+@gpu
+def test_find_lanelet_directions_sorted_by_distance_as_findWithin2d(town01):
+    g = np.random.default_rng(11)
+    cl = np.concatenate([l.centerline for l in town01.laneletLayer])
+    cls = {id(l): l.centerline for l in town01.laneletLayer}
+    n_multi = 0
+    for k in g.integers(0, len(cl), 40):
+        x, y = cl[k, 0] + g.normal(0, 1), cl[k, 1] + g.normal(0, 1)
+        try:
+            ref = lo.find_lanelet_directions(town01.laneletLayer, cls, x, y, [], 1.0)
+        except lo.LaneletError:
+            with pytest.raises(L.LaneletError):
+                L.find_lanelet_directions(town01, x, y)
+            continue
+        out = L.find_lanelet_directions(town01, x, y)
+        assert len(out) == len(ref)
+        np.testing.assert_allclose(sorted(out), sorted(ref), rtol=0, atol=1e-12)
+        n_multi += len(ref) > 1
+    assert n_multi > 3
+
+
+@gpu
+def test_simulator_compute_wrong_way_full_size_properties(town01):
+    """B = 1024 x A = 64 (BASELINE.json's size): agents ON a centre line heading along it have loss 0, heading against it have loss
+    -cos(pi) = 1 unless another lanelet through the same spot (an intersection) agrees with them; absent agents read 0."""
+    import bench
+    dev = torch.device('cuda', 0)
+    B, A = 1024, 64
+    sim, actions, host = bench.build_simulator(B, A, dev, seed=5, lanelet_map=town01)
+    g = np.random.default_rng(5)
+    mids, dirs = [], []
+    for l in town01.laneletLayer:
+        c = l.centerline
+        mids.append(0.5 * (c[:-1, :2] + c[1:, :2]))
+        dirs.append(np.arctan2(c[1:, 1] - c[:-1, 1], c[1:, 0] - c[:-1, 0]))
+    mids, dirs = np.concatenate(mids), np.concatenate(dirs)
+    k = g.integers(0, len(mids), (B, A))
+    against = g.uniform(size=(B, A)) < 0.5
+    state = np.concatenate([mids[k], (dirs[k] + np.pi * against)[..., None], np.ones((B, A, 1))], -1).astype(np.float32)
+    sim.set_state(torch.from_numpy(state).to(dev))
+    ww = sim.compute_wrong_way()
+    assert ww.shape == (B, A) and ww.dtype == torch.float32
+    w = ww.cpu().numpy()
+    present = sim.get_present_mask().cpu().numpy()
+    assert (w >= 0).all() and (w <= 1 + 1e-6).all()
+    assert not w[~present].any()
+    assert not w[~against].any()                                 # with the lane: never an infraction
+    hit = w[against & present]
+    assert (hit > 0.99).mean() > 0.5           # the rest sit where lanelets of an intersection cross and one of them agrees
+    # the sample the oracle can afford: the first scene
+    ref = lo.lanelet_orientation_loss([town01], state[:1], centerline_fn=L.calculate_centerline) * present[:1]
+    np.testing.assert_allclose(w[:1], ref, rtol=0, atol=2e-6)
+    # batch plumbing keeps the lane maps
+    sub = sim.select_batch_elements(torch.tensor([3, 1]), in_place=False)
+    np.testing.assert_array_equal(sub.compute_wrong_way().cpu().numpy(), w[[3, 1]])
+    sim.lanelet_map = None
+    assert not sim.compute_wrong_way().any()
+
+
+def test_map_config_builds_the_mesh_from_the_lanelet_map(tmp_path, town01_mesh):
+    """MapConfig.road_mesh without a mesh file (reference map.py:62-72): lane markings merged with the triangulated lanelets"""
+    import json
+    import shutil
+    from torchdrivesim_amd.map import load_map_config
+    d = tmp_path / 'carla_Town01'
+    d.mkdir()
+    shutil.copyfile(os.path.join(GOLD, 'carla_Town01.osm.gz'), d / 'carla_Town01.osm.gz')
+    (d / 'metadata.json').write_text(json.dumps(dict(name='carla_Town01', left_handed_coordinates=True, lanelet_path='carla_Town01.osm.gz',
+                                                      lanelet_map_origin=[0.0, 0.0])))
+    cfg = load_map_config(str(d / 'metadata.json'))
+    assert len(cfg.lanelet_map.laneletLayer) == 124
+    mesh = cfg.road_mesh
+    verts, faces, vcat, cats = town01_mesh
+    assert mesh.categories == ['left_lane', 'right_lane', 'road'] or sorted(mesh.categories) == sorted(cats)
+    assert mesh.verts.shape == (1, len(verts), 2) and mesh.faces.shape == (1, len(faces), 3)
+    mv, mf = mesh.verts[0].numpy(), mesh.faces[0].numpy()
+    assert _canon(mv[mf]) == _canon(verts[faces])

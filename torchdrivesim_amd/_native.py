@@ -51,6 +51,14 @@ _SIGNATURES = {
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
     'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp],
     'tds_raster_set_strip_width': [_i32],
+    'tds_lanelet_centerline_f64': [_vp, _i32, _vp, _i32, _vp, ctypes.POINTER(_i32)],
+    'tds_lanes_create': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, ctypes.POINTER(_vp)],
+    'tds_lanes_destroy': [_vp],
+    'tds_lanes_info': [_vp, ctypes.POINTER(_i64)],
+    'tds_laneset_create': [ctypes.POINTER(_vp), _i32, ctypes.POINTER(_vp)],
+    'tds_laneset_destroy': [_vp],
+    'tds_wrong_way_f32': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
+    'tds_lanelet_directions_f64': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _vp],
 }
 
 

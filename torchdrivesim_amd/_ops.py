@@ -514,3 +514,123 @@ def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dty
              ctypes.cast(lv, ctypes.c_void_p), len(levels), float(scale), int(res),
              nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8, nat.dev_ptr(out, out_dtype, 'out'), nat.stream_ptr(dev))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# lane tables and the wrong-way query (csrc/lanes.hip)
+# ---------------------------------------------------------------------------------------------------------------
+class LaneTableHandle:
+    """Device-resident lane table of one map (tds_lanes_t), built from the HOST arrays of `lanelet2.lane_table`."""
+
+    def __init__(self, table, device='cuda', max_tolerance=1.0, cell_size=0.0):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('lane tables live on an MI355X; there is no CPU implementation')
+        self.max_tolerance = float(max_tolerance)
+        self.n_lanelets = int(len(table.flags))
+        poly = np.ascontiguousarray(table.poly_xy, np.float64)
+        cl = np.ascontiguousarray(table.cl_xyz, np.float64)
+        ps, cs = np.ascontiguousarray(table.poly_start, np.int32), np.ascontiguousarray(table.cl_start, np.int32)
+        fl = np.ascontiguousarray(table.flags, np.int32)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        handle = ctypes.c_void_p()
+        nat.call('tds_lanes_create', self.device, vp(poly), vp(ps), vp(cl), vp(cs), vp(fl), self.n_lanelets, float(cell_size),
+                 self.max_tolerance, ctypes.byref(handle))
+        self._h = handle
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError('LaneTableHandle was destroyed')
+        return self._h
+
+    def info(self):
+        buf = (ctypes.c_int64 * 4)()
+        nat.call('tds_lanes_info', self.device, self.handle, buf)
+        return dict(lanelets=buf[0], nx=buf[1], ny=buf[2], bytes=buf[3])
+
+    def close(self):
+        if getattr(self, '_h', None) is not None:
+            h, self._h = self._h, None
+            nat.call('tds_lanes_destroy', self.device, h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LaneTableSet:
+    """The lane tables of a batch (tds_laneset_t) + which of them every scene uses (`scene_map`, (B,) int32 on the device, -1 = the
+    scene has no lane map; None = every scene uses table 0)."""
+
+    def __init__(self, tables, scene_map=None):
+        assert len(tables) > 0
+        self.tables = list(tables)                   # keeps the tables alive
+        self.device = self.tables[0].device
+        self.scene_map = None if scene_map is None else _c(torch.as_tensor(scene_map).to(self.device), i32)
+        arr = (ctypes.c_void_p * len(self.tables))(*[t.handle for t in self.tables])
+        handle = ctypes.c_void_p()
+        nat.call('tds_laneset_create', self.device, arr, len(self.tables), ctypes.byref(handle))
+        self._h = handle
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError('LaneTableSet was destroyed')
+        return self._h
+
+    def close(self):
+        if getattr(self, '_h', None) is not None:
+            h, self._h = self._h, None
+            nat.call('tds_laneset_destroy', self.device, h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def wrong_way(lane_set, state, recenter_offset, present, direction_angle_threshold, lanelet_dist_tolerance):
+    """lanelet_orientation_loss (infractions.py:232-304) [* present]: state (B,A,4) -> (B,A) float32.  No gradient, as in the
+    reference (the lane directions come from host floats there)."""
+    state = _c(state.detach())
+    if state.dim() != 3 or state.shape[-1] != 4:
+        raise RuntimeError(f'wrong_way: state must be (B,A,4), got {tuple(state.shape)}')
+    B, A = state.shape[:2]
+    out = torch.empty((B, A), dtype=f32, device=state.device)
+    if B * A == 0:
+        return out
+    if lane_set.scene_map is not None and lane_set.scene_map.shape[0] != B:
+        raise RuntimeError(f'wrong_way: the lane-table set was made for {lane_set.scene_map.shape[0]} scenes, the state has {B}')
+    off = None if recenter_offset is None else _c(recenter_offset.detach())
+    pres = None
+    if present is not None:
+        pres = present.contiguous().view(u8) if present.dtype == torch.bool else _c(present, u8)
+    nat.call('tds_wrong_way_f32', state.device, lane_set.handle, None if lane_set.scene_map is None else nat.dev_ptr(lane_set.scene_map, i32, 'scene_map'),
+             A, nat.dev_ptr(state, f32, 'state'), None if off is None else nat.dev_ptr(off, f32, 'recenter_offset'),
+             None if pres is None else nat.dev_ptr(pres, u8, 'present'), nat.dev_ptr(out, f32, 'out'), B * A,
+             float(direction_angle_threshold), float(lanelet_dist_tolerance), nat.stream_ptr(state.device))
+    return out
+
+
+def lanelet_directions(tables, scene_map, points, lanelet_dist_tolerance, max_dirs=16):
+    """find_lanelet_directions for points (n,2) float64 on the device: (dirs (n,max_dirs) f64, dists (n,max_dirs) f64, count (n) i32,
+    status (n) u8: bit 0 find_direction failed, bit 1 excluded tag)"""
+    f64 = torch.float64
+    lane_set = tables if isinstance(tables, LaneTableSet) else LaneTableSet(tables, scene_map)
+    points = _c(points, f64)
+    n = points.shape[0]
+    dev = points.device
+    dirs = torch.zeros((n, max_dirs), dtype=f64, device=dev)
+    dists = torch.zeros((n, max_dirs), dtype=f64, device=dev)
+    count = torch.zeros((n,), dtype=i32, device=dev)
+    status = torch.zeros((n,), dtype=u8, device=dev)
+    pps = 1 if lane_set.scene_map is None else max(1, n // max(1, lane_set.scene_map.shape[0]))
+    nat.call('tds_lanelet_directions_f64', dev, lane_set.handle, None if lane_set.scene_map is None else nat.dev_ptr(lane_set.scene_map, i32, 'scene_map'),
+             pps, nat.dev_ptr(points, f64, 'points'), nat.dev_ptr(dirs, f64, 'dirs'), nat.dev_ptr(dists, f64, 'dists'),
+             nat.dev_ptr(count, i32, 'count'), nat.dev_ptr(status, u8, 'status'), max_dirs, n, float(lanelet_dist_tolerance),
+             nat.stream_ptr(dev))
+    return dirs, dists, count, status

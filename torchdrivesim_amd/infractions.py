@@ -86,10 +86,44 @@ def offroad_infraction_loss(agent_states: Tensor, lenwid: Tensor, driving_surfac
     return torch.cat([_ops.offroad(m, agent_states[b:b + 1], lenwid[b:b + 1], threshold=threshold) for m, b in maps], dim=0)
 
 
+LANELET_TAGS_TO_EXCLUDE = ['parking']          # infractions.py:21
+
+
+def lane_table_set(lanelet_maps, device, lanelet_dist_tolerance: float = 1.0) -> Optional[_ops.LaneTableSet]:
+    """The device lane tables of a batch of maps (one table per DISTINCT map object, entries `None` -> no table)."""
+    uniq, index = [], {}
+    scene_map = []
+    for m in lanelet_maps:
+        if m is None:
+            scene_map.append(-1)
+            continue
+        if id(m) not in index:
+            index[id(m)] = len(uniq)
+            uniq.append(m)
+        scene_map.append(index[id(m)])
+    if not uniq:
+        return None
+    tables = [m.table(device, LANELET_TAGS_TO_EXCLUDE, lanelet_dist_tolerance) for m in uniq]
+    return _ops.LaneTableSet(tables, torch.tensor(scene_map, dtype=torch.int32))
+
+
 def lanelet_orientation_loss(lanelet_maps, agents_state: Tensor, recenter_offset: Optional[Tensor] = None,
-                             direction_angle_threshold: float = np.pi / 2, lanelet_dist_tolerance: float = 1.0) -> Tensor:
-    """Wrong-way loss (infractions.py:232-304).  Needs Lanelet2, which is outside this framework's scope:
-    scenes without a map give zeros exactly as the reference does; a real map is refused loudly."""
-    if any(m is not None for m in lanelet_maps):
-        raise NotImplementedError('lanelet2-based wrong-way detection is not available in torchdrivesim_amd')
-    return torch.zeros(agents_state.shape[:2], dtype=torch.float, device=agents_state.device)
+                             direction_angle_threshold: float = np.pi / 2, lanelet_dist_tolerance: float = 1.0,
+                             lane_set: Optional[_ops.LaneTableSet] = None) -> Tensor:
+    """
+    Wrong-way loss (infractions.py:232-304): for every agent the lanelets within `lanelet_dist_tolerance` of its position, the
+    local direction of each one's centre line, d = normalize_angle(direction - psi), loss = min over them of
+    -cos(d) * [|d| > direction_angle_threshold]; 0 without such a lanelet, for scenes whose map is None, near a lanelet tagged
+    'parking', and where the reference's `find_direction` raises.  One kernel launch for the batch (csrc/lanes.hip) instead of the
+    reference's Python loop over scenes, agents and lanelets.  `lanelet_maps`: a list of B `torchdrivesim_amd.lanelet2.LaneletMap`
+    or None; `lane_set`: the prepared tables of these maps (callers that query every step keep it).
+    """
+    assert len(lanelet_maps) == agents_state.shape[0]
+    if recenter_offset is not None:
+        assert len(lanelet_maps) == recenter_offset.shape[0]
+    assert direction_angle_threshold >= np.pi / 2, 'direction_angle_threshold smaller than pi / 2 will produce false positives'
+    if lane_set is None:
+        lane_set = lane_table_set(lanelet_maps, agents_state.device, lanelet_dist_tolerance)
+    if lane_set is None or agents_state.shape[1] == 0:
+        return torch.zeros(agents_state.shape[:2], dtype=torch.float, device=agents_state.device)
+    return _ops.wrong_way(lane_set, agents_state, recenter_offset, None, direction_angle_threshold, lanelet_dist_tolerance)

@@ -54,14 +54,19 @@ class MapConfig:
     def lanelet_map(self):
         if self.lanelet_path is None:
             return None
-        raise NotImplementedError('Lanelet2 maps are outside the scope of torchdrivesim_amd (SURVEY.md section 8: wrong-way is a later row)')
+        from .lanelet2 import load_lanelet_map
+        return load_lanelet_map(self.lanelet_path, origin=tuple(self.lanelet_map_origin))       # map.py:56-60
 
     @property
     def road_mesh(self) -> Optional[BirdviewMesh]:
         if self.mesh_path is None:
             if self.lanelet_path is None:
                 return None
-            raise NotImplementedError('building the road mesh from a Lanelet2 map needs lanelet2; ship a <name>_mesh.json instead')
+            from .lanelet2 import road_mesh_from_lanelet_map, lanelet_map_to_lane_mesh
+            lanelet_map = self.lanelet_map                                                        # map.py:67-72
+            road_mesh = BirdviewMesh.set_properties(road_mesh_from_lanelet_map(lanelet_map), category='road')
+            lane_mesh = lanelet_map_to_lane_mesh(lanelet_map, left_handed=False)
+            return lane_mesh.merge(road_mesh)
         return BirdviewMesh.load(self.mesh_path)
 
     @property

@@ -9,8 +9,10 @@
     compute_collision  -> K2a, all agents of all scenes in one launch        reference: simulator.py:1064-1194 (A launches)
     compute_offroad    -> K2b over the device-resident map grid              reference: simulator.py:1035-1044
 
+    compute_wrong_way  -> lane tables of `lanelet_map` (lanelet2.py), one launch  reference: simulator.py:607-630 (Python triple loop)
+
 Also carried: traffic controls, waypoint goals (state + rendering) and observation noise.  Out of scope:
-lanelet maps and lane features; passing them raises NotImplementedError instead of silently ignoring them.
+lane features; passing them raises NotImplementedError instead of silently ignoring them.
 """
 import logging
 from dataclasses import dataclass, field
@@ -22,6 +24,7 @@ import torch
 from torch import Tensor
 
 from torchdrivesim_amd import _ops
+from torchdrivesim_amd.infractions import lane_table_set
 from torchdrivesim_amd.kinematic import KinematicModel
 from torchdrivesim_amd.mesh import BirdviewMesh, BirdviewRGBMeshGenerator, actor_template, set_colors_with_defaults
 from torchdrivesim_amd.rendering import BirdviewRenderer, RendererConfig, renderer_from_config, HipRenderer
@@ -155,9 +158,9 @@ class Simulator:
                  waypoint_goals=None, agent_types: Optional[Tensor] = None, agent_type_names: Optional[List[str]] = None,
                  npc_controller: Optional[NPCController] = None, agent_lr: Optional[Tensor] = None, lane_features=None,
                  observation_noise_model=None, action_model_extras: Optional[Dict[str, Any]] = None):
-        for name, val in (('lanelet_map', lanelet_map), ('lane_features', lane_features)):
-            if val is not None and not (name == 'lanelet_map' and all(m is None for m in val)):
-                raise NotImplementedError(f'`{name}` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
+        if lane_features is not None:
+            raise NotImplementedError('`lane_features` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
+        self._lane_set = None                            # device lane tables of `lanelet_map`, made on the first compute_wrong_way
         self.road_mesh = road_mesh
         self.lanelet_map = lanelet_map
         self.recenter_offset = recenter_offset
@@ -278,6 +281,7 @@ class Simulator:
         self.agent_lr, self.present_mask = _enlarge(self.agent_lr, n), _enlarge(self.present_mask, n)
         self.recenter_offset = _enlarge(self.recenter_offset, n) if self.recenter_offset is not None else None
         self.lanelet_map = [m for m in self.lanelet_map for _ in range(n)] if self.lanelet_map is not None else None
+        self._lane_set = None
         self.kinematic_model.extend(n)
         self._batch_size *= n
         self.birdview_mesh_generator = self.birdview_mesh_generator.expand(n)
@@ -297,6 +301,7 @@ class Simulator:
         self.road_mesh = self.road_mesh[idx]
         self.recenter_offset = self.recenter_offset[idx] if self.recenter_offset is not None else None
         self.lanelet_map = [self.lanelet_map[i] for i in idx] if self.lanelet_map is not None else None
+        self._lane_set = None
         self.agent_size, self.agent_type = self.agent_size[idx], self.agent_type[idx]
         self.agent_lr, self.present_mask = self.agent_lr[idx], self.present_mask[idx]
         self.kinematic_model.select_batch_elements(idx)
@@ -714,9 +719,17 @@ class Simulator:
         return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 
     def compute_wrong_way(self) -> Tensor:
-        """Zeros without a lanelet map, as the reference (simulator.py:607-630)."""
+        """Wrong-way metric per agent, -cos of the angle between the agent and the lane it is on where that angle exceeds
+        `cfg.wrong_way_angle_threshold` (simulator.py:607-630 -> infractions.lanelet_orientation_loss), times the present mask.
+        Zeros without a lanelet map, as the reference.  `lanelet_map`: a list of B `lanelet2.LaneletMap` or None."""
         state = self.get_state()
-        return torch.zeros(state.shape[0], state.shape[1], device=state.device)
+        if self.lanelet_map is None or all(m is None for m in self.lanelet_map):
+            return torch.zeros(state.shape[0], state.shape[1], device=state.device)
+        tol = self.cfg.lanelet_inclusion_tolerance
+        if self._lane_set is None or self._lane_set[1] < tol or self._lane_set[0].device != state.device:
+            self._lane_set = (lane_table_set(self.lanelet_map, state.device, tol), tol)
+        assert self.cfg.wrong_way_angle_threshold >= np.pi / 2, 'direction_angle_threshold smaller than pi / 2 will produce false positives'
+        return _ops.wrong_way(self._lane_set[0], state, self.recenter_offset, self.get_present_mask(), self.cfg.wrong_way_angle_threshold, tol)
 
     def compute_traffic_lights_violations(self) -> Tensor:
         """BxA: the agent is (mostly) past the stop line of a red light (simulator.py:1046-1062)."""
