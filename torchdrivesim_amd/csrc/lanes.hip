@@ -7,7 +7,7 @@
 //
 // The reference asks the Lanelet2 C++ library one agent at a time.  Here a map is flattened ONCE on the host into a lane table
 // (outline polygon and centre line of every lanelet as float64 arrays, a uniform grid of lanelet indices) and the whole batch is
-// answered by one launch, one thread per agent, in float64 up to the direction angle (Lanelet2 computes in double) and in
+// answered by one launch, sixteen lanes per agent, in float64 up to the direction angle (Lanelet2 computes in double) and in
 // float32 from there on (the reference continues with `torch.tensor(directions)`, infractions.py:283).
 //
 // Host part of this file: the centre line of a lanelet (lanelet2_core Lanelet.cpp `calculateCenterline`, restated from the
@@ -310,37 +310,53 @@ TDS_EXPORT int tds_laneset_destroy(tds_laneset_t *s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// device: the query
+// device: the query.  An agent is served by a GROUP of 16 lanes (a quarter wavefront): the lanes split the outline edges and the
+// centre-line points of a candidate lanelet between them and combine their partial results with xor-shuffles inside the group,
+// so that 65 536 agents are 16 384 wavefronts (the first version, one thread per agent with serial loops over up to 250 points
+// per lanelet, ran one wave per SIMD and took 1.0 ms at B = 1024 x A = 64).
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int GROUP = 16;
+
+__device__ inline double group_min(double v) {
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) v = fmin(v, __shfl_xor(v, m, GROUP));
+    return v;
+}
+
 // squared distance from (x, y) to the outline ring, 0 when the point is inside (boost::geometry::distance(point, polygon) as used by
-// lanelet2 geometry::findWithin2d)
-__device__ double ring_distance2(const double *poly, int n, double x, double y) {
-    bool inside = false;
+// lanelet2 geometry::findWithin2d); edge i runs from point i-1 to point i, lanes take every 16th edge
+__device__ double ring_distance2(const double *poly, int n, double x, double y, int g) {
+    int parity = 0;
     double best = INFINITY;
-    double ax = poly[2 * (n - 1)], ay = poly[2 * (n - 1) + 1];
-    for (int i = 0; i < n; i++) {
-        double bx = poly[2 * i], by = poly[2 * i + 1];
+    for (int i = g; i < n; i += GROUP) {
+        int ia = i == 0 ? n - 1 : i - 1;
+        double ax = poly[2 * ia], ay = poly[2 * ia + 1], bx = poly[2 * i], by = poly[2 * i + 1];
         if ((ay > y) != (by > y)) {
             double xc = ax + (y - ay) * (bx - ax) / (by - ay);
-            if (x < xc) inside = !inside;
+            if (x < xc) parity ^= 1;
         }
         double dx = bx - ax, dy = by - ay, l2 = dx * dx + dy * dy;
         double t = l2 > 0 ? ((x - ax) * dx + (y - ay) * dy) / l2 : 0.0;
         t = fmin(fmax(t, 0.0), 1.0);
         double fx = ax + t * dx - x, fy = ay + t * dy - y;
         best = fmin(best, fx * fx + fy * fy);
-        ax = bx, ay = by;
     }
-    return inside ? 0.0 : best;
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) parity ^= __shfl_xor(parity, m, GROUP);
+    best = group_min(best);
+    return parity ? 0.0 : best;
 }
 
+__device__ inline bool lex_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+
 // find_direction (lanelet2.py:144-180): false when the two vertices closest to the projection are not neighbours
-__device__ bool line_direction(const double *cl, int n, double x, double y, double *dir) {
+__device__ bool line_direction(const double *cl, int n, double x, double y, int g, double *dir) {
     // lanelet2.geometry.project(linestring, BasicPoint3d(x, y, 0)): the closest point of the line, first segment on ties
-    double px = 0, py = 0, pz = 0, best = INFINITY;
-    for (int i = 0; i + 1 < n; i++) {
+    double best = INFINITY;
+    int sb = 0x7fffffff;
+    for (int i = g; i + 1 < n; i += GROUP) {
         double ax = cl[3 * i], ay = cl[3 * i + 1], az = cl[3 * i + 2];
         double dx = cl[3 * i + 3] - ax, dy = cl[3 * i + 4] - ay, dz = cl[3 * i + 5] - az;
         double l2 = dx * dx + dy * dy + dz * dz;
@@ -348,21 +364,49 @@ __device__ bool line_direction(const double *cl, int n, double x, double y, doub
         t = fmin(fmax(t, 0.0), 1.0);
         double fx = ax + t * dx, fy = ay + t * dy, fz = az + t * dz;
         double d2 = (fx - x) * (fx - x) + (fy - y) * (fy - y) + fz * fz;
-        if (d2 < best) best = d2, px = fx, py = fy, pz = fz;
+        if (d2 < best) best = d2, sb = i;
     }
-    double first = INFINITY, second = INFINITY;
-    int i1 = 0, i2 = 0;
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) {
+        double od = __shfl_xor(best, m, GROUP);
+        int oi = __shfl_xor(sb, m, GROUP);
+        if (lex_less(od, oi, best, sb)) best = od, sb = oi;
+    }
+    double px, py, pz;
+    {   // the foot point on the winning segment, with the arithmetic of the scan above
+        double ax = cl[3 * sb], ay = cl[3 * sb + 1], az = cl[3 * sb + 2];
+        double dx = cl[3 * sb + 3] - ax, dy = cl[3 * sb + 4] - ay, dz = cl[3 * sb + 5] - az;
+        double l2 = dx * dx + dy * dy + dz * dz;
+        double t = l2 > 0 ? ((x - ax) * dx + (y - ay) * dy + (0.0 - az) * dz) / l2 : 0.0;
+        t = fmin(fmax(t, 0.0), 1.0);
+        px = ax + t * dx, py = ay + t * dy, pz = az + t * dz;
+    }
+    // the two vertices closest to the projection: the reference's sequential scan (strict <) keeps the two smallest in the order
+    // (distance, index)
+    double d1 = INFINITY, d2 = INFINITY;
+    int i1 = 0x7fffffff, i2 = 0x7fffffff;
+    for (int i = g; i < n; i += GROUP) {
         double dx = cl[3 * i] - px, dy = cl[3 * i + 1] - py, dz = cl[3 * i + 2] - pz;
         double d = sqrt(dx * dx + dy * dy + dz * dz);
-        if (d < first) {
-            second = first, first = d, i2 = i1, i1 = i;
-        } else if (d < second) {
-            second = d, i2 = i;
+        if (lex_less(d, i, d1, i1)) {
+            d2 = d1, i2 = i1, d1 = d, i1 = i;
+        } else if (lex_less(d, i, d2, i2)) {
+            d2 = d, i2 = i;
+        }
+    }
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) {
+        double e1 = __shfl_xor(d1, m, GROUP), e2 = __shfl_xor(d2, m, GROUP);
+        int j1 = __shfl_xor(i1, m, GROUP), j2 = __shfl_xor(i2, m, GROUP);
+        if (lex_less(d1, i1, e1, j1)) {                   // mine first; second = the better of my second and the other's first
+            if (!lex_less(d2, i2, e1, j1)) d2 = e1, i2 = j1;
+        } else {
+            if (lex_less(e2, j2, d1, i1)) d2 = e2, i2 = j2; else d2 = d1, i2 = i1;
+            d1 = e1, i1 = j1;
         }
     }
     int lo = min(i1, i2), hi = max(i1, i2);
-    if (hi - lo != 1) return false;
+    if (i2 == 0x7fffffff || hi - lo != 1) return false;
     *dir = atan2(cl[3 * hi + 1] - cl[3 * lo + 1], cl[3 * hi] - cl[3 * lo]);
     return true;
 }
@@ -380,8 +424,9 @@ __global__ __launch_bounds__(256) void wrong_way_kernel(const LaneView *views, c
                                                         const float *offset, const uint8_t *present, float *out, double *dirs,
                                                         double *dists, int32_t *count, uint8_t *status, int max_dirs, int64_t n,
                                                         float tol, float thr) {
-    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
+    int64_t a = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+    int g = threadIdx.x & (GROUP - 1);
+    if (a >= n) return;                               // whole groups leave together
     int64_t scene = a / agents_per_scene;
     int m = scene_map ? scene_map[scene] : 0;
     float loss = 0.f;
@@ -402,10 +447,10 @@ __global__ __launch_bounds__(256) void wrong_way_kernel(const LaneView *views, c
         if (cx >= 0 && cy >= 0 && cx < v.nx && cy < v.ny) {              // also false for NaN coordinates
             int c = cy * v.nx + cx;
             double t = (double)tol;
-            for (int it = v.cell_start[c]; it < v.cell_start[c + 1] && !excluded; it++) {
+            for (int it = v.cell_start[c]; it < v.cell_start[c + 1]; it++) {
                 const LaneRec r = v.rec[v.cell_items[it]];
                 if (x < (double)r.bx0 - t || x > (double)r.bx1 + t || y < (double)r.by0 - t || y > (double)r.by1 + t) continue;
-                double d = sqrt(ring_distance2(v.poly + 2 * (int64_t)r.poly_start, r.poly_n, x, y));
+                double d = sqrt(ring_distance2(v.poly + 2 * (int64_t)r.poly_start, r.poly_n, x, y, g));
                 if (!(d <= t)) continue;
                 if (r.cl_n < 2) continue;                                 // lanelet2.py:131-132
                 if (r.flags & 1) {                                        // lanelet2.py:133-135: no directions at all
@@ -413,7 +458,7 @@ __global__ __launch_bounds__(256) void wrong_way_kernel(const LaneView *views, c
                     break;
                 }
                 double dir;
-                if (!line_direction(v.cl + 3 * (int64_t)r.cl_start, r.cl_n, x, y, &dir)) {
+                if (!line_direction(v.cl + 3 * (int64_t)r.cl_start, r.cl_n, x, y, g, &dir)) {
                     failed = true;                                        // LaneletError -> loss 0 (infractions.py:290-294)
                     continue;
                 }
@@ -421,11 +466,12 @@ __global__ __launch_bounds__(256) void wrong_way_kernel(const LaneView *views, c
                 float delta = normalize_angle_f32(df - ps);
                 float l = -cosf(delta) * (fabsf(delta) > thr ? 1.f : 0.f);
                 loss = k == 0 ? l : fminf(loss, l);
-                if (dirs && k < max_dirs) dirs[a * max_dirs + k] = dir, dists[a * max_dirs + k] = d;
+                if (dirs && k < max_dirs && g == 0) dirs[a * max_dirs + k] = dir, dists[a * max_dirs + k] = d;
                 k++;
             }
         }
     }
+    if (g != 0) return;
     if (excluded || failed) loss = 0.f, k = excluded ? 0 : k;
     if (present && !present[a]) loss = 0.f;       // `* self.get_present_mask()`, simulator.py:624 (loss is never NaN or infinite)
     if (out) out[a] = loss;
@@ -446,7 +492,7 @@ TDS_EXPORT int tds_wrong_way_f32(const tds_laneset_t *set, const int32_t *scene_
     TDS_CHECK_ARG(scene_map || set->n == 1, "tds_wrong_way_f32: a set of %d lane tables needs scene_map", set->n);
     if (n_agents == 0) return TDS_OK;
     TDS_CHECK_ARG(state, "tds_wrong_way_f32: state is null");
-    unsigned blocks = (unsigned)((n_agents + 255) / 256);
+    unsigned blocks = (unsigned)((n_agents * GROUP + 255) / 256);
     hipLaunchKernelGGL(wrong_way_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, set->d_views, scene_map, agents_per_scene, state,
                        (const double *)nullptr, state + 2, recenter_offset, present, out, (double *)nullptr, (double *)nullptr,
                        (int32_t *)nullptr, (uint8_t *)nullptr, 0, n_agents, lanelet_dist_tolerance, direction_angle_threshold);
@@ -465,7 +511,7 @@ TDS_EXPORT int tds_lanelet_directions_f64(const tds_laneset_t *set, const int32_
     TDS_CHECK_ARG(scene_map || set->n == 1, "tds_lanelet_directions_f64: a set of %d lane tables needs scene_map", set->n);
     if (n_points == 0) return TDS_OK;
     TDS_CHECK_ARG(xy, "tds_lanelet_directions_f64: xy is null");
-    unsigned blocks = (unsigned)((n_points + 255) / 256);
+    unsigned blocks = (unsigned)((n_points * GROUP + 255) / 256);
     hipLaunchKernelGGL(wrong_way_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, set->d_views, scene_map, points_per_scene,
                        (const float *)nullptr, xy, (const float *)nullptr, (const float *)nullptr, (const uint8_t *)nullptr, (float *)nullptr,
                        dirs, dists, count, status, max_dirs, n_points, lanelet_dist_tolerance, 4.f);
