@@ -128,8 +128,91 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
     // same boundary integral taken over every colour boundary of the image, i.e. over neighbouring pixel pairs:
     //   dL/dtheta = - sum_pairs f (I_B - I_A) (n . dp/dtheta),   dp/dcx = k (cc, -cs),  dp/dcy = k (cs, cc),
     //   dp/dcos = Rc^T (p - centre),  dp/dsin = (rot -90) of it      (p = -k Rc (w - cam) + centre)
+    // Memory: this pass reads the forward image and the incoming gradient once (2 x 786 432 B per camera at 256 x 256: the algorithmic
+    // bytes of the kernel).  A thread owns four neighbouring pixels of the fastest axis (one float4 per channel and array) and walks down a
+    // band of rows keeping the previous row in registers; the pixel to the right of its four comes from the next lane.
     {
         float Sx = 0.0f, Sy = 0.0f, Cc = 0.0f, Cs = 0.0f;
+        if ((res & 3) == 0 && res >= 8) {
+            const int CG = res >> 2;                                     // column groups per row
+            const int NB = max(1, min(res, BW_BLOCK / CG));              // row bands
+            const int RB = (res + NB - 1) / NB;
+            const int lane = tid & 63;
+            for (int item = tid; item < ((CG * NB + 63) & ~63); item += BW_BLOCK) {      // whole waves iterate together (shuffles below)
+                const bool live = item < CG * NB;
+                const int cg = live ? item % CG : 0, band = live ? item / CG : 0;
+                const int jc = cg * 4, r0 = band * RB, r1 = live ? min(res, r0 + RB) : r0;
+                float4 pi[3], pg[3];
+                if (r0 < r1) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        pi[ch] = *(const float4 *)(I + ch * plane + (int64_t)r0 * res + jc);
+                        pg[ch] = *(const float4 *)(G + ch * plane + (int64_t)r0 * res + jc);
+                    }
+                }
+                for (int rr = 0; rr < RB; ++rr) {                        // every lane of the wave runs RB rows (`on` masks the short last band)
+                    const int i = r0 + rr;
+                    const bool on = i < r1;
+                    // pairs along the fastest axis (pixel y): the fifth pixel is the first one of the next lane's group
+                    float ni[3], ng[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        ni[ch] = __shfl_down(pi[ch].x, 1);
+                        ng[ch] = __shfl_down(pg[ch].x, 1);
+                    }
+                    const bool has_right = on && cg + 1 < CG;
+                    if (has_right && lane == 63) {                           // the neighbour group sits in the next wave
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            ni[ch] = I[ch * plane + (int64_t)i * res + jc + 4];
+                            ng[ch] = G[ch * plane + (int64_t)i * res + jc + 4];
+                        }
+                    }
+                    if (on) {
+                        const float dxr = (float)i + 0.5f - half;
+                        float D[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            D[0] += 0.5f * (pg[ch].x + pg[ch].y) * (pi[ch].y - pi[ch].x);
+                            D[1] += 0.5f * (pg[ch].y + pg[ch].z) * (pi[ch].z - pi[ch].y);
+                            D[2] += 0.5f * (pg[ch].z + pg[ch].w) * (pi[ch].w - pi[ch].z);
+                            D[3] += 0.5f * (pg[ch].w + ng[ch]) * (ni[ch] - pi[ch].w);
+                        }
+                        if (!has_right) D[3] = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float dy = (float)(jc + q + 1) - half;
+                            Sy += D[q]; Cc += D[q] * (cs * dxr + cc * dy); Cs += -D[q] * (cc * dxr - cs * dy);
+                        }
+                    }
+                    // pairs along the slow axis (pixel x): this row and the next one
+                    if (on && i + 1 < res) {
+                        float4 qi[3], qg[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            qi[ch] = *(const float4 *)(I + ch * plane + (int64_t)(i + 1) * res + jc);
+                            qg[ch] = *(const float4 *)(G + ch * plane + (int64_t)(i + 1) * res + jc);
+                        }
+                        float D[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            D[0] += 0.5f * (pg[ch].x + qg[ch].x) * (qi[ch].x - pi[ch].x);
+                            D[1] += 0.5f * (pg[ch].y + qg[ch].y) * (qi[ch].y - pi[ch].y);
+                            D[2] += 0.5f * (pg[ch].z + qg[ch].z) * (qi[ch].z - pi[ch].z);
+                            D[3] += 0.5f * (pg[ch].w + qg[ch].w) * (qi[ch].w - pi[ch].w);
+                        }
+                        const float dx = (float)(i + 1) - half;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float dy = (float)(jc + q) + 0.5f - half;
+                            Sx += D[q]; Cc += D[q] * (cc * dx - cs * dy); Cs += D[q] * (cs * dx + cc * dy);
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) pi[ch] = qi[ch], pg[ch] = qg[ch];
+                    }
+                }
+            }
+        } else {
         for (int idx = tid; idx < res * res; idx += BW_BLOCK) {
             const int i = idx / res, j = idx - i * res;                       // out[ch][i][j]: i = pixel x, j = pixel y
             const int64_t o0 = (int64_t)i * res + j;
@@ -149,6 +232,7 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
                 const float dx = (float)i + 0.5f - half, dy = (float)(j + 1) - half;
                 Sy += D; Cc += D * (cs * dx + cc * dy); Cs += -D * (cc * dx - cs * dy);
             }
+        }
         }
         gcam[0] = -k * (cc * Sx - cs * Sy);
         gcam[1] = -k * (cs * Sx + cc * Sy);
