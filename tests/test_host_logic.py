@@ -141,3 +141,41 @@ def test_generator_matches_reference_generate():
     np.testing.assert_array_equal(rgb.verts[:, nv:].numpy(), g['g4_gen_actor_verts'])
     np.testing.assert_array_equal(rgb.faces[:, nf:].numpy(), g['g4_gen_actor_faces'])       # masked agents alias the first actor vertex
     np.testing.assert_array_equal(rgb.attrs[:, nv:].numpy(), g['g4_gen_actor_attrs'])
+
+
+def test_compound_npc_controller_merges_by_owner():
+    """simulator.py:206-278: every NPC is advanced by the controller that owns it; all controllers see the merged scene"""
+    from torchdrivesim_amd.simulator import NPCController, CompoundNPCController
+
+    class Mover(NPCController):
+        def __init__(self, *a, dx=0.0, **k):
+            super().__init__(*a, **k)
+            self.dx = dx
+
+        def advance_npcs(self, simulator):
+            self.npc_state = self.npc_state + torch.tensor([self.dx, 0.0, 0.0, 0.0])
+
+        def copy(self):
+            c = super().copy()
+            c.dx = self.dx
+            return c
+
+    B, n = 2, 3
+    size = torch.ones(B, n, 2)
+    state = torch.arange(B * n * 4, dtype=torch.float32).reshape(B, n, 4)
+    present = torch.tensor([[True, False, True], [True, True, True]])
+    a, b = Mover(size, state.clone(), present.clone(), dx=1.0), Mover(size * 2, state.clone() + 100, ~present, dx=-1.0)
+    owner = torch.tensor([[0, 1, 0], [1, 1, 0]])
+    comp = CompoundNPCController([a, b], owner)
+    want = torch.where((owner == 0).unsqueeze(-1), state, state + 100)
+    assert torch.equal(comp.get_npc_state(), want) and a.npc_state is comp.npc_state and b.npc_state is comp.npc_state
+    assert torch.equal(comp.get_npc_present_mask(), torch.where(owner == 0, present, ~present))
+    assert torch.equal(comp.get_npc_size()[..., 0], torch.where(owner == 0, 1.0, 2.0))
+    comp.advance_npcs(None)
+    moved = want + torch.where((owner == 0).unsqueeze(-1), torch.tensor([1.0, 0, 0, 0]), torch.tensor([-1.0, 0, 0, 0]))
+    assert torch.equal(comp.get_npc_state(), moved)
+    big = comp.extend(2, in_place=False)
+    assert big.get_npc_state().shape == (4, n, 4) and torch.equal(big.controller_indices, owner.repeat_interleave(2, 0))
+    assert torch.equal(big.get_npc_state()[::2], moved) and comp.get_npc_state().shape == (B, n, 4)
+    sel = comp.select_batch_elements(torch.tensor([1]), in_place=False)
+    assert torch.equal(sel.get_npc_state(), moved[1:]) and torch.equal(sel.controller_indices, owner[1:])

@@ -149,6 +149,65 @@ class NPCController:
         return me._map(lambda x: x[idx])
 
 
+class CompoundNPCController(NPCController):
+    """
+    Several NPC controllers over one set of NPCs: `controller_indices` (BxNpc) says which controller owns which NPC
+    (simulator.py:206-278).  After every advance the owners' results are merged and the merged tensors handed back to ALL controllers,
+    so that each of them sees the whole scene.  Deviation: `extend` repeats `controller_indices` per scene like every other tensor
+    (the reference's `expand(n, -1)` only works for a batch of one).
+    """
+
+    def __init__(self, controllers: List[NPCController], controller_indices: Tensor):
+        B, n = controller_indices.shape
+        dev = controller_indices.device
+        super().__init__(torch.zeros((B, n, 2), device=dev), torch.zeros((B, n, 4), device=dev), torch.zeros((B, n), device=dev, dtype=torch.bool),
+                         None if controllers[0].npc_types is None else torch.zeros((B, n), device=dev, dtype=torch.long), controllers[0].agent_type_names)
+        self.controllers = controllers
+        self.controller_indices = controller_indices
+        self.gather_npc_states()
+
+    def gather_npc_states(self):
+        for i, c in enumerate(self.controllers):
+            mine = self.controller_indices == i
+            self.npc_size = c.npc_size.where(mine.unsqueeze(-1), self.npc_size)
+            self.npc_state = c.npc_state.where(mine.unsqueeze(-1), self.npc_state)
+            self.npc_present_mask = c.npc_present_mask.where(mine, self.npc_present_mask)
+            self.npc_types = c.npc_types.where(mine, self.npc_types)
+        for c in self.controllers:
+            c.npc_size, c.npc_state, c.npc_present_mask, c.npc_types = self.npc_size, self.npc_state, self.npc_present_mask, self.npc_types
+
+    def advance_npcs(self, simulator: 'Simulator') -> None:
+        for c in self.controllers:
+            c.advance_npcs(simulator)
+        self.gather_npc_states()
+
+    def to(self, device):
+        super().to(device)
+        self.controller_indices = self.controller_indices.to(device)
+        for c in self.controllers:
+            c.to(device)
+        return self
+
+    def copy(self):
+        return self.__class__([c.copy() for c in self.controllers], self.controller_indices.clone())
+
+    def extend(self, n, in_place=True):
+        me = self if in_place else self.copy()
+        NPCController.extend(me, n, in_place=True)
+        me.controller_indices = _enlarge(me.controller_indices, n)
+        for c in me.controllers:
+            c.extend(n, in_place=True)
+        return me
+
+    def select_batch_elements(self, idx, in_place=True):
+        me = self if in_place else self.copy()
+        NPCController.select_batch_elements(me, idx, in_place=True)
+        me.controller_indices = me.controller_indices[idx]
+        for c in me.controllers:
+            c.select_batch_elements(idx, in_place=True)
+        return me
+
+
 class Simulator:
     """Batched 2-D driving simulator; see the module docstring.  Arguments follow simulator.py:283-309."""
 
