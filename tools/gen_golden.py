@@ -694,6 +694,48 @@ def gen_waypoints(out, cv2, town):
     print('g11 goal states', d[f'state_{T - 1}'].reshape(-1).tolist())
 
 
+# --------------------------------------------------------------------------------------
+# G12: traffic-light programmes (traffic_lights.py): the data files of the reference's own tests and of Town01, and a replay of the
+#      reference's TrafficLightController on Town01's programmes
+# --------------------------------------------------------------------------------------
+def gen_traffic_lights(out):
+    import random
+    import shutil
+    from torchdrivesim.traffic_lights import TrafficLightController, current_light_state_tensor_from_controller
+    dst = os.path.join(out, 'traffic_lights')
+    os.makedirs(os.path.join(dst, 'machines'), exist_ok=True)
+    tsrc = os.path.join(REF, 'tests', 'resources')
+    for name in sorted(os.listdir(os.path.join(tsrc, 'traffic_lights'))):                      # data files, not source
+        if name.endswith('.json'):
+            shutil.copyfile(os.path.join(tsrc, 'traffic_lights', name), os.path.join(dst, 'machines', name))
+    shutil.copyfile(os.path.join(tsrc, 'traffic_lights_controller', 'intersection_controller.json'), os.path.join(dst, 'intersection_controller.json'))
+    town = os.path.join(REF, 'torchdrivesim', 'resources', 'maps', 'carla_Town01')
+    ctl_path = os.path.join(out, 'maps', 'carla_Town01', 'carla_Town01_traffic_light_controller.json')
+    shutil.copyfile(os.path.join(town, 'carla_Town01_traffic_light_controller.json'), ctl_path)
+    stop = json.load(open(os.path.join(town, 'carla_Town01_stoplines.json')))
+    ids = [s['actor_id'] for s in stop if s['agent_type'] == 'traffic_light']
+    random.seed(12)
+    ctl = TrafficLightController.from_json(ctl_path)
+    n = ctl.get_number_of_light_groups()
+    rng = random.Random(1212)
+    script, trace = [], []
+
+    def snap():
+        trace.append(dict(state_per_machine=list(ctl.state_per_machine), time_remaining=[float(t) for t in ctl.time_remaining],
+                          names=ctl.current_state_with_name, tensor=current_light_state_tensor_from_controller(ctl, ids).tolist()))
+    snap()                                                        # after the seeded reset
+    ops = [('set_to', [[rng.randint(-1, 7), rng.choice([0.0, 0.5, 2.0, 3.0, 100.0])] for _ in range(n)])]
+    ops += [('tick', dt) for dt in (0.1, 0.1, 0.1, 1.0, 0.0, 2.0, 0.5, 3.7, 25.0, 0.1, 61.3, 1e-3, 10.0)]
+    ops += [('set_to', [[rng.randint(0, 5), float(rng.randint(0, 12))] for _ in range(n // 2)])]
+    ops += [('tick', float(rng.choice([0.1, 0.1, 0.1, 1.0, 2.0, 5.0, 7.5, 30.0]))) for _ in range(60)]
+    for op, arg in ops:
+        getattr(ctl, op)(arg)
+        script.append([op, arg])
+        snap()
+    with open(os.path.join(out, 'g12_traffic_lights.json'), 'w') as f:
+        json.dump(dict(seed=12, ids=ids, script=script, trace=trace, to_json=json.loads(ctl.to_json())), f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -705,6 +747,9 @@ def main():
     torch.set_num_threads(1)
     import torchdrivesim  # noqa: F401  (the reference)
     assert os.path.realpath(torchdrivesim.__path__[0]).startswith(os.path.realpath(REF))
+    if args.only == 'traffic_lights':
+        gen_traffic_lights(args.out)
+        return
     if args.only == 'waypoints':
         gen_waypoints(args.out, cv2, load_town01())
         return
@@ -718,6 +763,7 @@ def main():
     gen_traffic(args.out)
     gen_observation(args.out)
     gen_waypoints(args.out, cv2, town)
+    gen_traffic_lights(args.out)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

@@ -1,7 +1,8 @@
 """
 Map packages on disk (torchdrivesim/map.py): `<name>/metadata.json` naming `<name>_mesh.json` (the BirdviewMesh, mesh.py:700-719),
-`<name>_stoplines.json` (traffic-control stop lines) and the files this framework does not read (`.osm` Lanelet2 map, traffic-light
-controller).  Lets a Simulator be built from the reference's map folders without the reference or lanelet2.
+`<name>_stoplines.json` (traffic-control stop lines), `<name>.osm` (the Lanelet2 lane map, read by lanelet2.py) and
+`<name>_traffic_light_controller.json` (light programmes, traffic_lights.py).  Lets a Simulator be built from the reference's map
+folders without the reference or lanelet2.
 """
 import dataclasses
 import json
@@ -68,6 +69,14 @@ class MapConfig:
             lane_mesh = lanelet_map_to_lane_mesh(lanelet_map, left_handed=False)
             return lane_mesh.merge(road_mesh)
         return BirdviewMesh.load(self.mesh_path)
+
+    @property
+    def traffic_light_controller(self):
+        """the light programmes of the map, `None` without the file (map.py:85-89)"""
+        if self.traffic_light_controller_path is None:
+            return None
+        from .traffic_lights import TrafficLightController
+        return TrafficLightController.from_json(self.traffic_light_controller_path)
 
     @property
     def stoplines(self) -> List[Stopline]:
