@@ -179,3 +179,38 @@ def test_compound_npc_controller_merges_by_owner():
     assert torch.equal(big.get_npc_state()[::2], moved) and comp.get_npc_state().shape == (B, n, 4)
     sel = comp.select_batch_elements(torch.tensor([1]), in_place=False)
     assert torch.equal(sel.get_npc_state(), moved[1:]) and torch.equal(sel.controller_indices, owner[1:])
+
+
+def test_replay_controller_follows_the_log_and_wraps(tmp_path):
+    """behavior/replay.py: state(t) = log[..., t mod T, :]; batch plumbing carries the whole log"""
+    from torchdrivesim_amd.behavior import ReplayController, interaction_replay, InitializationFailedError
+    B, n, T = 2, 3, 4
+    log = torch.arange(B * n * T * 4, dtype=torch.float32).reshape(B, n, T, 4)
+    pres = torch.rand(B, n, T, generator=torch.Generator().manual_seed(1)) < 0.7
+    import types
+    rc = ReplayController(torch.ones(B, n, 2), log, pres)
+    sim_of = lambda c: types.SimpleNamespace(npc_controller=c)                # all the spawn controller touches
+    for t in range(1, 2 * T + 1):
+        rc.advance_npcs(sim_of(rc))
+        assert rc.time == t % T and torch.equal(rc.get_npc_state(), log[:, :, t % T]) and torch.equal(rc.get_npc_present_mask(), pres[:, :, t % T])
+    big = rc.extend(3, in_place=False)
+    assert big.npc_states.shape == (6, n, T, 4) and torch.equal(big.get_npc_state()[::3], rc.get_npc_state())
+    big.advance_npcs(sim_of(big))
+    assert torch.equal(big.get_npc_state()[::3], log[:, :, 1]) and rc.time == 0 and big.time == 1
+    sel = rc.select_batch_elements([1], in_place=False)
+    assert sel.npc_states.shape == (1, n, T, 4) and torch.equal(sel.get_npc_state(), log[1:, :, 0])
+    assert torch.equal(ReplayController(torch.ones(B, n, 2), log).get_npc_present_mask(), torch.ones(B, n, dtype=torch.bool))
+    # INTERACTION-format recording: two tracks, the second one appears late
+    d = tmp_path / 'recorded_trackfiles' / 'loc'
+    d.mkdir(parents=True)
+    rows = ['track_id,frame_id,timestamp_ms,agent_type,x,y,vx,vy,psi_rad,length,width']
+    rows += [f'1,{f},{100 * f},car,{10 + f},5,3,4,0.1,4.5,1.8' for f in range(1, 6)]
+    rows += [f'2,{f},{100 * f},car,{20 + f},7,0,2,-0.2,4.0,2.0' for f in range(3, 6)]
+    (d / 'vehicle_tracks_000.csv').write_text('\n'.join(rows))
+    attrs, states, present = interaction_replay('loc', str(tmp_path), initial_frame=2, segment_length=4)
+    assert attrs.shape == (1, 2, 3) and states.shape == (1, 2, 4, 4) and present.shape == (1, 2, 4)
+    assert attrs[0].tolist() == [[4.5, 1.8, 1.4], [4.0, 2.0, 1.4]]
+    assert present[0].tolist() == [[True] * 4, [False, True, True, True]]
+    assert states[0, 0, 0].tolist() == [12.0, 5.0, 0.1, 5.0] and states[0, 1, 0].tolist() == [0.0] * 4 and states[0, 1, 1].tolist() == [23.0, 7.0, -0.2, 2.0]
+    with pytest.raises(InitializationFailedError):
+        interaction_replay('loc', str(tmp_path), initial_frame=4, segment_length=10)
