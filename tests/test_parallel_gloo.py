@@ -28,12 +28,15 @@ def _worker(rank, world, port, B, out_dir):
     km = KinematicBicycle()
     km.set_params(lr=torch.ones(B, A))
     km.set_state(torch.arange(B * A * 4, dtype=torch.float32).reshape(B, A, 4))
+    from torchdrivesim_amd.lanelet2 import LaneletMap
+    lane_maps = [LaneletMap([], np.zeros((0, 3)), []) if b % 2 == 0 else None for b in range(B)]     # per-scene lane maps, some absent
     sim = Simulator(BirdviewMesh.empty(batch_size=B), km, torch.ones(B, A, 2), torch.ones(B, A, dtype=torch.bool),
-                    TorchDriveConfig(renderer=HipRendererConfig()))
+                    TorchDriveConfig(renderer=HipRendererConfig()), lanelet_map=lane_maps)
     mine = parallel.shard_simulator(sim, rank, world)
     start, stop = parallel.scene_shard(B, rank, world)
     assert mine.batch_size == stop - start
     assert torch.equal(mine.get_state(), sim.get_state()[start:stop])          # shards are plain batch slices
+    assert len(mine.lanelet_map) == stop - start and all(a is b for a, b in zip(mine.lanelet_map, lane_maps[start:stop]))
     # no data-path collective: the only exchanges are the timing reductions
     parallel.barrier()
     elapsed = 1.0 + rank                                                        # pretend rank 1 is the slow one
