@@ -829,7 +829,11 @@ class Simulator:
             state, size, present = self.get_state().detach(), self.get_agent_size(), self.get_present_mask()
             boxes = torch.cat([state[..., :2], size, state[..., 2:3]], dim=-1)
             if A > 64:
-                raise NotImplementedError('nograd metric: overlap bit masks support up to 64 agents')
+                # the bit masks hold 64 partners: larger scenes evaluate the A x A pairs with the element-wise kernel instead
+                b = torch.nan_to_num(boxes, nan=0.0)
+                o = _ops.pairwise_overlap(b.unsqueeze(2).expand(-1, -1, A, -1).contiguous(), b.unsqueeze(1).expand(-1, A, -1, -1).contiguous(), 'iou')
+                hit = (torch.nan_to_num(o, nan=0.0) > 0) & present.unsqueeze(1) & ~torch.eye(A, dtype=torch.bool, device=o.device)
+                return (hit.sum(-1) * present).to(torch.float64)
             _, bits, _ = _ops.collision_forward(boxes, _ops.metric_sc(torch.nan_to_num(boxes, nan=0.0), 'iou'), present, A, 'iou', want_overlap=True)
             shifts = torch.arange(A, device=bits.device)
             counts = ((bits.unsqueeze(-1) >> shifts) & 1).sum(-1)
