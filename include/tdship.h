@@ -94,6 +94,11 @@ int tds_collision_bwd_f32(const float *boxes, const float *sc, const uint8_t *pr
 int tds_pairwise_overlap_f32(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out,
                              int64_t n, int metric, void *stream);
 
+/* collision_detection_with_discs(box1, box2, num_discs) for a number of discs other than the default 5 (infractions.py:378-426,
+ * 503-545): odd, 3 .. 25 (torch.cdist changes its formulation above 25 points) */
+int tds_pairwise_discs_f32(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out, int64_t n,
+                           int num_discs, void *stream);
+
 /* box2corners_th (_iou_utils.py:270-299): box n x 5, sc n x 2 -> corners n x 4 x 2 */
 int tds_box2corners_f32(const float *box, const float *sc, float *corners, int64_t n, void *stream);
 

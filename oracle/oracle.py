@@ -113,9 +113,12 @@ def iou_pairs(box1, box2, sc1=None, sc2=None, debug=False):
     return (out, idx, nv, area) if debug else out
 
 
-def discs_pairs(box1, box2, sc1=None, sc2=None):
+def discs_pairs(box1, box2, sc1=None, sc2=None, num_discs=5):
     box1, box2, sc1, sc2 = _f(box1), _f(box2), _f(sc1), _f(sc2)
     out = np.empty(box1.shape[:-1], dtype=np.float32)
+    if num_discs != 5:
+        lib().orc_discs_pairs_n(_p(box1, c_f), _p(sc1, c_f), _p(box2, c_f), _p(sc2, c_f), _p(out, c_f), _i64(box1.size // 5), ctypes.c_int(num_discs))
+        return out
     lib().orc_discs_pairs(_p(box1, c_f), _p(sc1, c_f), _p(box2, c_f), _p(sc2, c_f), _p(out, c_f), _i64(box1.size // 5))
     return out
 

@@ -318,6 +318,33 @@ ORC_API void orc_discs_pairs(const float *box1, const float *sc1, const float *b
     }
 }
 
+/* the same for num_discs = 2 * nps + 1 discs per box (bbox2discs :390-400: centres i * (max/2 - r) / nps), num_discs <= 25 */
+ORC_API void orc_discs_pairs_n(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out, int64_t n, int num_discs) {
+    const int nps = (num_discs - 1) / 2;
+    for (int64_t k = 0; k < n; ++k) {
+        const float *a = box1 + 5 * k, *b = box2 + 5 * k;
+        float ya = a[4] + (PI_F / 2.0f) * (a[3] > a[2] ? 1.0f : 0.0f), yb = b[4] + (PI_F / 2.0f) * (b[3] > b[2] ? 1.0f : 0.0f);
+        float s1 = sc1 ? sc1[2 * k] : sinf(ya), c1 = sc1 ? sc1[2 * k + 1] : cosf(ya);
+        float s2 = sc2 ? sc2[2 * k] : sinf(yb), c2 = sc2 ? sc2[2 * k + 1] : cosf(yb);
+        float r1 = fminf(a[2], a[3]) / 2.0f, r2 = fminf(b[2], b[3]) / 2.0f;
+        float h1 = fmaxf(a[2], a[3]) / 2.0f - r1, h2 = fmaxf(b[2], b[3]) / 2.0f - r2;
+        float d = INFINITY;
+        for (int i = -nps; i <= nps; ++i) {
+            float da = ((float)i * h1) / (float)nps;
+            float ax = (da * c1 - 0.0f * s1) + a[0], ay = (da * s1 + 0.0f * c1) + a[1];
+            for (int j = -nps; j <= nps; ++j) {
+                float db = ((float)j * h2) / (float)nps;
+                float bx = (db * c2 - 0.0f * s2) + b[0], by = (db * s2 + 0.0f * c2) + b[1];
+                float dx = ax - bx, dy = ay - by;
+                float dd = sqrtf(fmaf(dy, dy, dx * dx));
+                if (dd < d || isnan(dd)) d = dd;
+            }
+        }
+        float l = 1.0f - d / (r1 + r2);
+        out[k] = l > 0.0f ? l : (isnan(l) ? l : 0.0f);
+    }
+}
+
 static float nan_to_num(float x) {
     if (isnan(x)) return 0.0f;
     if (isinf(x)) return x > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;

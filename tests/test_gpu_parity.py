@@ -158,6 +158,25 @@ def test_k2_pairwise_bit_exact(ops, oracle, metric, tag):
         assert ((out > 0) == (gold > 0)).mean() > 0.999
 
 
+@pytest.mark.parametrize('num_discs', [3, 5, 7, 9, 25])
+def test_k2_discs_with_other_disc_counts(ops, oracle, num_discs):
+    from torchdrivesim_amd.infractions import collision_detection_with_discs
+    g = load_golden('g13_discs_n.npz')
+    b1, b2 = dev(g['box1']), dev(g['box2'])
+    out = collision_detection_with_discs(b1, b2, num_discs=num_discs).cpu().numpy()
+    s1, s2 = ops.metric_sc(b1, 'discs'), ops.metric_sc(b2, 'discs')
+    ref = oracle.discs_pairs(g['box1'], g['box2'], sc_np(s1), sc_np(s2), num_discs=num_discs)
+    np.testing.assert_array_equal(out, ref)                      # same [sin, cos] in, same bits out
+    if num_discs != 5:
+        gold = g[f'discs_{num_discs}']                           # the reference's numbers (its sin / cos come from torch-CPU)
+        np.testing.assert_allclose(out, gold, atol=2e-6, rtol=0)
+        assert ((out > 0) == (gold > 0)).mean() > 0.995
+    with pytest.raises(AssertionError):
+        collision_detection_with_discs(b1, b2, num_discs=4)
+    with pytest.raises(RuntimeError):
+        collision_detection_with_discs(b1, b2, num_discs=27)
+
+
 def test_k2_box2corners_bit_exact(ops, oracle):
     g = load_golden('g2_boxes.npz')
     b = dev(g['rnd400_box1'])

@@ -76,6 +76,15 @@ def test_iou_and_discs_bit_exact(oracle, tag):
     assert ((d == ref) | (np.isnan(d) & np.isnan(ref))).all()
 
 
+@pytest.mark.parametrize('num_discs', [3, 7, 9, 25])
+def test_discs_with_other_disc_counts_bit_exact(oracle, num_discs):
+    g = load_golden('g13_discs_n.npz')                            # collision_detection_with_discs(..., num_discs=k) of the reference
+    b1, b2 = g['box1'], g['box2']
+    d = oracle.discs_pairs(b1, b2, tsc_discs(b1), tsc_discs(b2), num_discs=num_discs)
+    np.testing.assert_array_equal(d, g[f'discs_{num_discs}'])
+    assert (d > 0).sum() > 100
+
+
 def test_iou_known_answers(oracle):
     # SURVEY R3 known answers (base box (0,0,4,2,0))
     base = [0, 0, 4, 2, 0]

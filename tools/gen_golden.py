@@ -736,6 +736,26 @@ def gen_traffic_lights(out):
         json.dump(dict(seed=12, ids=ids, script=script, trace=trace, to_json=json.loads(ctl.to_json())), f)
 
 
+# --------------------------------------------------------------------------------------
+# G13: collision_detection_with_discs with num_discs other than 5
+# --------------------------------------------------------------------------------------
+def gen_discs_n(out):
+    from torchdrivesim.infractions import collision_detection_with_discs
+    g = seeded(1313)
+    n = 600
+    xy1 = torch.rand(n, 2, generator=g) * 8 - 4
+    xy2 = xy1 + torch.randn(n, 2, generator=g) * 2.5
+    lw = lambda: torch.stack([torch.rand(n, generator=g) * 4 + 1.5, torch.rand(n, generator=g) * 2 + 0.8], -1)
+    psi = lambda: (torch.rand(n, 1, generator=g) * 2 - 1) * math.pi
+    b1, b2 = torch.cat([xy1, lw(), psi()], -1), torch.cat([xy2, lw(), psi()], -1)
+    b1[:40, 2:4] = b1[:40, 2:4].flip(-1)                          # wid > len: the yaw + pi/2 branch
+    d = dict(box1=npy(b1), box2=npy(b2))
+    for k in (3, 7, 9, 25):
+        d[f'discs_{k}'] = npy(collision_detection_with_discs(b1[None], b2[None], num_discs=k))[0]
+    np.savez_compressed(os.path.join(out, 'g13_discs_n.npz'), **d)
+    print('g13: nonzero fractions', {k: float((d[f'discs_{k}'] > 0).mean()) for k in (3, 7, 9, 25)})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -747,6 +767,9 @@ def main():
     torch.set_num_threads(1)
     import torchdrivesim  # noqa: F401  (the reference)
     assert os.path.realpath(torchdrivesim.__path__[0]).startswith(os.path.realpath(REF))
+    if args.only == 'discs_n':
+        gen_discs_n(args.out)
+        return
     if args.only == 'traffic_lights':
         gen_traffic_lights(args.out)
         return
@@ -764,6 +787,7 @@ def main():
     gen_observation(args.out)
     gen_waypoints(args.out, cv2, town)
     gen_traffic_lights(args.out)
+    gen_discs_n(args.out)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

@@ -34,6 +34,7 @@ _SIGNATURES = {
     'tds_collision_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     'tds_collision_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     'tds_pairwise_overlap_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    'tds_pairwise_discs_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     'tds_box2corners_f32': [_vp, _vp, _vp, _i64, _vp],
     'tds_occlusion_mask_f32': [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     'tds_map_create': [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _f32, ctypes.POINTER(_vp)],

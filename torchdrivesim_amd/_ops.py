@@ -179,7 +179,7 @@ def collision(boxes, present, n_exposed=None, metric='iou', sc=None):
     return _Collision.apply(boxes, sc, present, n_exposed, metric)
 
 
-def pairwise_overlap(box1, box2, metric='iou', sc1=None, sc2=None):
+def pairwise_overlap(box1, box2, metric='iou', sc1=None, sc2=None, num_discs=5):
     """iou_differentiable / collision_detection_with_discs (infractions.py:307,503), element-wise; boxes (...,5).
     Forward only (the fused scene entry point carries the gradient)."""
     shape = box1.shape[:-1]
@@ -189,6 +189,10 @@ def pairwise_overlap(box1, box2, metric='iou', sc1=None, sc2=None):
         sc2 = metric_sc(box2, metric)
     b1, b2, s1, s2 = _c(box1).reshape(-1, 5), _c(box2).reshape(-1, 5), _c(sc1).reshape(-1, 2), _c(sc2).reshape(-1, 2)
     out = torch.empty(b1.shape[0], dtype=f32, device=b1.device)
+    if metric == 'discs' and num_discs != 5:
+        nat.call('tds_pairwise_discs_f32', b1.device, nat.dev_ptr(b1, f32, 'box1'), nat.dev_ptr(s1, f32, 'sc1'), nat.dev_ptr(b2, f32, 'box2'),
+                 nat.dev_ptr(s2, f32, 'sc2'), nat.dev_ptr(out, f32, 'out'), b1.shape[0], int(num_discs), nat.stream_ptr(b1.device))
+        return out.reshape(shape)
     nat.call('tds_pairwise_overlap_f32', b1.device, nat.dev_ptr(b1, f32, 'box1'), nat.dev_ptr(s1, f32, 'sc1'), nat.dev_ptr(b2, f32, 'box2'),
              nat.dev_ptr(s2, f32, 'sc2'), nat.dev_ptr(out, f32, 'out'), b1.shape[0], _METRICS[metric], nat.stream_ptr(b1.device))
     return out.reshape(shape)

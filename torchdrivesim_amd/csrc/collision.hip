@@ -239,6 +239,30 @@ __device__ float discs_pair(const Box &b1, const Box &b2) {
     return (l != l) ? l : fmaxf(l, 0.0f);
 }
 
+// the same with 2 * nps + 1 discs per box (`num_discs`, infractions.py:390-400): centres at i * (max/2 - r) / nps
+__device__ float discs_pair_n(const Box &b1, const Box &b2, int nps) {
+    float ra = fminf(b1.l, b1.w) / 2.0f, rb = fminf(b2.l, b2.w) / 2.0f;
+    float ha = fmaxf(b1.l, b1.w) / 2.0f - ra, hb = fmaxf(b2.l, b2.w) / 2.0f - rb;
+    float d = __builtin_inff();
+    bool any_nan = false;
+    const float fn = (float)nps;
+    for (int i = -nps; i <= nps; ++i) {
+        float da = ((float)i * ha) / fn;
+        float ax = (da * b1.c - 0.0f * b1.s) + b1.x, ay = (da * b1.s + 0.0f * b1.c) + b1.y;
+        for (int j = -nps; j <= nps; ++j) {
+            float db = ((float)j * hb) / fn;
+            float bx = (db * b2.c - 0.0f * b2.s) + b2.x, by = (db * b2.s + 0.0f * b2.c) + b2.y;
+            float ex = ax - bx, ey = ay - by;
+            float dd = sqrtf(__fmaf_rn(ey, ey, ex * ex));
+            any_nan |= (dd != dd);
+            d = fminf(d, dd);
+        }
+    }
+    if (any_nan) d = __builtin_nanf("");
+    float l = 1.0f - d / (ra + rb);
+    return (l != l) ? l : fmaxf(l, 0.0f);
+}
+
 __device__ __forceinline__ Box load_box(const float *boxes, const float *sc, int64_t idx) {
     Box b;
     const float *p = boxes + idx * 5;
@@ -388,6 +412,17 @@ __global__ void __launch_bounds__(CBLOCK) pairwise_kernel(const float *__restric
     out[i] = o;
 }
 
+__global__ void __launch_bounds__(CBLOCK) pairwise_discs_n_kernel(const float *__restrict__ box1, const float *__restrict__ sc1,
+                                                                  const float *__restrict__ box2, const float *__restrict__ sc2,
+                                                                  float *__restrict__ out, int64_t n, int nps) {
+    int64_t i = (int64_t)blockIdx.x * CBLOCK + threadIdx.x;
+    if (i >= n) return;
+    Box a, b;
+    a.x = box1[5 * i]; a.y = box1[5 * i + 1]; a.l = box1[5 * i + 2]; a.w = box1[5 * i + 3]; a.s = sc1[2 * i]; a.c = sc1[2 * i + 1];
+    b.x = box2[5 * i]; b.y = box2[5 * i + 1]; b.l = box2[5 * i + 2]; b.w = box2[5 * i + 3]; b.s = sc2[2 * i]; b.c = sc2[2 * i + 1];
+    out[i] = discs_pair_n(a, b, nps);
+}
+
 __global__ void __launch_bounds__(CBLOCK) box2corners_kernel(const float *__restrict__ box, const float *__restrict__ sc,
                                                              float *__restrict__ corners, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * CBLOCK + threadIdx.x;
@@ -443,6 +478,19 @@ TDS_EXPORT int tds_pairwise_overlap_f32(const float *box1, const float *sc1, con
     else
         hipLaunchKernelGGL(pairwise_kernel<TDS_METRIC_DISCS>, grid, dim3(CBLOCK), 0, (hipStream_t)stream, box1, sc1, box2, sc2, out, n);
     TDS_LAUNCH_CHECK("pairwise_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_pairwise_discs_f32(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out, int64_t n,
+                                      int num_discs, void *stream) {
+    TDS_CHECK_ARG(n >= 0, "tds_pairwise_discs_f32: negative n");
+    // torch.cdist switches to a matrix-multiply formulation above 25 points per set: the direct form restated here stops there
+    TDS_CHECK_ARG(num_discs > 1 && (num_discs & 1) && num_discs <= 25, "tds_pairwise_discs_f32: num_discs must be odd, 3 .. 25 (got %d)", num_discs);
+    if (n == 0) return TDS_OK;
+    TDS_CHECK_ARG(box1 && sc1 && box2 && sc2 && out, "tds_pairwise_discs_f32: null pointer");
+    hipLaunchKernelGGL(pairwise_discs_n_kernel, dim3((unsigned)((n + CBLOCK - 1) / CBLOCK)), dim3(CBLOCK), 0, (hipStream_t)stream, box1, sc1,
+                       box2, sc2, out, n, (num_discs - 1) / 2);
+    TDS_LAUNCH_CHECK("pairwise_discs_n_kernel");
     return TDS_OK;
 }
 

@@ -22,12 +22,12 @@ def iou_differentiable(box1: Tensor, box2: Tensor, fast: bool = True) -> Tensor:
 
 
 def collision_detection_with_discs(box1: Tensor, box2: Tensor, num_discs: int = 5, backend: str = 'torch') -> Tensor:
-    """TrafficSim-style overlap of 5 discs per box, relu(1 - d / (r1 + r2)) (infractions.py:503-545)."""
-    if num_discs != 5:
-        raise NotImplementedError('the HIP kernel implements the default num_discs=5')
+    """TrafficSim-style overlap of `num_discs` discs per box, relu(1 - d / (r1 + r2)) (infractions.py:503-545); `num_discs` odd,
+    3 .. 25 (torch.cdist, which the reference calls, changes its formulation above 25 points per set)."""
+    assert isinstance(num_discs, int) and num_discs > 1 and num_discs % 2 != 0          # bbox2discs, infractions.py:391
     if backend != 'torch':
         raise ValueError('Unknown backend framework.')
-    return _ops.pairwise_overlap(box1, box2, 'discs')
+    return _ops.pairwise_overlap(box1, box2, 'discs', num_discs=num_discs)
 
 
 def box2corners_th(box: Tensor) -> Tensor:
