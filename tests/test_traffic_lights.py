@@ -101,3 +101,27 @@ def test_tick_spanning_several_phases_and_map_config():
     assert t.shape == (len(ids),) and t.dtype == torch.int64
     names = TrafficLightControl._default_allowed_states()
     assert [names[i] for i in t.tolist()] == [ctl.current_state_with_name[str(i)] for i in ids]
+
+
+def test_state_machine_known_answers_of_the_reference_tests():
+    """tests/test_traffic_light_state_machine.py of the reference, on its intersection_1.json"""
+    fsm = TrafficLightStateMachine.from_json(os.path.join(GOLD, 'traffic_lights', 'machines', 'intersection_1.json'))
+    ids = ('4411', '3411', '4399', '3399')
+    phase = lambda colours, seq, dur, nxt: TrafficLightGroupState(dict(zip(ids, colours)), seq, dur, nxt)
+    fsm.reset()
+    assert fsm.time_remaining >= 1
+    for left in (3, 1):
+        fsm.set_to(2, time_remaining=left)
+        assert fsm.time_remaining == left and fsm.current_state == phase((G, R, Y, Y), 2, 5, 3)
+    fsm.set_to(0, 1)
+    fsm.tick(0.9)
+    assert fsm.time_remaining <= 0.1 and fsm.current_state == phase((R, R, R, R), 0, 10, 1)
+    fsm.tick(0.1)
+    assert fsm.time_remaining == 10 and fsm.current_state == phase((G, R, G, G), 1, 10, 2)
+    for dt, want, left in ((23, phase((G, R, Y, Y), 2, 5, 3), 2), (25, phase((G, G, R, R), 3, 10, 4), 10), (45, phase((R, R, R, R), 0, 10, 1), 5)):
+        fsm.set_to(0, 10)
+        fsm.tick(dt)
+        assert fsm.current_state == want and fsm.time_remaining == left
+    fsm.set_to(4, 3)
+    assert fsm.get_current_actor_states() == dict(zip(ids, (Y, Y, R, R)))
+    assert json.loads(fsm.to_json())[2]['next_state'] == '3'
