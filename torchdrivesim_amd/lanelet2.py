@@ -230,13 +230,16 @@ def _align_borders(left: np.ndarray, lids: np.ndarray, right: np.ndarray, rids: 
     return left, lids, right, rids
 
 
-def load_lanelet_map(map_path: str, origin: Tuple[float, float] = (0, 0)) -> LaneletMap:
+def load_lanelet_map(map_path: str, origin: Tuple[float, float] = (0, 0), align_borders: bool = True) -> LaneletMap:
     """
     Load a Lanelet2 map from an OSM file on disk (reference lanelet2.py:86-105; `.osm` or `.osm.gz`).
 
     Args:
         map_path: local path to the OSM file
         origin: latitude and longitude of the origin to use with the UTM projector
+        align_borders: orient the bounds like Lanelet2's loader (`geometry::align`: the right bound ends up on the right of the left
+            one, which fixes the lanelet's direction).  False keeps the order of the file.  See DESIGN.md, "Wrong-way": the shipped
+            CARLA maps store every lanelet against that rule, so the two settings give OPPOSITE lane directions on them.
     Raises:
         FileNotFoundError: if the file does not exist
     """
@@ -278,7 +281,8 @@ def load_lanelet_map(map_path: str, origin: Tuple[float, float] = (0, 0)) -> Lan
         lids, rids = sides['left'], sides['right']
         left = points[[index[i] for i in lids]]
         right = points[[index[i] for i in rids]]
-        left, lids, right, rids = _align_borders(left, lids, right, rids)
+        if align_borders:
+            left, lids, right, rids = _align_borders(left, lids, right, rids)
         attrs = {k: v for k, v in tags.items() if k != 'type'}
         attrs['type'] = 'lanelet'
         lanelets.append(Lanelet(int(rel.get('id')), left, right, lids, rids, attrs))

@@ -133,3 +133,29 @@ def traffic_controls_from_map_config(cfg: MapConfig) -> Dict[str, BaseTrafficCon
         if s.agent_type in poses:
             poses[s.agent_type].append([s.x, s.y, s.length, s.width, s.orientation])
     return {k: kinds[k](torch.tensor(v).unsqueeze(0)) for k, v in poses.items() if v}
+
+
+def find_wrong_way_stoplines(map_cfg: MapConfig, angle_threshold: float = 3.141592653589793 / 6, device=None) -> List[int]:
+    """Ids of the stop lines that face against every lanelet they lie on (map.py:231-245): a consistency check of a map package.
+    All stop lines are answered by ONE launch of the lane-direction query (the reference asks Lanelet2 stop line by stop line)."""
+    import numpy as np
+    from torchdrivesim_amd import _ops
+    from torchdrivesim_amd.lanelet2 import LaneletError
+    from torchdrivesim_amd.utils import normalize_angle
+    lanelet_map = map_cfg.lanelet_map
+    stoplines = map_cfg.stoplines
+    if lanelet_map is None or not stoplines:
+        return []
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    pts = torch.tensor([[s.x, s.y] for s in stoplines], dtype=torch.float64, device=dev)
+    dirs, _, count, status = _ops.lanelet_directions([lanelet_map.table(dev, [], 0.0)], None, pts, 0.0)
+    dirs, count, status = dirs.cpu().numpy(), count.cpu().numpy(), status.cpu().numpy()
+    wrong = []
+    for s, d, k, st in zip(stoplines, dirs, count, status):
+        if st & 1:
+            raise LaneletError('Failed to find direction of the linestring at a given point')
+        if k > d.shape[0]:
+            raise LaneletError(f'{k} lanelets at a stop line, more than the {d.shape[0]} the query returns')
+        if k and not any(abs(normalize_angle(float(psi) - s.orientation)) < angle_threshold for psi in d[:k]):
+            wrong.append(s.actor_id)
+    return wrong
