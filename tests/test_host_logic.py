@@ -62,7 +62,21 @@ def test_out_of_scope_arguments_are_refused():
     from torchdrivesim_amd.simulator import Simulator
     sim = make_sim()
     with pytest.raises(NotImplementedError):
-        Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lane_features=object())
+        sim.render_egocentric(noisy_perception=True)
+    # lane features are carried through the batch plumbing and the observation model (simulator.py:335,418,439,464,498,829)
+    from torchdrivesim_amd.lanelet2 import LaneFeatures
+    from torchdrivesim_amd.observation_noise import MapObservationNoiseFromLog
+    lf = LaneFeatures(dense_lane_features=torch.arange(2 * 5 * 4.0).reshape(2, 5, 4), dense_lane_features_mask=torch.ones(2, 5, dtype=torch.bool))
+    logged = LaneFeatures(dense_lane_features=torch.zeros(2, 5, 4))
+    s3 = Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lane_features=lf,
+                   observation_noise_model=MapObservationNoiseFromLog(noisy_lane_features=[logged]))
+    assert s3.get_noisy_lane_features() is logged                 # internal_time 0: from the log
+    s3.internal_time = 1
+    assert s3.get_noisy_lane_features() is s3.lane_features       # log exhausted: the simulator's own
+    big = s3.extend(2, in_place=False)
+    assert big.lane_features.dense_lane_features.shape == (4, 5, 4) and big.lane_features.sparse_lane_features is None
+    assert torch.equal(big.lane_features.dense_lane_features[::2], lf.dense_lane_features)
+    assert torch.equal(s3[[1]].lane_features.dense_lane_features, lf.dense_lane_features[1:])
     # lanelet maps are in scope (tests/test_lanelet2.py); scenes without one give zeros, as the reference
     s2 = Simulator(sim.road_mesh, sim.kinematic_model, sim.agent_size, sim.present_mask, sim.cfg, lanelet_map=[None, None])
     assert s2.compute_wrong_way().shape == (2, 3) and not s2.compute_wrong_way().any()

@@ -36,6 +36,32 @@ from .mesh import BaseMesh, BirdviewMesh, rendering_mesh
 is_available = True        # the reference exports this flag (lanelet2.py:21-27); this module needs no external package
 
 
+@dataclass
+class LaneFeatures:
+    """Lane markers handed to policies next to the image (lanelet2.py:30-69): dense `[B, M, D]` and sparse `[B, N, D]` feature rows with
+    their masks.  Pure batch-axis plumbing; the simulator only carries them."""
+    dense_lane_features: Optional[Tensor] = None
+    dense_lane_features_mask: Optional[Tensor] = None
+    sparse_lane_features: Optional[Tensor] = None
+    sparse_lane_features_mask: Optional[Tensor] = None
+
+    def _map(self, f) -> 'LaneFeatures':
+        return LaneFeatures(*[None if x is None else f(x) for x in (self.dense_lane_features, self.dense_lane_features_mask,
+                                                                    self.sparse_lane_features, self.sparse_lane_features_mask)])
+
+    def to(self, device) -> 'LaneFeatures':
+        return self._map(lambda x: x.to(device))
+
+    def copy(self) -> 'LaneFeatures':
+        return self._map(lambda x: x)
+
+    def extend(self, n: int) -> 'LaneFeatures':
+        return self._map(lambda x: x.unsqueeze(1).expand((x.shape[0], n) + x.shape[1:]).reshape((n * x.shape[0],) + x.shape[1:]))
+
+    def select_batch_elements(self, idx) -> 'LaneFeatures':
+        return self._map(lambda x: x[idx])
+
+
 class Lanelet2NotFound(ImportError):
     """Kept for interface compatibility (lanelet2.py:72-76); never raised here."""
 

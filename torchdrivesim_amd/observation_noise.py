@@ -51,6 +51,9 @@ class ObservationNoise:
     def get_noisy_background_mesh(self, simulator):
         return simulator.birdview_mesh_generator.background_mesh
 
+    def get_noisy_lane_features(self, simulator):
+        return simulator.lane_features
+
 
 class StandardSensingObservationNoise(ObservationNoise):
     """Gaussian position / heading / speed noise whose standard deviation steps up with the distance from the observer, and entities
@@ -78,3 +81,43 @@ class StandardSensingObservationNoise(ObservationNoise):
     def get_noisy_present_mask(self, simulator) -> Tensor:
         return _ops.occlusion_mask(simulator.get_all_agent_state(), simulator.get_all_agent_size(), simulator.get_all_agent_present_mask(),
                                    simulator.agent_count)
+
+
+class MapObservationNoiseFromLog(ObservationNoise):
+    """Map-side observations replayed from a log, one entry per simulation step, falling back to the simulator's own once the log is
+    exhausted (observation_noise.py:135-178).  Accessors only: rendering the logged backgrounds (`noisy_perception=True`) would swap the
+    static map every step and stays outside this framework."""
+
+    def __init__(self, cfg=None, noisy_lane_features=None, noisy_background_mesh=None, noisy_traffic_controls=None, noisy_crosswalk_features=None):
+        super().__init__(cfg)
+        self.noisy_lane_features = noisy_lane_features
+        self.noisy_background_mesh = noisy_background_mesh
+        self.noisy_traffic_controls = noisy_traffic_controls
+        self.noisy_crosswalk_features = noisy_crosswalk_features
+
+    @staticmethod
+    def _logged(log, simulator):
+        return log[simulator.internal_time] if log is not None and simulator.internal_time < len(log) else None
+
+    def get_noisy_lane_features(self, simulator):
+        hit = self._logged(self.noisy_lane_features, simulator)
+        return hit if hit is not None else simulator.lane_features
+
+    def get_noisy_background_mesh(self, simulator):
+        hit = self._logged(self.noisy_background_mesh, simulator)
+        if hit is None:
+            return simulator.birdview_mesh_generator.background_mesh
+        from torchdrivesim_amd.mesh import set_colors_with_defaults
+        gen = simulator.birdview_mesh_generator
+        return set_colors_with_defaults(hit.clone(), color_map=gen.color_map, rendering_levels=gen.rendering_levels)
+
+    def get_noisy_road_mesh(self, simulator):
+        hit = self._logged(self.noisy_background_mesh, simulator)
+        return hit if hit is not None else simulator.road_mesh
+
+    def get_noisy_traffic_controls(self, simulator):
+        hit = self._logged(self.noisy_traffic_controls, simulator)
+        return hit if hit is not None else simulator.traffic_controls
+
+    def get_noisy_crosswalk_features(self, simulator):
+        return self._logged(self.noisy_crosswalk_features, simulator)

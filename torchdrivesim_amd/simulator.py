@@ -11,8 +11,8 @@
 
     compute_wrong_way  -> lane tables of `lanelet_map` (lanelet2.py), one launch  reference: simulator.py:607-630 (Python triple loop)
 
-Also carried: traffic controls, waypoint goals (state + rendering) and observation noise.  Out of scope:
-lane features; passing them raises NotImplementedError instead of silently ignoring them.
+Also carried: traffic controls, waypoint goals (state + rendering), observation noise and lane features (plumbing only).  Out of scope
+(SURVEY.md section 8): `noisy_perception` rendering, which raises NotImplementedError instead of being silently ignored.
 """
 import logging
 from dataclasses import dataclass, field
@@ -217,8 +217,6 @@ class Simulator:
                  waypoint_goals=None, agent_types: Optional[Tensor] = None, agent_type_names: Optional[List[str]] = None,
                  npc_controller: Optional[NPCController] = None, agent_lr: Optional[Tensor] = None, lane_features=None,
                  observation_noise_model=None, action_model_extras: Optional[Dict[str, Any]] = None):
-        if lane_features is not None:
-            raise NotImplementedError('`lane_features` is outside the scope of torchdrivesim_amd (SURVEY.md section 8)')
         self._lane_set = None                            # device lane tables of `lanelet_map`, made on the first compute_wrong_way
         self.road_mesh = road_mesh
         self.lanelet_map = lanelet_map
@@ -229,7 +227,7 @@ class Simulator:
         self.action_model_extras = action_model_extras
         self.traffic_controls = traffic_controls        # Dict[str, BaseTrafficControl]: state and violations; not rendered by the fused path
         self.waypoint_goals = waypoint_goals             # WaypointGoal: ticked off in step(), drawn as discs by render_egocentric
-        self.lane_features = None
+        self.lane_features = lane_features               # lanelet2.LaneFeatures: carried for policies, not used by any kernel
         if observation_noise_model is None:
             from torchdrivesim_amd.observation_noise import ObservationNoise
             observation_noise_model = ObservationNoise()
@@ -314,6 +312,7 @@ class Simulator:
         if self.traffic_controls is not None:
             self.traffic_controls = {k: v.to(device) for k, v in self.traffic_controls.items()}
         self.waypoint_goals = self.waypoint_goals.to(device) if self.waypoint_goals is not None else None
+        self.lane_features = self.lane_features.to(device) if self.lane_features is not None else None
         self._scene_cache = None
         return self
 
@@ -326,7 +325,7 @@ class Simulator:
             agent_types=self.agent_type, agent_type_names=self.agent_types, agent_lr=self.agent_lr, npc_controller=self.npc_controller.copy(),
             traffic_controls={k: v.copy() for k, v in self.traffic_controls.items()} if self.traffic_controls is not None else None,
             waypoint_goals=self.waypoint_goals.copy() if self.waypoint_goals is not None else None,
-            observation_noise_model=self.observation_noise_model)
+            observation_noise_model=self.observation_noise_model, lane_features=self.lane_features.copy() if self.lane_features is not None else None)
         other._scene_cache = self._scene_cache          # static maps are immutable and can be shared
         return other
 
@@ -341,6 +340,7 @@ class Simulator:
         self.recenter_offset = _enlarge(self.recenter_offset, n) if self.recenter_offset is not None else None
         self.lanelet_map = [m for m in self.lanelet_map for _ in range(n)] if self.lanelet_map is not None else None
         self._lane_set = None
+        self.lane_features = self.lane_features.extend(n) if self.lane_features is not None else None
         self.kinematic_model.extend(n)
         self._batch_size *= n
         self.birdview_mesh_generator = self.birdview_mesh_generator.expand(n)
@@ -361,6 +361,7 @@ class Simulator:
         self.recenter_offset = self.recenter_offset[idx] if self.recenter_offset is not None else None
         self.lanelet_map = [self.lanelet_map[i] for i in idx] if self.lanelet_map is not None else None
         self._lane_set = None
+        self.lane_features = self.lane_features.select_batch_elements(idx) if self.lane_features is not None else None
         self.agent_size, self.agent_type = self.agent_size[idx], self.agent_type[idx]
         self.agent_lr, self.present_mask = self.agent_lr[idx], self.present_mask[idx]
         self.kinematic_model.select_batch_elements(idx)
@@ -530,6 +531,9 @@ class Simulator:
     def get_noisy_traffic_controls(self):
         return self.observation_noise_model.get_noisy_traffic_controls(self)
 
+    def get_noisy_lane_features(self):
+        return self.observation_noise_model.get_noisy_lane_features(self)
+
     def get_noisy_road_mesh(self):
         return self.observation_noise_model.get_noisy_road_mesh(self)
 
@@ -679,7 +683,7 @@ class Simulator:
                custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None) -> Tensor:
         """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992)."""
         if noisy_perception:
-            raise NotImplementedError('noisy perception needs lane features, which are outside the scope of torchdrivesim_amd')
+            raise NotImplementedError('noisy perception swaps the static background every step (logged maps); outside the scope of torchdrivesim_amd')
         camera_sc = _camera_sc if _camera_sc is not None else torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
         if camera_xy.dim() == 2:
             camera_xy, camera_sc = camera_xy.unsqueeze(1), camera_sc.unsqueeze(1)
