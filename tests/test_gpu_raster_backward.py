@@ -113,11 +113,12 @@ def render(ops, smap, oracle, state_t, size, mask, cam_xy_t, cam_sc_t, fov, res,
     return f(smap, state_t, sc, tmpl, actor_keys(smap, B, N), dev(mask), cam_xy_t, cam_sc_t, fov, res)
 
 
-def test_kernel_matches_numpy_definition(ops, oracle):
+@pytest.mark.parametrize('res', [96, 64, 90, 256, 320])      # float4 rows: several bands per wave / one group per lane / scalar path (90) / groups
+def test_kernel_matches_numpy_definition(ops, oracle, res):   # of a row in two waves (320)
     gen = np.random.default_rng(5)
     verts, faces, state, size, cam_xy, cam_psi, mask = scene(gen)
     smap = make_map(ops, verts, faces, MAP_VC, MAP_CATS)
-    fov, res = 35.0, 96
+    fov = 35.0
     st = dev(state).requires_grad_(True)
     cxy = dev(cam_xy).requires_grad_(True)
     cpsi = dev(cam_psi)
