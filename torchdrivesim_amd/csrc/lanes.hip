@@ -215,9 +215,12 @@ TDS_EXPORT int tds_lanes_create(const double *poly_xy, const int32_t *poly_start
         r.bx1 = nextafterf((float)x1, INFINITY), r.by1 = nextafterf((float)y1, INFINITY);
         if (r.poly_n > 0) gx0 = std::min(gx0, x0), gy0 = std::min(gy0, y0), gx1 = std::max(gx1, x1), gy1 = std::max(gy1, y1);
     }
+    int device = 0;
+    TDS_HIP(hipGetDevice(&device));
     tds_lanes *h = new (std::nothrow) tds_lanes();
     if (!h) return TDS_ENOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = device;
     LaneView &v = h->view;
     v.n = n_lanelets;
     v.max_tol = max_tolerance;
@@ -250,7 +253,6 @@ TDS_EXPORT int tds_lanes_create(const double *poly_xy, const int32_t *poly_start
     } else {
         v.ox = v.oy = 0, v.nx = v.ny = 0;
     }
-    TDS_HIP(hipGetDevice(&h->device));
     std::vector<double> poly(poly_xy, poly_xy + 2 * (size_t)n_poly), cl(cl_xyz, cl_xyz + 3 * (size_t)n_cl);
     int rc;
     if ((rc = upload(&h->d_poly, poly, &h->bytes)) || (rc = upload(&h->d_cl, cl, &h->bytes)) || (rc = upload(&h->d_rec, rec, &h->bytes)) ||
