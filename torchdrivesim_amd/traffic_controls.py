@@ -120,10 +120,16 @@ class TrafficLightControl(BaseTrafficControl):
             return torch.zeros(B, A, dtype=torch.bool, device=agent_state.device)
         rear = _rear_boxes(agent_state, self.violation_rear_factor)                       # B x A x 5
         # padding stop lines are parked at (-1000, -1000) like the reference's corners (traffic_controls.py:31-33)
-        m = self.mask.to(self.pos.dtype)[..., None]
-        lines = self.pos * m + (1 - m) * torch.tensor([-1000.0, -1000.0, 0.0, 0.0, 0.0], dtype=self.pos.dtype, device=self.pos.device)
+        key = (self.pos.data_ptr(), self.pos._version, tuple(self.pos.shape), self.mask.data_ptr(), self.mask._version, str(rear.device), A)
+        cached = getattr(self, '_lines_cache', None)
+        if cached is None or cached[0] != key:              # the stop lines do not move: their (B, A*N, 5) operand is built once
+            m = self.mask.to(self.pos.dtype)[..., None]
+            park = torch.tensor([-1000.0, -1000.0, 0.0, 0.0, 0.0], dtype=self.pos.dtype).to(self.pos.device)
+            lines = (self.pos * m + (1 - m) * park).to(rear.device)
+            cached = (key, lines[:, None, :, :].expand(B, A, N, 5).reshape(B, A * N, 5).contiguous())
+            self._lines_cache = cached
         b1 = rear[:, :, None, :].expand(B, A, N, 5).reshape(B, A * N, 5)
-        b2 = lines.to(rear.device)[:, None, :, :].expand(B, A, N, 5).reshape(B, A * N, 5)
+        b2 = cached[1]
         overlap = _ops.pairwise_overlap(b1.contiguous(), b2.contiguous(), metric='iou').reshape(B, A, N) > 0
         red = (self.state.to(overlap.device) == self.allowed_states.index('red'))[:, None, :]
         return (overlap & red).any(dim=-1)
