@@ -228,3 +228,12 @@ def test_replay_controller_follows_the_log_and_wraps(tmp_path):
     assert states[0, 0, 0].tolist() == [12.0, 5.0, 0.1, 5.0] and states[0, 1, 0].tolist() == [0.0] * 4 and states[0, 1, 1].tolist() == [23.0, 7.0, -0.2, 2.0]
     with pytest.raises(InitializationFailedError):
         interaction_replay('loc', str(tmp_path), initial_frame=4, segment_length=10)
+
+
+def test_a_configuration_for_the_opencv_backend_selects_the_rasteriser():
+    from torchdrivesim_amd.rendering import CV2RendererConfig, HipRenderer, RendererConfig, renderer_from_config
+    r = renderer_from_config(CV2RendererConfig(left_handed_coordinates=True))
+    assert isinstance(r, HipRenderer) and r.cfg.left_handed_coordinates and r.cfg.out_dtype == 'float32'
+    assert isinstance(renderer_from_config(RendererConfig()), HipRenderer)          # backend 'default'
+    with pytest.raises(NotImplementedError):
+        renderer_from_config(CV2RendererConfig(trim_mesh_before_rendering=False))

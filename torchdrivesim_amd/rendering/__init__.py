@@ -1,11 +1,12 @@
 """
 Renderers.  The reference ships OpenCV / pytorch3d / nvdiffrast backends behind `renderer_from_config`
 (torchdrivesim/rendering/__init__.py:18-50); here the one real backend is the MI355X rasteriser (`hip`), which has
-the OpenCV backend's pixel semantics, plus the dummy renderer.  'default' selects `hip`.
+the OpenCV backend's pixel semantics, plus the dummy renderer.  'default' selects `hip`; a `CV2RendererConfig` (the reference's
+OpenCV configuration) selects it too.
 """
 from torchdrivesim_amd.rendering.base import (RendererConfig, DummyRendererConfig, BirdviewRenderer, DummyRenderer, Cameras,
                                               get_default_color_map, get_default_rendering_levels)
-from torchdrivesim_amd.rendering.hip import HipRendererConfig, HipRenderer
+from torchdrivesim_amd.rendering.hip import HipRendererConfig, CV2RendererConfig, HipRenderer
 
 
 def renderer_from_config(cfg: RendererConfig, *args, **kwargs) -> BirdviewRenderer:

@@ -26,6 +26,14 @@ class HipRendererConfig(RendererConfig):
     out_dtype: str = 'float32'      #: 'float32' (reference-faithful values 0..255) or 'uint8' (same values, 4x fewer bytes)
 
 
+@dataclass
+class CV2RendererConfig(HipRendererConfig):
+    """The reference's name for the configuration of its OpenCV backend (rendering/cv2.py:12-15).  A configuration written for that
+    backend selects the MI355X rasteriser here: same pixel semantics, no OpenCV involved."""
+    backend: str = 'cv2'
+    trim_mesh_before_rendering: bool = True      #: the rasteriser always applies the reference's trim rule; False is refused
+
+
 def level_table(*level_sources) -> list:
     """distinct rendering levels in descending order (painter order: first = drawn first)"""
     vals = set()
@@ -38,6 +46,9 @@ class HipRenderer(BirdviewRenderer):
     def __init__(self, cfg: HipRendererConfig, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)
         self.cfg: HipRendererConfig = cfg
+        if not getattr(cfg, 'trim_mesh_before_rendering', True):
+            # untrimmed, faces without a vertex in view are drawn too (cv2.py:32-41): other pixels than the kernels produce
+            raise NotImplementedError('trim_mesh_before_rendering=False is not available: the rasteriser culls with the trim rule')
 
     @property
     def out_dtype(self) -> torch.dtype:
