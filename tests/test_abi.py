@@ -47,3 +47,28 @@ def test_cpu_tensors_are_rejected():
     s = torch.zeros(2, 3, 4)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _ops.bicycle_step(s, torch.zeros(2, 3, 2), torch.ones(2, 3))
+
+
+def _build_c_caller(out_dir):
+    """tests/abi_smoke.c with plain gcc against include/tdship.h and libtdship.so: the header is valid C, every entry point links"""
+    import subprocess
+    from torchdrivesim_amd import _native
+    _native.build()
+    exe = os.path.join(str(out_dir), 'abi_smoke')
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I' + os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'tests', 'abi_smoke.c'), '-o', exe, '-L' + lib_dir, '-ltdship', '-L/opt/rocm/lib', '-lamdhip64', '-lm',
+                           '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib'])
+    return exe
+
+
+def test_a_plain_c_program_builds_against_the_header(tmp_path):
+    assert os.path.exists(_build_c_caller(tmp_path))
+
+
+@pytest.mark.gpu
+def test_a_plain_c_program_runs_through_the_abi(tmp_path):
+    """no Python and no torch in the process: kinematics known answer, an IoU scene, and the error path"""
+    import subprocess
+    out = subprocess.run([_build_c_caller(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'abi smoke ok' in out.stdout, out.stdout + out.stderr
