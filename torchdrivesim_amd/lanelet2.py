@@ -184,6 +184,11 @@ class Lanelet:
         """left bound followed by the reversed right bound (lanelet2 `Lanelet::polygon2d`)"""
         return np.concatenate([self.left[:, :2], self.right[::-1, :2]], 0)
 
+    def invert(self) -> 'Lanelet':
+        """The same surface driven the other way (`lanelet2.core.Lanelet.invert`): the reversed right bound becomes the left one."""
+        return Lanelet(self.id, self.right[::-1].copy(), self.left[::-1].copy(), self.right_ids[::-1].copy(), self.left_ids[::-1].copy(),
+                       dict(self.attributes))
+
 
 class LaneletMap:
     """The two layers of a Lanelet2 map the reference touches: `pointLayer` (ids + coordinates, in file order) and
@@ -216,6 +221,13 @@ class LaneletMap:
 
     def __bool__(self) -> bool:           # `if not lanelet_map` in the reference (infractions.py:266)
         return True
+
+
+def revert_map(lanelet_map: 'LaneletMap') -> 'LaneletMap':
+    """Every lanelet inverted -- what the reference's examples/lanelet2_to_birdview_mesh.py:20-36 does to CARLA maps after loading
+    ("Fixing for Carla left-handed coordinates"): a loader that works in number space turns the lanelets of a map authored in a
+    left-handed frame around, and this turns them back."""
+    return LaneletMap(lanelet_map.point_ids, lanelet_map.points, [l.invert() for l in lanelet_map.laneletLayer if len(l.left) and len(l.right)])
 
 
 def make_lanelet(lanelet_id: int, left, right, attributes: Optional[Dict[str, str]] = None) -> Lanelet:
