@@ -33,6 +33,17 @@ def town01_mesh():
     return t['verts'], t['faces'], t['vert_category'], [str(c) for c in t['categories']]
 
 
+@pytest.fixture(scope='module')
+def town02():
+    return L.load_lanelet_map(os.path.join(GOLD, 'carla_Town02.osm.gz'), origin=(0.0, 0.0))
+
+
+@pytest.fixture(scope='module')
+def town02_mesh():
+    t = np.load(os.path.join(GOLD, 'town02_mesh.npz'))
+    return t['verts'], t['faces'], t['vert_category'], [str(c) for c in t['categories']]
+
+
 def _canon(tris, ordered=True):
     """triangles (n,3,2) -> sorted list of coordinate tuples on a 0.1 mm lattice (the two builds differ by 1 ulp of float32 in places)"""
     q = np.round(np.asarray(tris, np.float64) * 1e4).astype(np.int64)
@@ -353,3 +364,20 @@ def test_inverted_lanelets_and_revert_map(town01):
     tri = lambda m: sorted(tuple(sorted(map(tuple, np.round(t * 1e4).astype(np.int64)))) for t in
                            L.road_mesh_from_lanelet_map(m).verts[0].numpy()[L.road_mesh_from_lanelet_map(m).faces[0].numpy()][:200 * 0 + 6150])
     assert len(tri(back)) == len(tri(town01)) == 6150
+
+
+def test_town02_reproduces_its_shipped_mesh_too(town02, town02_mesh):
+    """a second map of the reference, generated upstream at another time (its categories are stored in another order)"""
+    verts, faces, vcat, cats = town02_mesh
+    assert len(town02.laneletLayer) == 88 and town02.points.shape == (5148, 3)
+    from scipy.spatial import cKDTree
+    road_pts = verts[vcat == cats.index('road')]
+    mine = town02.points[:, :2].astype(np.float32)
+    assert cKDTree(road_pts).query(mine)[0].max() < 2e-5 and cKDTree(mine).query(road_pts)[0].max() < 2e-5
+    fcat = vcat[faces[:, 0]]
+    rm = L.road_mesh_from_lanelet_map(town02)
+    assert _canon(rm.verts[0].numpy()[rm.faces[0].numpy()]) == _canon(verts[faces[fcat == cats.index('road')]])
+    lm = L.lanelet_map_to_lane_mesh(town02, left_handed=False)
+    mv, mf, mc = lm.verts[0].numpy(), lm.faces[0].numpy(), lm.vert_category[0].numpy()
+    for ci, name in enumerate(lm.categories):
+        assert _canon(mv[mf[mc[mf[:, 0]] == ci]]) == _canon(verts[faces[fcat == cats.index(name)]]), name
