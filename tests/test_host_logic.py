@@ -58,11 +58,9 @@ def test_copy_extend_select():
     assert sim.get_state()[0, 0].tolist() == [1, 1, 1, 1] and sim.get_state()[0, 1].tolist() == [4, 5, 6, 7]
 
 
-def test_out_of_scope_arguments_are_refused():
+def test_lanelet_maps_and_lane_features_are_carried():
     from torchdrivesim_amd.simulator import Simulator
     sim = make_sim()
-    with pytest.raises(NotImplementedError):
-        sim.render_egocentric(noisy_perception=True)
     # lane features are carried through the batch plumbing and the observation model (simulator.py:335,418,439,464,498,829)
     from torchdrivesim_amd.lanelet2 import LaneFeatures
     from torchdrivesim_amd.observation_noise import MapObservationNoiseFromLog

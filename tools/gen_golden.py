@@ -756,6 +756,64 @@ def gen_discs_n(out):
     print('g13: nonzero fractions', {k: float((d[f'discs_{k}'] > 0).mean()) for k in (3, 7, 9, 25)})
 
 
+# --------------------------------------------------------------------------------------
+# G14: noisy perception (simulator.py:951-978): the observation model's background mesh, lane markers and traffic controls in the
+#      rendered frame -- the call list of render_egocentric(noisy_perception=True) at the OpenCV boundary
+# --------------------------------------------------------------------------------------
+def gen_noisy_perception(out, cv2, town):
+    from torchdrivesim.lanelet2 import LaneFeatures
+    from torchdrivesim.observation_noise import MapObservationNoiseFromLog, StandardSensingObservationNoiseConfig
+    from torchdrivesim.rendering import CV2RendererConfig, renderer_from_config
+    from torchdrivesim.traffic_controls import TrafficLightControl, StopSignControl
+    g = seeded(1414)
+    centre = (100.0, 2.0)
+    crop = crop_mesh(town, centre, 40.0)
+    B, A, M = 2, 3, 6
+    state, size, present = random_scene(g, B, A, spread=20.0, centre=centre)
+    present[:, 0] = True
+    # what the policy is shown: a smaller crop of the map shifted by 1.5 m, six lane markers (two masked), lights in other states
+    noisy_bg = crop_mesh(town, centre, 25.0)
+    noisy_bg = type(noisy_bg)(verts=noisy_bg.verts + torch.tensor([1.5, -0.75]), faces=noisy_bg.faces, categories=noisy_bg.categories,
+                              colors=noisy_bg.colors, zs=noisy_bg.zs, vert_category=noisy_bg.vert_category, _cat_fill=noisy_bg._cat_fill).expand(B)
+    markers = torch.cat([torch.tensor(centre) + (torch.rand(B, M, 2, generator=g) - 0.5) * 30, (torch.rand(B, M, 1, generator=g) * 2 - 1) * math.pi,
+                         torch.rand(B, M, 1, generator=g) * 2 + 0.5], -1)
+    mmask = torch.ones(B, M, dtype=torch.bool)
+    mmask[0, 1] = mmask[1, 4] = False
+    lights = torch.cat([torch.tensor(centre) + (torch.rand(B, 3, 2, generator=g) - 0.5) * 24, torch.tensor([1.0, 4.0]).expand(B, 3, 2),
+                        (torch.rand(B, 3, 1, generator=g) * 2 - 1) * math.pi], -1)
+    true_tc = {'traffic_light': TrafficLightControl(lights.clone())}
+    true_tc['traffic_light'].set_state(torch.zeros(B, 3, dtype=torch.long))
+    noisy_tc = {'traffic_light': TrafficLightControl(lights.clone() + torch.tensor([0.5, 0.5, 0, 0, 0])),
+                'stop_sign': StopSignControl(torch.cat([torch.tensor(centre) + (torch.rand(B, 2, 2, generator=g) - 0.5) * 24,
+                                                        torch.tensor([1.0, 3.5]).expand(B, 2, 2), torch.zeros(B, 2, 1)], -1))}
+    noisy_tc['traffic_light'].set_state(torch.tensor([[2, 1, 0], [1, 2, 2]]))
+    model = MapObservationNoiseFromLog(StandardSensingObservationNoiseConfig(),
+                                       noisy_lane_features=[LaneFeatures(dense_lane_features=markers, dense_lane_features_mask=mmask)],
+                                       noisy_background_mesh=[noisy_bg], noisy_traffic_controls=[noisy_tc])
+    from torchdrivesim.simulator import Simulator, TorchDriveConfig
+    from torchdrivesim.kinematic import KinematicBicycle
+    km = KinematicBicycle()
+    km.set_params(lr=torch.full((B, A), 1.5))
+    km.set_state(state.clone())
+    sim = Simulator(crop.expand(B), km, size.clone(), present.clone(), TorchDriveConfig(), renderer=renderer_from_config(CV2RendererConfig()),
+                    traffic_controls=true_tc, observation_noise_model=model,
+                    lane_features=LaneFeatures(dense_lane_features=markers[:, :2] + torch.tensor([2.0, 2.0, 0.3, 0.0]), dense_lane_features_mask=mmask[:, :2] | True))
+    d = dict(state=npy(state), size=npy(size), present=npy(present), markers=npy(markers), markers_mask=npy(mmask), lights=npy(lights),
+             noisy_lights=npy(noisy_tc['traffic_light'].pos), noisy_light_state=npy(noisy_tc['traffic_light'].state),
+             noisy_stop=npy(noisy_tc['stop_sign'].pos),
+             road_verts=npy(crop.verts[0]), road_faces=npy(crop.faces[0]).astype(np.int32), road_vert_category=npy(crop.vert_category[0]).astype(np.uint8),
+             noisy_verts=npy(noisy_bg.verts[0]), noisy_faces=npy(noisy_bg.faces[0]).astype(np.int32),
+             noisy_vert_category=npy(noisy_bg.vert_category[0]).astype(np.uint8))
+    for tag, kw in (('noisy', dict(noisy_perception=True)), ('plain', dict())):
+        tris, cols, shape = render_record(cv2, sim, 96, 35.0, **kw)
+        d[f'tris_{tag}'], d[f'cols_{tag}'] = tris, cols
+        print('g14', tag, tris.shape, 'marker-coloured calls', int((cols == np.array([255, 0, 255], np.uint8)).all(-1).sum()))
+    sim.internal_time = 1                                       # the log is exhausted: noisy perception shows the truth
+    tris, cols, _ = render_record(cv2, sim, 96, 35.0, noisy_perception=True)
+    d['tris_after'], d['cols_after'] = tris, cols
+    np.savez_compressed(os.path.join(out, 'g14_noisy_perception.npz'), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -767,6 +825,9 @@ def main():
     torch.set_num_threads(1)
     import torchdrivesim  # noqa: F401  (the reference)
     assert os.path.realpath(torchdrivesim.__path__[0]).startswith(os.path.realpath(REF))
+    if args.only == 'noisy':
+        gen_noisy_perception(args.out, cv2, load_town01())
+        return
     if args.only == 'discs_n':
         gen_discs_n(args.out)
         return
@@ -788,6 +849,7 @@ def main():
     gen_waypoints(args.out, cv2, town)
     gen_traffic_lights(args.out)
     gen_discs_n(args.out)
+    gen_noisy_perception(args.out, cv2, town)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

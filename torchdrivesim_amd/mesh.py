@@ -533,7 +533,8 @@ class BirdviewRGBMeshGenerator:
 
     def initialize_traffic_controls_mesh(self, traffic_controls) -> None:
         mk = lambda sel: set_colors_with_defaults(self._create_traffic_controls_mesh(traffic_controls, sel), color_map=self.color_map,
-                                                  rendering_levels=self.rendering_levels)
+                                                  rendering_levels=self.rendering_levels).to(self.background_mesh.device)     # an absent kind is an
+        #                                                                                               empty mesh, created on the host
         self.static_traffic_controls_mesh = mk(['stop_sign', 'yield_sign'])
         self.traffic_lights_mesh = mk(['traffic_light'])
         self.traffic_light_colors = None
@@ -541,6 +542,13 @@ class BirdviewRGBMeshGenerator:
             tl = traffic_controls['traffic_light']
             cols = torch.stack([tensor_color(self.color_map[f'traffic_light_{st}'], device=self.traffic_lights_mesh.device) for st in tl.allowed_states])
             self.traffic_light_colors = cols.reshape(1, 1, -1, 3).expand(self.traffic_lights_mesh.batch_size, tl.state.shape[1], -1, -1)
+
+    def add_static_meshes(self, meshes: List[BirdviewMesh]) -> None:
+        """more static elements behind the actors: coloured by category and appended to the background (mesh.py:870-883)"""
+        self.add_static_rgb_meshes([set_colors_with_defaults(m.clone(), color_map=self.color_map, rendering_levels=self.rendering_levels) for m in meshes])
+
+    def add_static_rgb_meshes(self, meshes: List[RGBMesh]) -> None:
+        self.background_mesh = self.background_mesh.concat([self.background_mesh] + list(meshes))
 
     # ---- batch plumbing
     def to(self, device):

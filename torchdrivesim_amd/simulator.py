@@ -12,7 +12,7 @@
     compute_wrong_way  -> lane tables of `lanelet_map` (lanelet2.py), one launch  reference: simulator.py:607-630 (Python triple loop)
 
 Also carried: traffic controls, waypoint goals (state + rendering), observation noise and lane features (plumbing only).  Out of scope
-(SURVEY.md section 8): `noisy_perception` rendering, which raises NotImplementedError instead of being silently ignored.
+(SURVEY.md section 8): lanelet-derived lane features (the tensors are supplied by the caller).
 """
 import logging
 from dataclasses import dataclass, field
@@ -678,12 +678,48 @@ class Simulator:
         return torch.stack([body, torch.zeros_like(body)], dim=-1).to(torch.int32)
 
     # ------------------------------------------------------------------------------------------------- rendering
+    def _noisy_scene_sources(self):
+        """(mesh generator, traffic controls) of a noisy-perception frame (simulator.py:951-978)"""
+        from torchdrivesim_amd.mesh import BaseMesh
+        from torchdrivesim_amd.utils import rotate
+        gen = self.birdview_mesh_generator.copy()
+        gen.background_mesh = self.get_noisy_background_mesh()
+        noisy_lf = self.get_noisy_lane_features()
+        if noisy_lf is not None and noisy_lf.dense_lane_features is not None:
+            markers, markers_mask = noisy_lf.dense_lane_features, noisy_lf.dense_lane_features_mask      # B x M x [x, y, psi, width], B x M
+            if markers_mask is None:
+                markers_mask = torch.ones_like(markers[..., 0], dtype=torch.bool)
+            n_markers = markers.shape[-2]
+            width = markers[..., 3]
+            zero, one = torch.zeros_like(width), torch.ones_like(width)
+            arrow = torch.stack([torch.stack([zero, -width / 2], dim=-1), torch.stack([zero, width / 2], dim=-1), torch.stack([one, zero], dim=-1)], dim=-2)
+            verts = rotate(arrow, markers[..., None, 2:3]) + markers[..., None, :2]                    # one metre long, pointing along psi
+            verts = torch.where(markers_mask[..., None, None], verts, torch.zeros_like(verts))
+            faces = torch.tensor([[0, 1, 2]], dtype=torch.long, device=markers.device) + 3 * torch.arange(n_markers, device=markers.device)[:, None]
+            dense = BirdviewMesh.set_properties(BaseMesh(verts=verts.flatten(-3, -2), faces=faces.expand_as(verts[..., 0])), category='stop_sign')
+            gen.add_static_meshes([dense])
+        controls = self.get_noisy_traffic_controls()
+        if controls is not None:
+            gen.initialize_traffic_controls_mesh(controls)
+        return gen, controls
+
     def render(self, camera_xy: Tensor, camera_psi: Tensor, res: Optional[Resolution] = None, rendering_mask: Optional[Tensor] = None,
                fov: Optional[float] = None, waypoints: Optional[Tensor] = None, waypoints_rendering_mask: Optional[Tensor] = None,
                custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None) -> Tensor:
         """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992)."""
         if noisy_perception:
-            raise NotImplementedError('noisy perception swaps the static background every step (logged maps); outside the scope of torchdrivesim_amd')
+            # what the policy is shown instead of the truth (simulator.py:951-978): the observation model's background, its lane markers
+            # drawn as triangles, its traffic controls.  The scene of the ordinary path is swapped for the duration of the call; its
+            # static map is rebuilt from the noisy background (a map upload per call: this is the slow lane of the renderer).
+            gen, controls = self._noisy_scene_sources()
+            saved = (self.birdview_mesh_generator, self.traffic_controls, self._scene_cache)
+            self.birdview_mesh_generator, self.traffic_controls, self._scene_cache = gen, controls, None
+            try:
+                return self.render(camera_xy, camera_psi, res=res, rendering_mask=rendering_mask, fov=fov, waypoints=waypoints,
+                                   waypoints_rendering_mask=waypoints_rendering_mask, custom_agent_colors=custom_agent_colors,
+                                   noisy_perception=False, _camera_sc=_camera_sc)
+            finally:
+                self.birdview_mesh_generator, self.traffic_controls, self._scene_cache = saved
         camera_sc = _camera_sc if _camera_sc is not None else torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
         if camera_xy.dim() == 2:
             camera_xy, camera_sc = camera_xy.unsqueeze(1), camera_sc.unsqueeze(1)
