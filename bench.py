@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 RES, FOV = 256, 35.0
 ALGO_BYTES_PER_IMAGE = 3 * RES * RES * 4          # fp32 CHW raster output, the algorithmic bytes of K3
 HBM_PEAK_GBS = 8000.0                             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0                             # what a float4 copy reaches on this part (same guide): the practical roof, reported beside the spec
 
 
 def load_town01():
@@ -173,7 +174,8 @@ def main():
                                  f'fp32 fov {FOV:g} m + compute_collision(iou) + compute_offroad', global_batch=world * B, agents=A, res=RES,
                         parallelism=f'scene-batch sharding x{world}, no collectives'),
             roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                          kernel='raster_scene_bits_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE))
+                          kernel='raster_scene_bits_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE,
+                          measured_copy_peak=HBM_COPY_GBS, frac_of_measured_copy=achieved / HBM_COPY_GBS))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(host, min(args.cpu_scenes, B), A)
         print(json.dumps(line))
