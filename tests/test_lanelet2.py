@@ -381,3 +381,12 @@ def test_town02_reproduces_its_shipped_mesh_too(town02, town02_mesh):
     mv, mf, mc = lm.verts[0].numpy(), lm.faces[0].numpy(), lm.vert_category[0].numpy()
     for ci, name in enumerate(lm.categories):
         assert _canon(mv[mf[mc[mf[:, 0]] == ci]]) == _canon(verts[faces[fcat == cats.index(name)]]), name
+
+
+def test_point_queries_refuse_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        L.find_direction(KAT_LEFT, (0.5, 0.5, 0))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        L.find_lanelet_directions(L.LaneletMap([], np.zeros((0, 3)), [L.make_lanelet(1, KAT_LEFT, KAT_RIGHT)]), 0.5, 0.5)

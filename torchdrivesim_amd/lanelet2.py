@@ -475,6 +475,15 @@ def lane_table(lanelet_map: LaneletMap, tags_to_exclude: Optional[Sequence[str]]
 # ------------------------------------------------------------------------------------------------------------------------
 # point queries with the reference's signatures; both run the batch kernel on one point
 # ------------------------------------------------------------------------------------------------------------------------
+def _query_device(device):
+    """where a point query runs: the given device, else the current MI355X -- there is no CPU implementation"""
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError('lane-map queries run on an MI355X; no GPU is visible and there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
 def find_lanelet_directions(lanelet_map: LaneletMap, x: float, y: float, tags_to_exclude: Optional[List[str]] = None,
                             lanelet_dist_tolerance: float = 1.0, device=None) -> List[float]:
     """
@@ -482,7 +491,7 @@ def find_lanelet_directions(lanelet_map: LaneletMap, x: float, y: float, tags_to
     (reference lanelet2.py:108-141).  Raises LaneletError where the reference's `find_direction` does.
     """
     from . import _ops
-    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    dev = _query_device(device)
     lanes = lanelet_map.table(dev, tags_to_exclude or [], lanelet_dist_tolerance)
     pts = torch.tensor([[float(x), float(y)]], dtype=torch.float64, device=dev)
     dirs, dists, count, status = _ops.lanelet_directions([lanes], None, pts, float(lanelet_dist_tolerance))
@@ -514,7 +523,7 @@ def find_direction(linestring, location3d, device=None) -> float:
     hi = np.maximum(ls[:, :2].max(0), loc[:2]) + 1.0
     box = np.array([[lo[0], lo[1]], [hi[0], lo[1]], [hi[0], hi[1]], [lo[0], hi[1]]])
     table = LaneTable(box, np.array([0, 4], np.int32), np.ascontiguousarray(ls), np.array([0, len(ls)], np.int32), np.zeros(1, np.int32))
-    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    dev = _query_device(device)
     lanes = _ops.LaneTableHandle(table, dev, max_tolerance=0.0)
     dirs, _, count, status = _ops.lanelet_directions([lanes], None, torch.tensor([[loc[0], loc[1]]], dtype=torch.float64, device=dev), 0.0)
     if int(status[0]) & 1 or int(count[0]) != 1:

@@ -146,7 +146,8 @@ def find_wrong_way_stoplines(map_cfg: MapConfig, angle_threshold: float = 3.1415
     stoplines = map_cfg.stoplines
     if lanelet_map is None or not stoplines:
         return []
-    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    from torchdrivesim_amd.lanelet2 import _query_device
+    dev = _query_device(device)
     pts = torch.tensor([[s.x, s.y] for s in stoplines], dtype=torch.float64, device=dev)
     dirs, _, count, status = _ops.lanelet_directions([lanelet_map.table(dev, [], 0.0)], None, pts, 0.0)
     dirs, count, status = dirs.cpu().numpy(), count.cpu().numpy(), status.cpu().numpy()
