@@ -5,13 +5,21 @@ Headline benchmark (BASELINE.json): agent-steps/s of the GymEnv.step body (examp
 at B = 1024 scenes x A = 64 agents per GPU on the Town01 map (tests/golden/town01_mesh.npz), synthetic agents.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ...`: one process per GPU, the scene batch is
-sharded (B per GPU is fixed: weak scaling), there is no data-path collective; RCCL is only used for the barrier and
-the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+One process per GPU; the scene batch is sharded (B per GPU is fixed: weak scaling) and there is NO data-path collective.
+N > 1 runs either way:
+  * `python bench.py --gpus N ...` by itself: this process never touches a GPU; it starts N children (one per GPU, each with
+    HIP_VISIBLE_DEVICES narrowed to its own device), which rendezvous on 127.0.0.1 over gloo -- used only for the barrier
+    around the timed region and the max-over-ranks of the elapsed time (SURVEY.md 8e);
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: the same worker, barrier over RCCL.
+Rank 0 prints ONE JSON line.  `--dry-run` runs the whole launch / barrier / reduction / reporting path without a GPU and
+without kernels (CPU test of the launcher, tests/test_bench_launcher.py).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -102,6 +110,173 @@ def cpu_baseline(host, n_scenes, A):
                 value_single_thread=out['one'][0])
 
 
+def kernel_source_stamp():
+    """sha256 over the sources of the raster kernel: PMC figures committed under profiles/ carry the stamp of the build they were
+    measured on and are refused for any other (the static traffic figure must not go stale silently)."""
+    h = hashlib.sha256()
+    for name in ('raster.hip', 'tds_common.h'):
+        with open(os.path.join(ROOT, 'torchdrivesim_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def stamped_traffic(B, A, mode='f32'):
+    """(HBM bytes per launch from the PMC passes committed in profiles/raster_traffic.json, note) -- null unless it was measured on
+    exactly this kernel source and this workload."""
+    tpath = os.path.join(ROOT, 'profiles', 'raster_traffic.json')
+    if not os.path.exists(tpath):
+        return None, 'no PMC figure committed'
+    tj = json.load(open(tpath))
+    ent = tj.get(mode) if isinstance(tj.get(mode), dict) else (tj if mode == 'f32' else None)
+    if not ent:
+        return None, f'no PMC figure for mode {mode}'
+    if ent.get('kernel_source_sha') != kernel_source_stamp():
+        return None, f"PMC figure refused: measured on kernel source {ent.get('kernel_source_sha')}, this build is {kernel_source_stamp()}"
+    if (ent.get('batch'), ent.get('agents'), ent.get('res')) != (B, A, RES):
+        return None, 'PMC figure is for another workload'
+    return ent.get('hbm_bytes_per_launch'), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {ent.get('source')}"
+
+
+def other_configs(device, steps, warmup):
+    """BASELINE.json's other single-GPU configurations (2, 3, 5) and the uint8 output mode of the headline kernel, measured in
+    this run after the timed region: ms/step, agent-steps/s, the dominant kernel and its fraction of the HBM roof."""
+    from torchdrivesim_amd import _ops, lanelet2
+    from torchdrivesim_amd.utils import Resolution
+    res = Resolution(RES, RES)
+    lanes = lanelet2.load_lanelet_map(os.path.join(ROOT, 'tests', 'golden', 'carla_Town01.osm.gz'), origin=(0.0, 0.0))
+    out, sink = [], {}
+
+    def timed(fn):
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize(device)
+        _ops.raster_events, _ops.raster_bwd_events = [], []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        fwd = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else None
+        bwd = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_bwd_events])) if _ops.raster_bwd_events else None
+        _ops.raster_events = _ops.raster_bwd_events = None
+        return dt, fwd, bwd
+
+    B, A = 256, 64
+    for name in ('config2', 'config3', 'config5'):
+        sim, actions, _ = build_simulator(B, A, device, seed=1234, lanelet_map=lanes)
+        state0 = sim.get_state().clone()
+
+        def fwd(i):
+            sim.step(actions[i % actions.shape[0]])
+            sink['img'] = sim.render_egocentric(res=res, fov=FOV)
+            sink['col'] = sim.compute_collision()
+            if name != 'config2':
+                sink['off'] = sim.compute_offroad()
+                sink['ww'] = sim.compute_wrong_way()
+
+        def fwd_bwd(i):
+            s0 = state0.clone().requires_grad_(True)
+            act = actions[i % actions.shape[0]].clone().requires_grad_(True)
+            sim.kinematic_model.set_state(s0)
+            sim.step(act)
+            img = sim.render_egocentric(res=res, fov=FOV)
+            loss = (img * sink['w']).sum() + sim.compute_collision().sum() + sim.compute_offroad().sum()
+            loss.backward()
+            sink['g'] = (s0.grad, act.grad)
+
+        if name == 'config5':
+            # the incoming image gradient is a fixed random field (what a policy network's first layer would hand back), not the
+            # gradient of a mean: the loss costs one fused multiply-reduce over the image instead of round 1's mean + its materialised gradient
+            sink['w'] = torch.rand(B, A, 3, RES, RES, device=device)
+        dt, k_fwd, k_bwd = timed(fwd_bwd if name == 'config5' else fwd)
+        what = {'config2': 'step + render_egocentric 256x256 + compute_collision(iou)',
+                'config3': 'config2 + compute_offroad + compute_wrong_way (Town01 lane map)',
+                'config5': 'step + render + collision + offroad, then backward through kinematics, IoU, off-road and the rasteriser; '
+                           'loss = sum(image * fixed random weights) + sum(collision) + sum(offroad)'}[name]
+        ent = dict(config=name, what=what, batch=B, agents=A, ms_per_step=1e3 * dt, agent_steps_per_s=B * A / dt,
+                   dominant_kernel='raster_scene_bits_kernel', dominant_kernel_ms=k_fwd,
+                   dominant_kernel_frac_of_hbm_peak=None if not k_fwd else B * A * ALGO_BYTES_PER_IMAGE / (k_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        if k_bwd is not None:
+            ent['raster_backward_kernel_ms'] = k_bwd
+        out.append(ent)
+        del sim
+        sink.clear()
+        torch.cuda.empty_cache()
+    return out
+
+
+def u8_mode(device, steps, warmup, B, A):
+    """The uint8 output mode of the headline render (a quarter of the bytes, same pixels): a SEPARATE roofline entry, never `value`."""
+    from torchdrivesim_amd import _ops
+    from torchdrivesim_amd.rendering import HipRendererConfig, renderer_from_config
+    from torchdrivesim_amd.utils import Resolution
+    sim, actions, _ = build_simulator(B, A, device, seed=1234)
+    sim.renderer = renderer_from_config(HipRendererConfig(out_dtype='uint8'), res=Resolution(RES, RES), fov=FOV)
+    sim._scene_cache = None
+    sim.step(actions[0])
+    for _ in range(warmup):
+        img = sim.render_egocentric(res=Resolution(RES, RES), fov=FOV)
+    torch.cuda.synchronize(device)
+    _ops.raster_events = []
+    for _ in range(steps):
+        img = sim.render_egocentric(res=Resolution(RES, RES), fov=FOV)
+    torch.cuda.synchronize(device)
+    ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events]))
+    _ops.raster_events = None
+    assert img.dtype == torch.uint8
+    algo = B * A * 3 * RES * RES
+    achieved = algo / (ms * 1e-3) / 1e9
+    traffic, note = stamped_traffic(B, A, 'u8')
+    del sim, img
+    torch.cuda.empty_cache()
+    return dict(mode='uint8 output (3*H*W bytes per camera)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                traffic=traffic, traffic_source=note, kernel='raster_scene_bits_kernel<uint8>', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` by itself: start one worker per GPU and wait.  This process makes NO GPU call (it would otherwise
+    hold a context on device 0 beside rank 0's)."""
+    n = args.gpus
+    visible = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('CUDA_VISIBLE_DEVICES')
+    ids = [v.strip() for v in visible.split(',') if v.strip()] if visible else [str(i) for i in range(n)]
+    if len(ids) < n:
+        raise SystemExit(f'--gpus {n} but only {len(ids)} devices are visible ({visible})')
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=ids[r], TDS_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.pop('CUDA_VISIBLE_DEVICES', None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ['--worker'], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b''
+    deadline = time.time() + args.launch_timeout
+    failed = None
+    try:
+        out0 = procs[0].communicate(timeout=args.launch_timeout)[0]
+        for r, pr in enumerate(procs):
+            rc = pr.wait(timeout=max(1.0, deadline - time.time()))
+            if rc != 0 and failed is None:
+                failed = (r, rc)
+    except subprocess.TimeoutExpired:
+        failed = ('timeout', -1)
+    finally:
+        for pr in procs:                        # exact PIDs of the children this process started, nothing else
+            if pr.poll() is None:
+                pr.kill()
+    for ln in out0.decode().splitlines():       # rank 0's JSON line to stdout, anything else it printed to stderr
+        (sys.stdout if ln.lstrip().startswith('{') else sys.stderr).write(ln + '\n')
+    sys.stdout.flush()
+    if failed is not None:
+        raise SystemExit(f'bench worker {failed[0]} failed (exit code {failed[1]})')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -110,37 +285,64 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='scenes per GPU')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help="skip the extra `configs` / `roofline_u8` entries (BASELINE.json's configs 2, 3, 5; N = 1 only)")
     ap.add_argument('--cpu-scenes', type=int, default=320, help='scenes of the CPU-baseline sample (all cores, about 10 s); the single-thread run uses a sixteenth')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU, no kernels: exercises launch, barrier, reduction and the JSON line only')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0)
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world == 1 and not args.worker:
+        return launch(args, [a for a in sys.argv[1:]])
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N')
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    backend = os.environ.get('TDS_BENCH_BACKEND', 'nccl')
+    if args.dry_run:
+        device, backend = torch.device('cpu'), 'gloo'
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        # the transports announce themselves on fd 1 ("[Gloo] Rank 0 is connected to ..."): stdout carries the ONE JSON line and nothing else
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=device)
+            else:
+                dist.init_process_group('gloo')
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+    red_dev = device if backend == 'nccl' else 'cpu'        # where the (timing-only) reductions live
 
     B, A = args.batch, args.agents
-    sim, actions, host = build_simulator(B, A, device, seed=1234 + rank)
-    from torchdrivesim_amd.utils import Resolution
-    res = Resolution(RES, RES)
-
-    from torchdrivesim_amd import _ops
-    sink = {}
-
-    def step(i):
-        sim.step(actions[i % actions.shape[0]])
-        sink['img'] = sim.render_egocentric(res=res, fov=FOV)
-        sink['col'] = sim.compute_collision()
-        sink['off'] = sim.compute_offroad()
-
     from torchdrivesim_amd import parallel
+    sink = {}
+    if args.dry_run:
+        host = None
+
+        def step(i):
+            sink['i'] = i
+    else:
+        sim, actions, host = build_simulator(B, A, device, seed=1234 + rank)
+        from torchdrivesim_amd.utils import Resolution
+        res = Resolution(RES, RES)
+        from torchdrivesim_amd import _ops
+
+        def step(i):
+            sim.step(actions[i % actions.shape[0]])
+            sink['img'] = sim.render_egocentric(res=res, fov=FOV)
+            sink['col'] = sim.compute_collision()
+            sink['off'] = sim.compute_offroad()
 
     def barrier():
         parallel.barrier(device)            # dist.barrier() when there is a process group, then torch.cuda.synchronize()
@@ -148,24 +350,24 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    _ops.raster_events = []             # HIP events around every raster launch of the timed region
+    if not args.dry_run:
+        _ops.raster_events = []             # HIP events around every raster launch of the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)        # slowest rank
-    raster_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else float('nan')
-    _ops.raster_events = None
+    mine = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(mine, red_dev)        # slowest rank
+    per_rank = parallel.gather_over_ranks(mine, red_dev)
+    raster_ms = None
+    if not args.dry_run:
+        raster_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else None
+        _ops.raster_events = None
 
     if rank == 0:
         value = world * B * A * args.steps / elapsed
-        achieved = (B * A * ALGO_BYTES_PER_IMAGE) / (raster_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'raster_traffic.json')
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get('batch') == B and tj.get('agents') == A and tj.get('res') == RES:
-                traffic = tj.get('hbm_bytes_per_launch')
+        achieved = (B * A * ALGO_BYTES_PER_IMAGE) / (raster_ms * 1e-3) / 1e9 if raster_ms else None
+        traffic, traffic_note = stamped_traffic(B, A)
         line = dict(
             metric='agent-steps/sec (whole node) at B=1024xA=64, 256x256 BEV', value=value, unit='agent-steps/s', n_gpus=world,
             steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / max(args.steps, 1), higher_is_better=True, scaling='weak',
@@ -173,13 +375,28 @@ def main():
             config=dict(workload=f'B={B}xA={A} per GPU, carla_Town01 mesh (30750 faces): KinematicBicycle.step + render_egocentric {RES}x{RES} '
                                  f'fp32 fov {FOV:g} m + compute_collision(iou) + compute_offroad', global_batch=world * B, agents=A, res=RES,
                         parallelism=f'scene-batch sharding x{world}, no collectives'),
-            roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+            roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=None if achieved is None else achieved / HBM_PEAK_GBS,
+                          traffic=traffic, traffic_source=traffic_note,
                           kernel='raster_scene_bits_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE,
-                          measured_copy_peak=HBM_COPY_GBS, frac_of_measured_copy=achieved / HBM_COPY_GBS))
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(host, min(args.cpu_scenes, B), A)
-        print(json.dumps(line))
+                          measured_copy_peak=HBM_COPY_GBS, frac_of_measured_copy=None if achieved is None else achieved / HBM_COPY_GBS))
+        if world > 1:
+            line['per_rank_agent_steps_per_s'] = [B * A * args.steps / t for t in per_rank]
+            line['launcher'] = 'torch.distributed.run + RCCL barrier' if backend == 'nccl' else 'bench.py self-launch, one child per GPU, gloo barrier on 127.0.0.1'
+        if args.dry_run:
+            line['dry_run'] = True
+            line['data'] = 'none (dry run: no kernels were launched, the value is meaningless)'
+        if world == 1 and not args.dry_run:
+            if not args.no_configs:
+                line['roofline_u8'] = u8_mode(device, args.steps, args.warmup, B, A)
+                del sim
+                sink.clear()
+                torch.cuda.empty_cache()
+                line['configs'] = other_configs(device, args.steps, args.warmup)
+            if not args.no_cpu_baseline:
+                line['cpu_baseline'] = cpu_baseline(host, min(args.cpu_scenes, B), A)
+        print(json.dumps(line), flush=True)
     if distributed:
+        barrier()
         dist.destroy_process_group()
 
 

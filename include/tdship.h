@@ -268,8 +268,22 @@ int tds_lanelet_directions_f64(const tds_laneset_t *set, const int32_t *scene_ma
                                double *dirs, double *dists, int32_t *count, uint8_t *status, int max_dirs, int64_t n_points,
                                float lanelet_dist_tolerance, void *stream);
 
-/* test / tuning hook: force the LDS strip width of K3 (0 = automatic, else 8 .. 128 output rows) */
+/* ---- testing hooks ------------------------------------------------------------------------------------------------------------
+ * NOT part of the product: libtdship.so exports none of these.  They exist in libtdship_testing.so, the same sources compiled with
+ * -DTDS_TESTING, which tools/ (ablations, work counters) and a few tests (forcing the slow code paths) load instead. */
+#ifdef TDS_TESTING
+/* force the LDS strip width of K3 (0 = automatic, else 8 .. 128 output rows) */
 int tds_raster_set_strip_width(int tw);
+/* waves per workgroup of the bit-plane raster kernel (4 or 8) */
+int tds_raster_set_bits_waves(int n);
+/* ablation switches of K3: 1 no static map, 2 no actors, 4 no store, 8 no outline edges, 16 no scan conversion, 32 no binned path,
+ * 64 no bit planes, 128 work counters on */
+int tds_raster_set_debug(int flags);
+/* read and reset the 16 work counters of the bit-plane kernel */
+int tds_raster_get_stats(unsigned long long *out16);
+/* 0: maps created from now on carry no nearest-face candidate lists (K2b then walks grid rings) */
+int tds_testing_set_near_lists(int enabled);
+#endif
 
 #ifdef __cplusplus
 }

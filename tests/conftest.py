@@ -24,3 +24,12 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture
+def testing_lib():
+    """Routes the test through libtdship_testing.so (the product's sources + the header's "testing hooks": forced strip widths, the
+    ring-walk fallback of K2b, ablation switches) and yields it.  Handles created by the test die with its locals, before the switch back."""
+    from torchdrivesim_amd import _native
+    with _native.testing() as T:
+        yield T

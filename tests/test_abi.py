@@ -9,10 +9,22 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
+def _header(testing):
     src = open(os.path.join(ROOT, 'include', 'tdship.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\bint\s+(tds_\w+)\s*\(', src)))
+    hooks = re.search(r'#ifdef TDS_TESTING\n(.*?)#endif', src, flags=re.S)
+    assert hooks, 'include/tdship.h has no "testing hooks" section'
+    return hooks.group(1) if testing else src.replace(hooks.group(0), '')
+
+
+def declared_symbols(testing=False):
+    return sorted(set(re.findall(r'\bint\s+(tds_\w+)\s*\(', _header(testing))))
+
+
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if ' T tds_' in ln)
 
 
 def test_header_symbols_are_exported_and_bound():
@@ -26,6 +38,28 @@ def test_header_symbols_are_exported_and_bound():
         assert n in _native._SIGNATURES, f'{n} has no ctypes signature in _native.py'
     assert set(_native._SIGNATURES) <= set(names)
     assert L.tds_version() == 1
+    # the product exports exactly what the header declares outside its testing section
+    assert exported_symbols(_native.LIB_PATH) == names
+
+
+def test_testing_hooks_are_not_in_the_product():
+    """ablation switches, work counters, tuning knobs and the switch that disables K2b's candidate lists live in
+    libtdship_testing.so only; the product library neither exports them nor reads the environment."""
+    from torchdrivesim_amd import _native
+    _native.build()
+    hooks = declared_symbols(testing=True)
+    assert set(hooks) == set(_native._TESTING_SIGNATURES) and len(hooks) >= 5
+    product = exported_symbols(_native.LIB_PATH)
+    assert not set(hooks) & set(product)
+    assert exported_symbols(_native.TESTING_LIB_PATH) == sorted(set(product) | set(hooks))
+    T = _native.testing_lib()
+    for n in hooks:
+        assert hasattr(T, n)
+    blob = open(_native.LIB_PATH, 'rb').read()
+    assert b'TDS_NO_NEAR_LISTS' not in blob
+    import subprocess
+    undefined = subprocess.run(['nm', '-D', '--undefined-only', _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert ' getenv' not in undefined, 'the product library must not read the environment'
 
 
 def test_errors_are_loud_without_touching_the_gpu():
@@ -34,11 +68,10 @@ def test_errors_are_loud_without_touching_the_gpu():
     # negative size -> TDS_EINVAL with a message; no kernel is launched
     rc = L.tds_bicycle_step_f32(None, None, None, None, -1, 0.1, 5.0, 1.5, 0, 0, None)
     assert rc == -1 and 'out of range' in _native.last_error()
-    rc = L.tds_raster_set_strip_width(5)
-    assert rc == -1
     with pytest.raises(RuntimeError):
-        _native.check(rc, 'tds_raster_set_strip_width')
-    assert L.tds_raster_set_strip_width(0) == 0
+        _native.check(rc, 'tds_bicycle_step_f32')
+    T = _native.testing_lib()
+    assert T.tds_raster_set_strip_width(5) == -1 and T.tds_raster_set_strip_width(0) == 0
 
 
 def test_cpu_tensors_are_rejected():

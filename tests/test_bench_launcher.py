@@ -1,0 +1,69 @@
+"""bench.py's own multi-GPU launcher (BASELINE.json config 4), end to end on the CPU: `python bench.py --gpus 2 --dry-run`
+starts one worker per rank, the workers rendezvous on 127.0.0.1 (gloo), run the barrier / timed loop / max-over-ranks path without
+any kernel, and rank 0 prints ONE well-formed JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TDS_BENCH_BACKEND'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def check_line(line, n, steps, warmup):
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline'):
+        assert k in line, k
+    assert line['n_gpus'] == n and line['steps'] == steps and line['warmup'] == warmup
+    assert line['scaling'] == 'weak' and line['higher_is_better'] is True and line['unit'] == 'agent-steps/s'
+    assert line['config']['global_batch'] == n * 1024 and line['config']['agents'] == 64
+    assert f'x{n}' in line['config']['parallelism'] and 'no collectives' in line['config']['parallelism']
+    assert line['value'] > 0 and line['dry_run'] is True
+
+
+def test_self_launch_two_ranks_dry_run():
+    line = check = run_bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run')
+    check_line(line, 2, 3, 1)
+    assert len(line['per_rank_agent_steps_per_s']) == 2 and 'self-launch' in line['launcher']
+    assert 'cpu_baseline' not in check                               # rank 0 of N = 1 only
+
+
+def test_device_list_is_narrowed_per_rank():
+    # the launcher hands rank r the r-th entry of an inherited device list
+    line = run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--dry-run', env=dict(HIP_VISIBLE_DEVICES='5,3,1'))
+    check_line(line, 2, 1, 0)
+
+
+def test_single_process_dry_run_and_torchrun_shape():
+    line = run_bench('--steps', '2', '--warmup', '1', '--dry-run')
+    check_line(line, 1, 2, 1)
+    assert 'per_rank_agent_steps_per_s' not in line
+    # the worker also runs under an external launcher that provides RANK / WORLD_SIZE (the driver's torch.distributed.run shape)
+    line = run_bench('--gpus', '1', '--steps', '2', '--warmup', '1', '--dry-run', env=dict(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1'))
+    check_line(line, 1, 2, 1)
+
+
+def test_traffic_figure_is_refused_for_another_build(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    val, note = bench.stamped_traffic(1024, 64)
+    tj = json.load(open(os.path.join(ROOT, 'profiles', 'raster_traffic.json')))
+    ent = tj.get('f32', tj)
+    if ent.get('kernel_source_sha') == bench.kernel_source_stamp():
+        assert val == ent['hbm_bytes_per_launch']
+    else:
+        assert val is None and 'refused' in note
+    monkeypatch.setattr(bench, 'kernel_source_stamp', lambda: 'deadbeefdeadbeef')
+    val, note = bench.stamped_traffic(1024, 64)
+    assert val is None and 'refused' in note

@@ -261,15 +261,15 @@ def test_k2b_offroad_town01_random(ops, oracle, town):
     assert (out > 0).any() and (out == 0).any()
 
 
-def test_k2b_candidate_lists_equal_the_ring_walk(ops, oracle, town, monkeypatch):
+def test_k2b_candidate_lists_equal_the_ring_walk(ops, oracle, town, testing_lib):
     """Geometry-only maps answer the off-road query from per-cell nearest-face candidate lists; maps built without them (and points
     outside the grid) walk grid rings.  Both are the exact minimum over all faces: identical bits, at any distance from the road."""
     import os
     m = make_map(ops, town['verts'], town['faces'], None, None, render=False)
     assert m.info()['near_candidates'] > 0
-    monkeypatch.setenv('TDS_NO_NEAR_LISTS', '1')
+    testing_lib.tds_testing_set_near_lists(0)      # this hook exists only in libtdship_testing.so
     m0 = make_map(ops, town['verts'], town['faces'], None, None, render=False)
-    monkeypatch.delenv('TDS_NO_NEAR_LISTS')
+    testing_lib.tds_testing_set_near_lists(1)
     assert m0.info()['near_candidates'] == 0
     gen = np.random.default_rng(11)
     lo, hi = town['verts'].min(0), town['verts'].max(0)
@@ -294,7 +294,7 @@ def test_k2b_candidate_lists_equal_the_ring_walk(ops, oracle, town, monkeypatch)
 
 
 @pytest.mark.parametrize('cell', [1.0, 3.0, 8.0])
-def test_k2b_candidate_lists_on_adversarial_meshes(ops, oracle, monkeypatch, cell):
+def test_k2b_candidate_lists_on_adversarial_meshes(ops, oracle, testing_lib, cell):
     """random triangle soups with huge faces, slivers (area < 5e-3: never "inside"), repeated vertices, collate-padded [0,0,0] faces and a
     face with a NaN vertex; queries inside the mesh, in the margin of the candidate grid and far beyond it"""
     gen = np.random.default_rng(int(cell * 10))
@@ -313,9 +313,9 @@ def test_k2b_candidate_lists_on_adversarial_meshes(ops, oracle, monkeypatch, cel
             verts[20, 0] = np.nan                                                                           # never binned, never nearest
         faces = np.array(faces, np.int32)
         m = ops.StaticMap(verts, faces, device=DEV, cell_size=cell)
-        monkeypatch.setenv('TDS_NO_NEAR_LISTS', '1')
+        testing_lib.tds_testing_set_near_lists(0)      # this hook exists only in libtdship_testing.so
         m0 = ops.StaticMap(verts, faces, device=DEV, cell_size=cell)
-        monkeypatch.delenv('TDS_NO_NEAR_LISTS')
+        testing_lib.tds_testing_set_near_lists(1)
         assert m.info()['near_candidates'] > 0 and m0.info()['near_candidates'] == 0
         B, A = 8, 64
         xy = gen.uniform(-90, 140, (B, A, 2))
@@ -349,7 +349,7 @@ def render_both(ops, oracle, smap, static, state, size, mask, cam_xy, cam_sc, fo
     return img.cpu().numpy(), ref
 
 
-def test_k3_golden_scenes_bit_exact(ops, oracle, town):
+def test_k3_golden_scenes_bit_exact(ops, oracle, town, testing_lib):
     g = load_golden('g45_mesh_preraster.npz')
     for m in json.loads(str(g['g5_meta'])):
         n = m['name']
@@ -368,14 +368,13 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town):
         # (with bits=True a strip width >= 32 cuts the bit-plane kernel's image into strips as well)
         for tw, ws, bits in ((0, True, True), (32, True, True), (64, True, True), (0, True, False), (0, False, False), (64, True, False),
                              (16, True, False), (16, False, False)):
-            from torchdrivesim_amd import _native
-            _native.lib().tds_raster_set_strip_width(tw)
+            testing_lib.tds_raster_set_strip_width(tw)
             ops.use_workspace, ops.use_bitplanes = ws, bits
             ops._workspaces.clear()
             try:
                 img, ref = render_both(ops, oracle, smap, static, st, sz, mask, st[..., :2].copy(), g[f'g5_{n}_cam_sc'], m['fov'], m['res'])
             finally:
-                _native.lib().tds_raster_set_strip_width(0)
+                testing_lib.tds_raster_set_strip_width(0)
                 ops.use_workspace, ops.use_bitplanes = True, True
                 ops._workspaces.clear()
             assert img.shape == tuple(m['out_shape'])

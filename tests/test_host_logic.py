@@ -235,3 +235,46 @@ def test_a_configuration_for_the_opencv_backend_selects_the_rasteriser():
     assert isinstance(renderer_from_config(RendererConfig()), HipRenderer)          # backend 'default'
     with pytest.raises(NotImplementedError):
         renderer_from_config(CV2RendererConfig(trim_mesh_before_rendering=False))
+
+
+def test_heading_cache_follows_the_live_state():
+    """the [sin, cos] cache must never serve an earlier state.  States arrive as fresh tensors with version 0 whose
+    storage the allocator may recycle, so the cache is keyed on tensor identity (and keeps that tensor alive)."""
+    sim = make_sim(2, 3)
+    ref = lambda st: torch.stack([torch.sin(st[..., 2]), torch.cos(st[..., 2])], -1)
+    g = torch.Generator().manual_seed(0)
+    assert torch.equal(sim._heading_sc(), ref(sim.get_state()))
+    first = sim._heading_sc()
+    assert sim._heading_sc() is first                                   # same tensor, same version: served from the cache
+    for step in range(12):                                              # states replaced WITHOUT a query in between, buffers recycled
+        buf = torch.empty(2, 3, 4)
+        buf.copy_(torch.rand(2, 3, 4, generator=g) * 6 - 3)
+        sim.kinematic_model.set_state(buf)
+        del buf
+        if step % 3 == 2:
+            assert torch.equal(sim._heading_sc(), ref(sim.get_state()))
+    st = sim.get_state()
+    sc0 = sim._heading_sc().clone()
+    st[..., 2] += 1.0                                                   # in-place update of the same tensor bumps its version
+    assert not torch.equal(sim._heading_sc(), sc0) and torch.equal(sim._heading_sc(), ref(st))
+    # scenes with NPCs build the concatenated state per call: never cached, always current
+    sim2 = make_sim(2, 3, npc=2)
+    a = sim2._heading_sc()
+    sim2.kinematic_model.set_state(sim2.get_state() + 0.5)
+    assert torch.equal(sim2._heading_sc(), ref(sim2.get_all_agent_state())) and not torch.equal(sim2._heading_sc()[:, :3], a[:, :3])
+
+
+def test_scene_cache_is_keyed_on_its_sources():
+    """the device scene cache (static map, actor templates, keys) is stamped on the identity of the long-lived
+    tensors it is derived from, not on the addresses of torch.cat temporaries."""
+    sim = make_sim(2, 3, npc=2)
+    built = []
+    sim.renderer.make_static_map = lambda *a, **k: built.append(1) or type('M', (), dict(rank_of=lambda self, z: 1))()
+    sim._scene(); sim._scene(); sim._scene()
+    assert len(built) == 1                                              # NPC scenes: cat temporaries differ per call, the cache still holds
+    sim.npc_controller.npc_size = sim.npc_controller.npc_size.clone()   # replaced NPC sizes: rebuilt
+    sim._scene()
+    assert len(built) == 2
+    sim.agent_size.mul_(1.5)                                            # in-place edit of the sizes: rebuilt
+    s = sim._scene()
+    assert len(built) == 3 and torch.allclose(s['tmpl'][:, :3].abs().amax((1, 2, 3)), torch.full((2,), 0.75))

@@ -30,6 +30,13 @@ def main():
     from torchdrivesim_amd import _native, _ops
     from torchdrivesim_amd.utils import Resolution
     dev = torch.device('cuda', 0)
+    # ablation switches / tuning knobs exist only in the testing build; a plain timing or counter run measures the PRODUCT library
+    plain = args.tw == [0] and args.debug == [0] and args.bits_waves == [4]
+    L = None
+    if not plain:
+        L = _native.testing_lib()
+        _native._lib = L                 # every call of this process goes through it
+    print('library:', 'libtdship.so (product)' if plain else 'libtdship_testing.so')
     _ops.use_workspace = not args.no_ws
     _ops.use_bitplanes = not args.no_bits
     sim, actions, _ = bench.build_simulator(args.batch, args.agents, dev, seed=1234)
@@ -38,19 +45,18 @@ def main():
     for i in range(args.steps_before):
         sim.step(actions[i % 8])
     res = Resolution(bench.RES, bench.RES)
-    L = _native.lib()
-    L.tds_raster_set_debug.argtypes = [ctypes.c_int]
     img = sim.render_egocentric(res=res, fov=bench.FOV)
     torch.cuda.synchronize()
     nbytes = img.numel() * img.element_size()
     print(f'images {img.shape[0] * img.shape[1]}, output {nbytes / 1e9:.2f} GB, nonzero fraction {(img[:8] > 0).float().mean().item():.3f}')
     del img
-    L.tds_raster_set_bits_waves.argtypes = [ctypes.c_int]
     for tw, bw in [(t, b) for t in args.tw for b in args.bits_waves]:
-        L.tds_raster_set_bits_waves(bw)
+        if L is not None:
+            L.tds_raster_set_bits_waves(bw)
         for dbg in args.debug:
-            L.tds_raster_set_strip_width(tw)
-            L.tds_raster_set_debug(dbg)
+            if L is not None:
+                L.tds_raster_set_strip_width(tw)
+                L.tds_raster_set_debug(dbg)
             _ops.raster_events = []
             for _ in range(args.iters):
                 sim.render_egocentric(res=res, fov=bench.FOV)
@@ -59,8 +65,9 @@ def main():
             _ops.raster_events = None
             print(f'tw={tw:3d} waves={bw} debug={dbg:2d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
                   f'({nbytes / np.median(ms) / 1e6 / 80:.1f}% of 8 TB/s)')
-    L.tds_raster_set_strip_width(0)
-    L.tds_raster_set_debug(0)
+    if L is not None:
+        L.tds_raster_set_strip_width(0)
+        L.tds_raster_set_debug(0)
 
 
 if __name__ == '__main__':

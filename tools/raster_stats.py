@@ -9,12 +9,11 @@ from torchdrivesim_amd import _native
 from torchdrivesim_amd.utils import Resolution
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device('cuda', 0)
+L = _native.testing_lib()           # the work counters exist only in the testing build
+_native._lib = L
 sim, actions, _ = bench.build_simulator(B, 64, dev, seed=1234)
 for i in range(5):
     sim.step(actions[i % 8])
-L = _native.lib()
-L.tds_raster_set_debug.argtypes = [ctypes.c_int]
-L.tds_raster_get_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 buf = (ctypes.c_ulonglong * 16)()
 sim.render_egocentric(res=Resolution(256, 256), fov=35.0); torch.cuda.synchronize()
 L.tds_raster_get_stats(buf)

@@ -4,6 +4,7 @@ ctypes binding of libtdship.so (C ABI: include/tdship.h).  The library is built 
 
 There is deliberately NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -11,7 +12,9 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('TDSHIP_LIB') or os.path.join(_HERE, 'lib', 'libtdship.so')     # TDSHIP_LIB: tuning builds (tools/)
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtdship.so')
+#: the same sources built with -DTDS_TESTING: the product plus the hooks of the header's "testing hooks" section (tools/, tests/ only)
+TESTING_LIB_PATH = os.path.join(_HERE, 'lib', 'libtdship_testing.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 METRIC_IOU, METRIC_DISCS = 0, 1
@@ -51,7 +54,6 @@ _SIGNATURES = {
     'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp],
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
     'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp],
-    'tds_raster_set_strip_width': [_i32],
     'tds_lanelet_centerline_f64': [_vp, _i32, _vp, _i32, _vp, ctypes.POINTER(_i32)],
     'tds_lanes_create': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, ctypes.POINTER(_vp)],
     'tds_lanes_destroy': [_vp],
@@ -60,6 +62,16 @@ _SIGNATURES = {
     'tds_laneset_destroy': [_vp],
     'tds_wrong_way_f32': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     'tds_lanelet_directions_f64': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _vp],
+}
+
+
+#: entry points that only libtdship_testing.so exports (include/tdship.h, "testing hooks")
+_TESTING_SIGNATURES = {
+    'tds_raster_set_strip_width': [_i32],
+    'tds_raster_set_bits_waves': [_i32],
+    'tds_raster_set_debug': [_i32],
+    'tds_raster_get_stats': [ctypes.POINTER(ctypes.c_ulonglong)],
+    'tds_testing_set_near_lists': [_i32],
 }
 
 
@@ -72,23 +84,50 @@ def build(force=False):
     return LIB_PATH
 
 
+def _load(path, signatures):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f'{path} is missing: the HIP extension has not been built. Run '
+            '`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). There is no CPU fallback.')
+    try:
+        L = ctypes.CDLL(path)
+    except OSError as e:
+        raise RuntimeError(f'cannot load {path}: {e}') from e
+    for name, argtypes in signatures.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f'{LIB_PATH} is missing: the HIP extension has not been built. Run '
-                '`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). There is no CPU fallback.')
-        try:
-            L = ctypes.CDLL(LIB_PATH)
-        except OSError as e:
-            raise RuntimeError(f'cannot load {LIB_PATH}: {e}') from e
-        for name, argtypes in _SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
-        _lib = L
+        _lib = _load(LIB_PATH, _SIGNATURES)
     return _lib
+
+
+_testing_lib = None
+
+
+def testing_lib():
+    """libtdship_testing.so (tools/ and tests/ only; the product never loads it)"""
+    global _testing_lib
+    if _testing_lib is None:
+        _testing_lib = _load(TESTING_LIB_PATH, {**_SIGNATURES, **_TESTING_SIGNATURES})
+    return _testing_lib
+
+
+@contextlib.contextmanager
+def testing():
+    """Route every call of this process through the testing build for the duration of the block (handles created inside must be
+    used and dropped inside: the two libraries are separate images).  Yields the testing library for its hooks."""
+    global _lib
+    saved, _lib = _lib, testing_lib()
+    try:
+        yield _lib
+    finally:
+        _lib = saved
 
 
 def last_error():

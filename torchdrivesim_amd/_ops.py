@@ -3,7 +3,9 @@ Tensor-level entry points of the HIP kernels (device tensors in, device tensors 
 stream through the C ABI of include/tdship.h).  The reference-shaped classes in kinematic.py, infractions.py,
 rendering/ and simulator.py are thin layers over these.
 """
+import collections
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -384,25 +386,35 @@ def offroad(smap, state, lenwid, threshold=0.5, present=None, sc=None):
 # ---------------------------------------------------------------------------------------------------------------
 # K3 rasteriser
 # ---------------------------------------------------------------------------------------------------------------
-#: scratch for the binned fast path of K3, one per (device, cameras, resolution); never carries state between calls
-_workspaces = {}
+#: scratch for the binned fast path of K3, one per (device, stream, cameras, resolution): two renders of one shape on different streams
+#: (or threads) of a device never share it.  Never carries state between calls; the least recently used entries are dropped.
+_workspaces = collections.OrderedDict()
+_WORKSPACES_MAX = 8
 use_workspace = True
 use_bitplanes = True      # test hook: False forces the packed-key kernels
 
 
 def _raster_workspace(dev, n_img, res):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n_img, res)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident(), n_img, res)
     ws = _workspaces.get(key)
     if ws is None:
         n = ctypes.c_int64(0)
         nat.call('tds_raster_scene_workspace_bytes', dev, n_img, res, ctypes.byref(n))
         ws = torch.empty(max(int(n.value), 0), dtype=torch.uint8, device=dev) if n.value > 0 else False
         _workspaces[key] = ws
+        while len(_workspaces) > _WORKSPACES_MAX:
+            _workspaces.popitem(last=False)            # the tensor is freed stream-ordered by the caching allocator
+    else:
+        _workspaces.move_to_end(key)
     return ws if ws is not False else None
 
 
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
 raster_events = None
+#: the same for the launches of the raster backward kernel
+raster_bwd_events = None
+
 
 def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None,
                  extra_tri=None, extra_key=None):
@@ -487,10 +499,17 @@ class _RasterScene(torch.autograd.Function):
         g_cam = torch.empty((B, Nc, 4), dtype=f32, device=dev)
         m8 = mask.contiguous().view(u8) if mask.dtype == torch.bool else _c(mask, u8)
         p = lambda t, d, nme: nat.dev_ptr(_c(t, d), d, nme) if N > 0 else None
+        ev = None
+        if raster_bwd_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(dev))
         nat.call('tds_raster_scene_bwd_f32', dev, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
                  None if N == 0 else nat.dev_ptr(m8, u8, 'mask'), nat.dev_ptr(_c(cam_xy), f32, 'cam_xy'), nat.dev_ptr(_c(cam_sc), f32, 'cam_sc'),
                  nat.dev_ptr(out, f32, 'image'), nat.dev_ptr(gout, f32, 'grad_out'), B, Nc, N, float(2.0 / ctx.fov), int(ctx.res),
                  nat.dev_ptr(g_agent, f32, 'grad_agent'), nat.dev_ptr(g_cam, f32, 'grad_cam'), nat.stream_ptr(dev))
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(dev))
+            raster_bwd_events.append(ev)
         ga = g_agent.sum(dim=1) if N > 0 else None                   # over cameras: (B, N, 4)
         g_state = g_sc = None
         if N > 0:

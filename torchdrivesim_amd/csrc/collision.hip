@@ -445,9 +445,10 @@ TDS_EXPORT int tds_collision_f32(const float *boxes, const float *sc, const uint
     TDS_CHECK_ARG(boxes && sc && present && out, "tds_collision_f32: null pointer");
     TDS_CHECK_ARG(!overlap || N <= 64, "tds_collision_f32: overlap bit masks need N <= 64 (got %lld)", (long long)N);
     TDS_CHECK_ARG(N <= 8192 && B < 65536 * 32768ll, "tds_collision_f32: N=%lld too large", (long long)N);
-    if (metric == TDS_METRIC_IOU && A * N <= 4096) {
-        // whole scene per workgroup: near pairs gathered first (see collision_scene_iou_kernel)
-        const size_t lds_scene = ((size_t)(CBLOCK / 64) * 16 * 64 + (size_t)N * 6 + 2 * (size_t)A * N) * sizeof(float);
+    // whole scene per workgroup: near pairs gathered first (see collision_scene_iou_kernel).  Its LDS footprint grows with N, so scenes
+    // with few exposed agents and many NPCs (A=4, N=1024: 73.7 KB) take the row kernel instead of exceeding the 64 KiB default.
+    const size_t lds_scene = ((size_t)(CBLOCK / 64) * 16 * 64 + (size_t)N * 6 + 2 * (size_t)A * N) * sizeof(float);
+    if (metric == TDS_METRIC_IOU && A * N <= 4096 && lds_scene <= 64 * 1024) {
         hipLaunchKernelGGL(collision_scene_iou_kernel, dim3((unsigned)B), dim3(CBLOCK), lds_scene, (hipStream_t)stream, boxes, sc, present, out,
                            overlap, partner, (int)A, (int)N);
         TDS_LAUNCH_CHECK("collision_scene_iou_kernel");

@@ -14,6 +14,19 @@
 using tds::GridEntry;
 using tds::MapView;
 
+// The ring-walk fallback of K2b can be forced (no nearest-face candidate lists) only in the TESTING build of the library
+// (tds_testing_set_near_lists, include/tdship.h "testing hooks"); the product never reads the environment.
+#ifdef TDS_TESTING
+static int g_near_lists = 1;
+#define TDS_NEAR_LISTS_ENABLED (g_near_lists != 0)
+TDS_EXPORT int tds_testing_set_near_lists(int enabled) {
+    g_near_lists = enabled;
+    return TDS_OK;
+}
+#else
+#define TDS_NEAR_LISTS_ENABLED true
+#endif
+
 
 namespace {
 // Host: nearest-face candidate lists (tds::NearView).  For a cell C (its box grown by a rounding margin) and the reference's distance
@@ -263,7 +276,7 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
     std::vector<int32_t> cand_start;
     std::vector<tds::NearCand> cand;
     std::vector<GridEntry> face_entries;
-    const bool with_near = !face_z && any && F > 0 && nx > 0 && (int64_t)nx * ny <= (int64_t)(1 << 21) && getenv("TDS_NO_NEAR_LISTS") == nullptr;
+    const bool with_near = !face_z && any && F > 0 && nx > 0 && (int64_t)nx * ny <= (int64_t)(1 << 21) && TDS_NEAR_LISTS_ENABLED;
     float near_ox = 0, near_oy = 0;
     int near_nx = 0, near_ny = 0;
     if (with_near) {

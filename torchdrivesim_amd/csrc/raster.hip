@@ -23,6 +23,14 @@
 using tds::GridEntry;
 using tds::MapView;
 
+// Ablation switches, work counters and tuning knobs exist only in the TESTING build of the library (libtdship_testing.so, -DTDS_TESTING:
+// tools/ and tests/); in the product they are compiled out -- TDS_DBG(x) is the constant 0 there.
+#ifdef TDS_TESTING
+#define TDS_DBG(x) (x)
+#else
+#define TDS_DBG(x) 0
+#endif
+
 namespace {
 
 constexpr int RWAVES = 4;
@@ -407,7 +415,7 @@ __device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
         key = w.q[lane]; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
         const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
         r = face_rows(px, py, H, W, X0, TW);
-        if (r.nrows > 0 && !(w.debug & 16)) {
+        if (r.nrows > 0 && !(TDS_DBG(w.debug) & 16)) {
             int i1 = r.imin == 2 ? 0 : r.imin + 1, i2 = r.imin == 0 ? 2 : r.imin - 1;
             a = make_chain(px, py, r.imin, i1, i2);
             b = make_chain(px, py, r.imin, i2, i1);
@@ -470,7 +478,7 @@ __device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
         }
     }
     // ---- outline edges: OpenCV draws Line(v2,v0), Line(v0,v1), Line(v1,v2) before the scan conversion
-    if (!(w.debug & 8)) {
+    if (!(TDS_DBG(w.debug) & 8)) {
 #pragma unroll 1
         for (int l = 0; l < 3; ++l) {
             const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
@@ -707,14 +715,14 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const Comm
     if (a.views != nullptr) st.map = a.views[a.scene_map[img / a.Nc]];
     const MapView &m = st.map;
     const int res = c.res;
-    st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 3 per-camera triangles, 2 static map
+    st.phase = (a.N > 0 && !(TDS_DBG(c.debug) & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 3 per-camera triangles, 2 static map
     if constexpr (has_extras<SA>::value) { if (st.phase == 2 && a.K > 0) st.phase = 3; }
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
     st.have = false; st.cur_top = false; st.cur_i = -1; st.cur_fe = 0; st.cur_pw = SCAN_EMPTY_ROW;
     st.pu0 = st.pu1 = make_uint4(0, 0, 0, 0);
-    if (m.nx > 0 && !(c.debug & 1)) {
+    if (m.nx > 0 && !(TDS_DBG(c.debug) & 1)) {
         // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell rectangle
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
         const float half = (float)res / 2.0f;
@@ -899,7 +907,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_kernel(SceneArgsEx a, 
         if (!more) break;
     }
     __syncthreads();
-    if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+    if (!(TDS_DBG(c.debug) & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
 // ---- fast path: two kernels ---------------------------------------------------------------------------------
@@ -983,7 +991,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_scene_list_kernel(SceneArgsE
         }
     }
     __syncthreads();
-    if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+    if (!(TDS_DBG(c.debug) & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
 // =========================================================================================================
@@ -1262,10 +1270,15 @@ __device__ __forceinline__ int chain_x32(int xs1, int dx1, int ysw, int xs2, int
 //            c2 = 2 |dy| - dx - (sgn < 0).
 // Both are floor((N0 + tau * 2 dx) / D): stepping tau adds divmod(2 dx, D) = (ia, ib) to (quotient, remainder) with one carry.
 // (checked exhaustively against the iterative walk in tests/test_oracle_fill.py::test_line_rows_closed_form)
-// optional work counters (profiling hook tds_raster_get_stats; active with debug flag 128)
+// optional work counters (profiling hook tds_raster_get_stats of the testing build; active with debug flag 128)
+#ifdef TDS_TESTING
 __device__ unsigned long long g_stats[16];
 #define TDS_STAT_LANES(W, I, V) do { if ((W).debug & 128) { const unsigned long long v_ = (unsigned long long)(V); if (v_) atomicAdd(&g_stats[I], v_); } } while (0)
 #define TDS_STAT(W, I, V) do { if (((W).debug & 128) && (W).lane == 0) atomicAdd(&g_stats[I], (unsigned long long)(V)); } while (0)
+#else
+#define TDS_STAT_LANES(W, I, V) do { } while (0)
+#define TDS_STAT(W, I, V) do { } while (0)
+#endif
 #ifndef TDS_FCHUNK
 #define TDS_FCHUNK 4
 #endif
@@ -1301,7 +1314,7 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     }
     TDS_STAT(w, 0, 1); TDS_STAT(w, 1, n);
     // ---- scan-converted rows ----
-    if (!(w.debug & 16)) {
+    if (!(TDS_DBG(w.debug) & 16)) {
         const int nch = (r.nrows + CHUNK - 1) / CHUNK;
         const int incl = wave_scan_add(nch), excl = incl - nch;
         const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -1344,7 +1357,7 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     // ---- outline edges ----
     // The edges to draw go through a per-wave ring of EQCAP entries (two packed end points + plane index) that lives across
     // batches: 64 of them are taken at a time, so that the per-edge set-up and the row items below run on full waves.
-    if (!(w.debug & 8)) {
+    if (!(TDS_DBG(w.debug) & 8)) {
         TDS_STAT(w, 5, __popcll(__ballot(lane < n && (em & 1))) + __popcll(__ballot(lane < n && (em & 2))) + __popcll(__ballot(lane < n && (em & 4))));
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
@@ -1683,7 +1696,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
-    if (!(c.debug & 4)) write_out_bits<BBLOCK, NB, OutT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
+    if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
 }
 
 inline int bits_index_bits(int K) { return K <= 3 ? 2 : (K <= 7 ? 3 : 4); }
@@ -1731,7 +1744,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_mesh_kernel(MeshArgs a, Comm
         if (!more) break;
     }
     __syncthreads();
-    if (!(c.debug & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
+    if (!(TDS_DBG(c.debug) & 4)) write_out<TW, OutT>(tile, (OutT *)c.out, img, res, X0, tid);
 }
 
 inline size_t lds_bytes(int tw, int res) { return ((size_t)tw * res + (size_t)RWAVES * WAVE_LDS_DW) * sizeof(uint32_t); }
@@ -1747,25 +1760,29 @@ inline int pick_tw(int res) {
 }
 
 int g_force_tw = 0;
+#ifdef TDS_TESTING
 int g_debug = 0;
+#endif
 
 }  // namespace
 
-// test/benchmark hook: force the strip width (0 = automatic)
+#ifdef TDS_TESTING
+// ---- testing build only (include/tdship.h, section "testing hooks"): absent from libtdship.so --------------------------------
+// force the strip width (0 = automatic)
 TDS_EXPORT int tds_raster_set_strip_width(int tw) {
     TDS_CHECK_ARG(tw == 0 || tw == 8 || tw == 16 || tw == 32 || tw == 64 || tw == 96 || tw == 128, "strip width must be 0, 8, 16, 32, 64, 96 or 128");
     g_force_tw = tw;
     return TDS_OK;
 }
 
-// tuning hook (not part of include/tdship.h): waves per workgroup of the bit-plane kernel (4 or 8)
+// waves per workgroup of the bit-plane kernel (4 or 8)
 TDS_EXPORT int tds_raster_set_bits_waves(int n) {
     TDS_CHECK_ARG(n == 4 || n == 8, "waves per workgroup must be 4 or 8");
     g_bits_waves = n;
     return TDS_OK;
 }
 
-// profiling hook (not part of include/tdship.h): read and reset the work counters of the bit-plane kernel (debug flag 128)
+// read and reset the work counters of the bit-plane kernel (debug flag 128)
 TDS_EXPORT int tds_raster_get_stats(unsigned long long *out16) {
     TDS_CHECK_ARG(out16, "tds_raster_get_stats: null output");
     unsigned long long zero[16] = {0};
@@ -1774,11 +1791,12 @@ TDS_EXPORT int tds_raster_get_stats(unsigned long long *out16) {
     return TDS_OK;
 }
 
-// profiling hook (not part of include/tdship.h): ablation switches, see CommonArgs::debug
+// ablation switches, see CommonArgs::debug
 TDS_EXPORT int tds_raster_set_debug(int flags) {
     g_debug = flags;
     return TDS_OK;
 }
+#endif  // TDS_TESTING
 
 #define TDS_LAUNCH_RASTER(KERNEL, ARGS)                                                                                        \
     do {                                                                                                                       \
@@ -1887,9 +1905,9 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     a.extra_tri = extra_tri; a.extra_key = extra_key; a.K = (int)n_extra;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = TDS_DBG(g_debug);
     // fastest path: bit planes, when the scene uses at most MAX_KEYS distinct keys and the caller listed the actors' keys
-    if (((N == 0 && n_extra == 0) || (actor_keys && n_actor_keys > 0)) && ms.n_uniq >= 0 && !(g_debug & 64)) {
+    if (((N == 0 && n_extra == 0) || (actor_keys && n_actor_keys > 0)) && ms.n_uniq >= 0 && !(TDS_DBG(g_debug) & 64)) {
         KeyTable kt;
         kt.n = 0;
         bool ok = true;
@@ -1938,7 +1956,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
         }
     }
     // general path: bin once per camera (K3a), then rasterise per strip from the lists (K3b)
-    if (workspace && !(g_debug & 32) && cm.strips <= MAX_STRIPS) {
+    if (workspace && !(TDS_DBG(g_debug) & 32) && cm.strips <= MAX_STRIPS) {
         int64_t caps = (workspace_bytes / (n_img * cm.strips) - (int64_t)sizeof(uint32_t)) / (int64_t)sizeof(uint4);
         if (caps > 4096) caps = 4096;
         if (caps >= 64) {
@@ -1990,7 +2008,7 @@ TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int
     for (int i = 1; i < n_levels; ++i) TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_raster_mesh: levels must be strictly descending");
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = g_debug;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = TDS_DBG(g_debug);
     TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
     TDS_LAUNCH_CHECK("raster_mesh_kernel");
     return TDS_OK;

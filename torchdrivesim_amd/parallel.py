@@ -55,6 +55,17 @@ def sum_over_ranks(value: float, device='cpu') -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, device='cpu'):
+    """list of every rank's value, in rank order (one element without a process group)"""
+    d = _dist()
+    if d is None:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(d.get_world_size())]
+    d.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def aggregate_throughput(units_this_rank: float, elapsed_this_rank: float, device='cpu') -> float:
     """whole-job rate = units processed by all ranks / slowest rank's time"""
     return sum_over_ranks(units_this_rank, device) / max_over_ranks(elapsed_this_rank, device)

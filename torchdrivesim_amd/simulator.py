@@ -449,16 +449,18 @@ class Simulator:
 
     def _heading_sc(self) -> Tensor:
         """[sin psi, cos psi] of ALL agents, computed once per state tensor and shared by render / collision / off-road (each of them
-        would otherwise launch its own sin and cos).  Not cached when gradients are being recorded."""
+        would otherwise launch its own sin and cos).  Not cached when gradients are being recorded.  The cache is keyed on the
+        IDENTITY of the state tensor (which it keeps alive, so the allocator cannot hand its block to a later state) and on its
+        version counter; a kinematic model whose get_state() builds a fresh tensor per call (CompoundKinematicModel) or a scene
+        with NPCs (torch.cat per call) therefore never hits it."""
         state = self.get_all_agent_state()
         if state.requires_grad and torch.is_grad_enabled():
             return _ops.heading_sc(state[..., 2])
-        key = (state.data_ptr(), state._version, tuple(state.shape), str(state.device)) if self.npc_count == 0 else None
         cached = getattr(self, '_sc_cache', None)
-        if key is not None and cached is not None and cached[0] == key:
-            return cached[1]
+        if cached is not None and cached[0] is state and cached[1] == state._version:
+            return cached[2]
         sc = _ops.heading_sc(state[..., 2].detach())
-        self._sc_cache = (key, sc)
+        self._sc_cache = (state, state._version, sc)
         return sc
 
     def get_all_agent_size(self) -> Tensor:
@@ -585,11 +587,19 @@ class Simulator:
         """Static maps (one per distinct road mesh in the batch), actor templates and packed actor keys; rebuilt after
         `to` / `extend` / `select_batch_elements` or when sizes / types tensors are replaced."""
         gen = self.birdview_mesh_generator
+        # stamped on the IDENTITY (and version) of the long-lived tensors the cache is derived from -- not on the torch.cat temporaries
+        # of get_all_agent_size() / get_all_agent_type(), whose addresses depend on the allocator.  The cache keeps the sources alive.
+        sources = [self.agent_size, self.agent_type, gen.background_mesh.verts, gen.background_mesh.faces, gen.background_mesh.attrs]
+        if self.npc_count > 0:
+            sources += [self.get_npc_size(), self.get_npc_types()]
+        for v in (self.traffic_controls or {}).values():
+            sources += [v.pos, v.mask]
+        extra = (self.batch_size, self.npc_count, tuple((self.traffic_controls or {}).keys()))
+        c = self._scene_cache
+        if c is not None and c['extra'] == extra and len(c['sources']) == len(sources) and \
+                all(a is b and a._version == ver for a, b, ver in zip(sources, c['sources'], c['versions'])):
+            return c
         sizes, types = self.get_all_agent_size(), self.get_all_agent_type()
-        stamp = (sizes.data_ptr(), tuple(sizes.shape), types.data_ptr(), gen.background_mesh.verts.data_ptr(), str(sizes.device), self.batch_size,
-                 tuple((k, v.pos.data_ptr(), v.mask.data_ptr()) for k, v in (self.traffic_controls or {}).items()))
-        if self._scene_cache is not None and self._scene_cache['stamp'] == stamp:
-            return self._scene_cache
         if not isinstance(self.renderer, HipRenderer):
             raise RuntimeError(f'{type(self.renderer).__name__} cannot take the fused scene path; use HipRenderer')
         dev = sizes.device
@@ -649,7 +659,7 @@ class Simulator:
             ctrl = dict(kinds=ctrl_kinds, state=torch.cat(st_q, dim=1).contiguous(), tmpl=torch.cat(tm_q, dim=1).contiguous(), key_lut=static_keys)
             for i in range(len(maps)):
                 key_tables[i] = sorted(set(key_tables[i]) | {int(v) for per_map in static_keys for v in per_map[i].tolist()})
-        self._scene_cache = dict(stamp=stamp, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables, ctrl=ctrl, wp_keys=wp_keys)
+        self._scene_cache = dict(sources=sources, versions=[t._version for t in sources], extra=extra, maps=maps, tmpl=tmpl, keys=keys, key_tables=key_tables, ctrl=ctrl, wp_keys=wp_keys)
         return self._scene_cache
 
     def _waypoint_triangles(self, waypoints: Tensor, rendering_mask: Optional[Tensor]):
