@@ -89,6 +89,12 @@ int tds_collision_f32(const float *boxes, const float *sc, const uint8_t *presen
 int tds_collision_bwd_f32(const float *boxes, const float *sc, const uint8_t *present, const float *grad_out,
                           float *grad_boxes, float *grad_sc, int64_t B, int64_t A, int64_t N, int metric, void *stream);
 
+/* The `nograd` metric (simulator.py:1111-1149 -> infractions.py:352-375, 429-500; the reference asks shapely for
+ * `intersection(...).area != 0` pair by pair on the host): out B x A float64 = number of OTHER present agents whose rectangle shares
+ * area with agent i's, 0 for an absent agent.  boxes B x A x 5, sc B x A x 2 = [sin psi, cos psi], present B x A uint8.  Corners as
+ * infractions.rectangle_vertices in float32; the predicate (no separating edge line, touching does not count) in float64. */
+int tds_overlap_count_f32(const float *boxes, const float *sc, const uint8_t *present, double *out, int64_t B, int64_t A, void *stream);
+
 /* iou_differentiable (infractions.py:307-324) / collision_detection_with_discs (:503-545), element-wise over n pairs.
  * box1, box2: n x 5; sc1, sc2: n x 2 as above. */
 int tds_pairwise_overlap_f32(const float *box1, const float *sc1, const float *box2, const float *sc2, float *out,

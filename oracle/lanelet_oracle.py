@@ -13,10 +13,14 @@ is a pip dependency of the reference (CI_cpu.yml:34, unpinned), not installed he
     lanelet2.geometry.project(linestring, p)             closest point of the line, 3-D
     lanelet.centerline                                   lanelet2_core Lanelet.cpp calculateCenterline (pure Python loops here)
 
+The oracle also reads maps BY ITSELF (`load_osm`: XML, transverse Mercator in complex arithmetic, bound alignment, outline polygons, its
+own centre lines) so that a comparison with the product shares neither the product's reader nor its centre-line code.
+
 Pinning: the known answers of the reference's own tests for this path (tests/simulator/test_util.py:17-44: direction pi/4 on the
 line (0,0)-(1,1)-(2,1); losses [[0,1],[0,1]] for the two-agent scene, all zeros once the lanelet is tagged `parking`) --
 tests/test_lanelet2.py.  Everything else about this path is PARITY UNPINNED (no Lanelet2 here to generate vectors with).
 """
+import cmath
 import math
 
 import numpy as np
@@ -208,6 +212,135 @@ def find_lanelet_directions(lanelets, centerlines, x, y, tags_to_exclude=(), tol
     return directions
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# the oracle's own lane table: OSM file -> lanelets.  Independent of torchdrivesim_amd/lanelet2.py (no import, different code);
+# both restate lanelet2_io's OsmHandlerLoad + lanelet2_projection's UtmProjector [UNVERIFIED-UPSTREAM], and the product's reader is
+# separately pinned against the mesh the reference ships (tests/test_lanelet2.py).
+# ------------------------------------------------------------------------------------------------------------------------
+class OracleLanelet:
+    """left / right bound (k,3) float64 in travel order + OSM tags"""
+
+    def __init__(self, ident, left, right, attributes=None):
+        self.id = ident
+        self.left = np.asarray(left, np.float64).reshape(-1, 3)
+        self.right = np.asarray(right, np.float64).reshape(-1, 3)
+        self.attributes = dict(attributes or {})
+
+    def polygon2d(self):
+        """Lanelet::polygon2d: the left bound, then the right bound backwards"""
+        return np.concatenate([self.left[:, :2], self.right[::-1, :2]], 0)
+
+
+class _LazyCenterlines(dict):
+    """id(lanelet) -> centre line, computed when first asked for (the pure-Python construction takes 70 ms per lanelet)"""
+
+    def __init__(self, lanelets, fn):
+        super().__init__()
+        self._by_id, self._fn = {id(l): l for l in lanelets}, fn
+
+    def __missing__(self, key):
+        l = self._by_id[key]
+        self[key] = self._fn(l.left, l.right)
+        return self[key]
+
+
+class OracleMap:
+    def __init__(self, lanelets):
+        self.laneletLayer = list(lanelets)
+        self._centerlines = None
+
+    def centerlines(self, centerline_fn=None):
+        if centerline_fn is not None:
+            return _LazyCenterlines(self.laneletLayer, centerline_fn)
+        if self._centerlines is None:
+            self._centerlines = _LazyCenterlines(self.laneletLayer, calculate_centerline)
+        return self._centerlines
+
+
+def transverse_mercator(lat_deg, lon_deg, lon0_deg):
+    """(easting - 500 km, northing) / metres of a WGS84 position on the central meridian lon0: Krueger's series in the complex
+    form  zeta = zeta' + sum_j alpha_j sin(2 j zeta'),  zeta' = xi' + i eta',  alpha_j to n^6 (Karney 2011, eq. 35; the series
+    GeographicLib::TransverseMercator evaluates)."""
+    a, f, k0 = 6378137.0, 1.0 / 298.257223563, 0.9996
+    n = f / (2.0 - f)
+    e = math.sqrt(f * (2.0 - f))
+    A = a / (1.0 + n) * (1.0 + n ** 2 / 4.0 + n ** 4 / 64.0 + n ** 6 / 256.0)
+    alpha = (n * (1 / 2 + n * (-2 / 3 + n * (5 / 16 + n * (41 / 180 + n * (-127 / 288 + n * 7891 / 37800))))),
+             n ** 2 * (13 / 48 + n * (-3 / 5 + n * (557 / 1440 + n * (281 / 630 - n * 1983433 / 1935360)))),
+             n ** 3 * (61 / 240 + n * (-103 / 140 + n * (15061 / 26880 + n * 167603 / 181440))),
+             n ** 4 * (49561 / 161280 + n * (-179 / 168 + n * 6601661 / 7257600)),
+             n ** 5 * (34729 / 80640 - n * 3418889 / 1995840),
+             n ** 6 * 212378941 / 319334400)
+    phi, lam = math.radians(lat_deg), math.radians(lon_deg - lon0_deg)
+    tau = math.tan(phi)
+    sigma = math.sinh(e * math.atanh(e * tau / math.sqrt(1.0 + tau * tau)))
+    tau_p = tau * math.sqrt(1.0 + sigma * sigma) - sigma * math.sqrt(1.0 + tau * tau)
+    zeta_p = complex(math.atan2(tau_p, math.cos(lam)), math.asinh(math.sin(lam) / math.hypot(tau_p, math.cos(lam))))
+    zeta = zeta_p
+    for j, al in enumerate(alpha, 1):
+        zeta += al * cmath.sin(2 * j * zeta_p)
+    return k0 * A * zeta.imag, k0 * A * zeta.real
+
+
+def _utm_zone(lat, lon):
+    lon_i = int(math.floor(lon))
+    lon_i = lon_i - 360 if lon_i >= 180 else (lon_i + 360 if lon_i < -180 else lon_i)
+    zone = (lon_i + 186) // 6
+    band = max(-10, min(9, (int(math.floor(lat)) + 80) // 8 - 10))
+    if band == 7 and zone == 31 and lon_i >= 3:
+        return 32                                                              # south-west Norway
+    if band == 9 and 0 <= lon_i < 42:
+        return 2 * ((lon_i + 183) // 12) + 1                                   # Svalbard
+    return zone
+
+
+def _side(line, p):
+    """> 0: p on the left of the poly-line, < 0: on its right, judged at the closest segment"""
+    best, side = float('inf'), 0.0
+    for (ax, ay), (bx, by) in zip(line[:-1, :2], line[1:, :2]):
+        dx, dy = bx - ax, by - ay
+        l2 = dx * dx + dy * dy
+        t = 0.0 if l2 == 0 else min(1.0, max(0.0, ((p[0] - ax) * dx + (p[1] - ay) * dy) / l2))
+        d2 = (ax + t * dx - p[0]) ** 2 + (ay + t * dy - p[1]) ** 2
+        if d2 < best:
+            best, side = d2, dx * (p[1] - ay) - dy * (p[0] - ax)
+    return side
+
+
+def load_osm(path, origin=(0.0, 0.0), align=True):
+    """lanelet2.io.load(path, UtmProjector(Origin(*origin))) restricted to what the wrong-way query reads: the lanelets' bounds in the
+    UTM zone of the origin, relative to the origin, each bound turned so that the right one lies on the right of the left one
+    (OsmHandlerLoad alignLaneletBorders; align=False keeps the file's order)."""
+    import gzip
+    import xml.etree.ElementTree as ET
+    with (gzip.open if path.endswith('.gz') else open)(path, 'rb') as f:
+        osm = ET.parse(f).getroot()
+    lon0 = 6.0 * _utm_zone(*origin) - 183.0
+    e0, n0 = transverse_mercator(origin[0], origin[1], lon0)
+    node = {}
+    for nd in osm.findall('node'):
+        ele = [float(t.get('v')) for t in nd.findall('tag') if t.get('k') == 'ele']
+        e, n = transverse_mercator(float(nd.get('lat')), float(nd.get('lon')), lon0)
+        node[nd.get('id')] = (e - e0, n - n0, ele[-1] if ele else 0.0)
+    way = {w.get('id'): np.array([node[r.get('ref')] for r in w.findall('nd')], np.float64).reshape(-1, 3) for w in osm.findall('way')}
+    out = []
+    for rel in osm.findall('relation'):
+        tags = {t.get('k'): t.get('v') for t in rel.findall('tag')}
+        if tags.get('type') != 'lanelet':
+            continue
+        side = {m.get('role'): way[m.get('ref')] for m in rel.findall('member') if m.get('type') == 'way' and m.get('role') in ('left', 'right')}
+        if len(side) != 2:
+            continue
+        left, right = side['left'], side['right']
+        if align and len(left) > 1 and len(right) > 1:
+            # the right bound must begin on the right of the left bound, and the left bound on the left of the right bound
+            flip_left, flip_right = _side(left, right[0]) > 0, _side(right, left[0]) < 0
+            left = left[::-1].copy() if flip_left else left
+            right = right[::-1].copy() if flip_right else right
+        out.append(OracleLanelet(int(rel.get('id')), left, right, tags))
+    return OracleMap(out)
+
+
 def lanelet_orientation_loss(lanelet_maps, agents_state, recenter_offset=None, thr=math.pi / 2, tol=1.0, centerline_fn=None,
                              tags_to_exclude=('parking',)):
     """infractions.py:232-304.  lanelet_maps: list of B objects with `.laneletLayer` (or None); agents_state (B,A,4) float32.
@@ -220,7 +353,10 @@ def lanelet_orientation_loss(lanelet_maps, agents_state, recenter_offset=None, t
         if m is None:
             continue
         if id(m) not in cache:
-            cache[id(m)] = {id(l): centerline_fn(l.left, l.right) for l in m.laneletLayer}
+            if isinstance(m, OracleMap):
+                cache[id(m)] = m.centerlines(None if centerline_fn is calculate_centerline else centerline_fn)
+            else:
+                cache[id(m)] = {id(l): centerline_fn(l.left, l.right) for l in m.laneletLayer}
         cls = cache[id(m)]
         for a in range(agents_state.shape[1]):
             x, y, psi = f32(agents_state[b, a, 0]), f32(agents_state[b, a, 1]), f32(agents_state[b, a, 2])

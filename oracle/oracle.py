@@ -94,6 +94,22 @@ def bicycle_fit_action(future, current, dt=0.1, max_acc=MAX_ACC, max_steer=MAX_S
     return out
 
 
+def bicycle_by_displacement_step(state, action, lr, dt=None, model_dt=0.1, max_dx=20.0, oriented=False):
+    """BicycleByDisplacement / BicycleByOrientedDisplacement.step (kinematic.py:526-587): the displacement action becomes a target
+    position, KinematicBicycle.fit_action (made with the model's own dt, :556) turns it into a bicycle action, KinematicBicycle.step
+    applies it with `dt`.  float32 throughout, the reference's operation order."""
+    state, action, lr = _f(state), _f(action), _f(lr)
+    dt = model_dt if dt is None else dt
+    xy = action * np.float32(max_dx)
+    if oriented:                                   # utils.rotate: [[c, -s], [s, c]] @ v, products rounded separately
+        c, s_ = np.cos(state[..., 2]), np.sin(state[..., 2])
+        xy = np.stack([c * xy[..., 0] + (-s_) * xy[..., 1], s_ * xy[..., 0] + c * xy[..., 1]], -1).astype(np.float32)
+    target = state.copy()
+    target[..., 0] = state[..., 0] + xy[..., 0] * np.float32(dt)
+    target[..., 1] = state[..., 1] + xy[..., 1] * np.float32(dt)
+    return bicycle_step(state, bicycle_fit_action(target, state, dt=model_dt), lr, dt=dt)
+
+
 def box2corners(box5, sc=None):
     box5, sc = _f(box5), _f(sc)
     out = np.empty(box5.shape[:-1] + (4, 2), dtype=np.float32)

@@ -492,7 +492,14 @@ static void transform_pt(float px, float py, float s, float c, float x, float y,
     *oy = (s * px + c * py) + y;
 }
 
-/* ---- OpenCV restatement (PARITY UNPINNED, see header) ---- */
+/* ---- OpenCV restatement (PARITY UNPINNED, see header) ----
+ * clip_line, orc_line and orc_fill_convex_poly below follow, step by step, cv::clipLine, cv::Line / LineIterator and
+ * cv::FillConvexPoly of OpenCV's modules/imgproc/src/drawing.cpp.  OpenCV is Copyright (C) 2000-2024 the OpenCV team and its
+ * contributors (Intel Corporation, Willow Garage Inc., NVIDIA Corporation, Advanced Micro Devices Inc., OpenCV Foundation, Itseez
+ * Inc., Xperience AI, Shenzhen Institute of Artificial Intelligence and Robotics for Society) and is distributed under the Apache
+ * License 2.0 (OpenCV 4.5.0 and later; the 3-clause BSD licence before that): https://opencv.org/license/.  This derived
+ * restatement is used as a test oracle only and is offered under the same terms.
+ * The live check against the real library is oracle/opencv_check.py (runs wherever `cv2` imports). */
 typedef struct { float *img; int W, H; } orc_img;      /* raw OpenCV image: img[(y*W + x)*3 + ch] */
 
 static void put_px(orc_img *im, int x, int y, const float *col) {

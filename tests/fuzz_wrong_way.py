@@ -18,13 +18,14 @@ worst, total, t0 = 0.0, 0, time.time()
 for town in ('carla_Town01', 'carla_Town02'):
     for align in (True, False):
         lanes = L.load_lanelet_map(os.path.join(ROOT, 'tests', 'golden', town + '.osm.gz'), origin=(0.0, 0.0), align_borders=align)
+        own = lo.load_osm(os.path.join(ROOT, 'tests', 'golden', town + '.osm.gz'), origin=(0.0, 0.0), align=align)     # the oracle's own reading and centre lines
         cl = np.concatenate([l.centerline for l in lanes.laneletLayer])
         for k, (tol, thr) in enumerate(((1.0, np.pi / 2), (0.0, np.pi / 2), (0.25, 2.2), (2.5, np.pi / 2))):
             g = np.random.default_rng(hash((town, align, k)) % 2 ** 32)
             n = a.agents
             xy = cl[g.integers(0, len(cl), n), :2] + g.normal(0, 2.0, (n, 2)) * g.choice([0.05, 1.0, 3.0], (n, 1))
             state = np.concatenate([xy, g.uniform(-np.pi, np.pi, (n, 1)), np.ones((n, 1))], -1).astype(np.float32)[None]
-            ref = lo.lanelet_orientation_loss([lanes], state, None, thr, tol, centerline_fn=L.calculate_centerline)
+            ref = lo.lanelet_orientation_loss([own], state, None, thr, tol)
             out = lanelet_orientation_loss([lanes], torch.from_numpy(state).to(dev), direction_angle_threshold=thr, lanelet_dist_tolerance=tol).cpu().numpy()
             err = float(np.abs(out - ref).max())
             worst, total = max(worst, err), total + n

@@ -56,44 +56,6 @@ def test_compute_collision_matches_reference(metric):
     np.testing.assert_allclose(out, g['coll_npc_' + metric], atol=2e-6, rtol=0)
 
 
-def test_nograd_counts_overlapping_present_agents():
-    from torchdrivesim_amd.mesh import BirdviewMesh
-    from torchdrivesim_amd.simulator import CollisionMetric
-    state = np.array([[[0, 0, 0, 0], [2, 0, 0, 0], [30, 30, 0, 0], [1, 0.5, 0.5, 0], [4, 0, 0, 0]]], np.float32)
-    size = np.tile(np.array([4.0, 2.0], np.float32), (1, 5, 1))
-    present = np.array([[True, True, True, False, True]])
-    sim = make_sim(state, size, present, BirdviewMesh.empty(batch_size=1).to(DEV))
-    sim.cfg.collision_metric = CollisionMetric.nograd
-    # 0-1 overlap, 1-4 overlap, 0-4 only touch (no area), 3 is absent, 2 is far away
-    assert sim.compute_collision().cpu().tolist() == [[1.0, 2.0, 0.0, 0.0, 1.0]]
-
-
-def test_nograd_beyond_64_agents_equals_the_bit_mask_path():
-    from torchdrivesim_amd.mesh import BirdviewMesh
-    from torchdrivesim_amd.simulator import CollisionMetric
-    g = np.random.default_rng(21)
-    B, A = 3, 96
-    state = np.concatenate([g.uniform(-25, 25, (B, A, 2)), g.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
-    size = (np.array([4.5, 2.0]) * g.uniform(0.9, 1.1, (B, A, 2))).astype(np.float32)
-    present = g.uniform(size=(B, A)) < 0.85
-    present[:, 64:] = False                                       # the extra agents are absent: the first 64 must count as if alone
-    road = BirdviewMesh.empty(batch_size=B).to(DEV)
-    big = make_sim(state, size, present, road)
-    small = make_sim(state[:, :64], size[:, :64], present[:, :64], road)
-    big.cfg.collision_metric = small.cfg.collision_metric = CollisionMetric.nograd
-    a, b = big.compute_collision().cpu().numpy(), small.compute_collision().cpu().numpy()
-    assert a.dtype == np.float64 and a.shape == (B, A)
-    np.testing.assert_array_equal(a[:, :64], b)
-    assert not a[:, 64:].any() and b.sum() > 10
-    present[:, 64:] = True                                        # now they count: compare with the IoU metric's own overlaps
-    big = make_sim(state, size, present, road)
-    big.cfg.collision_metric = CollisionMetric.nograd
-    cnt = big.compute_collision().cpu().numpy()
-    big.cfg.collision_metric = CollisionMetric.iou
-    iou = big.compute_collision().cpu().numpy()
-    np.testing.assert_array_equal(cnt > 0, (iou > 1e-7) & present)
-
-
 def test_compute_offroad_matches_reference():
     from torchdrivesim_amd.mesh import BaseMesh
     g = load_golden('g3_offroad.npz')

@@ -46,6 +46,18 @@ def test_kinematics_match_reference(oracle):
     assert np.abs(oracle.bicycle_fit_action(g['future'], s, left_handed=True) - g['fit_bicycle_lh']).max() <= 1e-5
 
 
+def test_bicycle_by_displacement_matches_reference(oracle):
+    """G1b: BicycleByDisplacement / BicycleByOrientedDisplacement (kinematic.py:526-587) = fit_action then step"""
+    g = load_golden('g1b_bicycle_displacement.npz')
+    rel = lambda a, b: np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3))
+    s, a, lr = g['state'], g['action'], g['lr']
+    for name, kw in (('disp', {}), ('disp_max5', dict(max_dx=5.0, model_dt=0.2)), ('oriented', dict(oriented=True))):
+        one = oracle.bicycle_by_displacement_step(s, a, lr, **kw)
+        assert rel(one, g[f'out_{name}']) <= 2e-6, name
+        two = oracle.bicycle_by_displacement_step(one, a[:, ::-1], lr, dt=0.05, **kw)          # dt of the step differs from the model's
+        assert rel(two, g[f'out_{name}_2steps']) <= 2e-6, name
+
+
 def test_bicycle_known_answer(oracle):
     # SURVEY 8c G1 known answer, kinematic.py:462-477
     out = oracle.bicycle_step(np.array([[[1, 2, 0.5, 3]]]), np.array([[[0.4, -0.2]]]), np.array([[1.5]]))

@@ -161,6 +161,33 @@ def gen_kinematic(out):
     print('g1', {k: v.shape for k, v in d.items()})
 
 
+def gen_kinematic_displacement(out):
+    """G1b: BicycleByDisplacement / BicycleByOrientedDisplacement (kinematic.py:526-587), a file of its own so that g1_kinematic.npz keeps its bytes"""
+    from torchdrivesim.kinematic import BicycleByDisplacement, BicycleByOrientedDisplacement
+    g = seeded(131)
+    B, A = 3, 7
+    state = torch.stack([(torch.rand(B, A, generator=g) - 0.5) * 600, (torch.rand(B, A, generator=g) - 0.5) * 600,
+                         (torch.rand(B, A, generator=g) - 0.5) * 4 * math.pi, (torch.rand(B, A, generator=g) - 0.3) * 20], dim=-1)
+    action = (torch.rand(B, A, 2, generator=g) - 0.5) * 2
+    action[0, 0] = 0.0                                                   # no displacement: the sign(abs(v)) == 0 branch of the fitted steering
+    lr = 1.0 + torch.rand(B, A, generator=g)
+    future = state + torch.stack([(torch.rand(B, A, generator=g) - 0.5) * 3, (torch.rand(B, A, generator=g) - 0.5) * 3,
+                                  (torch.rand(B, A, generator=g) - 0.5) * 0.4, (torch.rand(B, A, generator=g) - 0.5) * 2], dim=-1)
+    d = dict(state=npy(state), action=npy(action), lr=npy(lr), future=npy(future))
+    for name, cls, kw in (('disp', BicycleByDisplacement, {}), ('disp_max5', BicycleByDisplacement, dict(max_dx=5, dt=0.2)),
+                          ('oriented', BicycleByOrientedDisplacement, {})):
+        m = cls(**kw)
+        m.set_params(lr=lr.clone())
+        m.set_state(state.clone())
+        d[f'fit_{name}'] = npy(m.fit_action(future.clone()))
+        m.step(action.clone())
+        d[f'out_{name}'] = npy(m.get_state())
+        m.step(action.flip(1).clone(), dt=0.05)
+        d[f'out_{name}_2steps'] = npy(m.get_state())
+    np.savez_compressed(os.path.join(out, 'g1b_bicycle_displacement.npz'), **d)
+    print('g1b', {k: v.shape for k, v in d.items()})
+
+
 # --------------------------------------------------------------------------------------
 # G2 boxes / IoU / discs / collision
 # --------------------------------------------------------------------------------------
@@ -834,6 +861,9 @@ def main():
     if args.only == 'traffic_lights':
         gen_traffic_lights(args.out)
         return
+    if args.only == 'displacement':
+        gen_kinematic_displacement(args.out)
+        return
     if args.only == 'waypoints':
         gen_waypoints(args.out, cv2, load_town01())
         return
@@ -850,6 +880,7 @@ def main():
     gen_traffic_lights(args.out)
     gen_discs_n(args.out)
     gen_noisy_perception(args.out, cv2, town)
+    gen_kinematic_displacement(args.out)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')

@@ -36,6 +36,7 @@ _SIGNATURES = {
     'tds_unicycle_step_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
     'tds_collision_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     'tds_collision_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    'tds_overlap_count_f32': [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     'tds_pairwise_overlap_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     'tds_pairwise_discs_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     'tds_box2corners_f32': [_vp, _vp, _vp, _i64, _vp],

@@ -150,6 +150,19 @@ def collision_forward(boxes, sc, present, n_exposed, metric, want_overlap=False,
     return out, overlap, partner
 
 
+def overlap_count(boxes, present, sc=None):
+    """The `nograd` collision metric (simulator.py:1111-1149, infractions.py:352-375): boxes (B,A,5), present (B,A) -> (B,A) float64,
+    the number of other present agents whose rectangle shares area with the agent's.  NaNs are scrubbed to 0 first."""
+    boxes = torch.nan_to_num(_c(boxes.detach()), nan=0.0)
+    sc = heading_sc(boxes[..., 4]) if sc is None else _c(sc)
+    present = _c(present, u8) if present.dtype != torch.bool else present.contiguous().view(u8)
+    B, A = boxes.shape[:2]
+    out = torch.empty((B, A), dtype=torch.float64, device=boxes.device)
+    nat.call('tds_overlap_count_f32', boxes.device, nat.dev_ptr(boxes, f32, 'boxes'), nat.dev_ptr(sc, f32, 'sc'), nat.dev_ptr(present, u8, 'present'),
+             nat.dev_ptr(out, torch.float64, 'out'), B, A, nat.stream_ptr(boxes.device))
+    return out
+
+
 class _Collision(torch.autograd.Function):
     @staticmethod
     def forward(ctx, boxes, sc, present, n_exposed, metric):

@@ -3,6 +3,7 @@
 // Reference: simulator.py:1064-1109,1161-1194; _iou_utils.py:42-367; infractions.py:378-426,503-545.
 // Compute bound (~2k VALU ops per surviving pair, 16 IEEE divisions); bytes are negligible (20 B/agent).
 #include "tds_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -464,6 +465,94 @@ TDS_EXPORT int tds_collision_f32(const float *boxes, const float *sc, const uint
         hipLaunchKernelGGL(collision_kernel<TDS_METRIC_DISCS>, grid, dim3(CBLOCK), lds, (hipStream_t)stream, boxes, sc, present, out,
                            overlap, partner, (int)A, (int)N);
     TDS_LAUNCH_CHECK("collision_kernel");
+    return TDS_OK;
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// `nograd` metric: per agent the NUMBER of other present agents whose rectangle overlaps it with non-zero area
+// (simulator.py:1111-1149 -> infractions.compute_agent_collisions_metric :352-375 -> get_all_intersections :429-474, where shapely
+// answers `a.intersection(b).area != 0`).  The corners are built like infractions.rectangle_vertices (:476-500, float32, length along
+// the heading); two convex quadrilaterals share area iff no edge line of either one has the whole other one on its outer side or on
+// the line itself -- evaluated in float64 on the float32 corners (the orientation determinants are then exact up to one rounding of a
+// 60-bit product, far below the fp32 noise that the IoU pipeline in absolute coordinates carries for centimetre-deep overlaps).
+// One wavefront per agent i, lanes = partners j; the hits of 64 partners are one ballot + popcount.
+// ---------------------------------------------------------------------------------------------------------
+struct Quad { float x[4], y[4]; };
+
+__device__ inline Quad rectangle_vertices(float cx, float cy, float w, float h, float s, float c) {
+    const float dx = w / 2.0f, dy = h / 2.0f;
+    const float dxcos = dx * c, dxsin = dx * s, dycos = dy * c, dysin = dy * s;
+    Quad q;
+    q.x[0] = cx + (-dxcos - -dysin); q.y[0] = cy + (-dxsin + -dycos);
+    q.x[1] = cx + (dxcos - -dysin);  q.y[1] = cy + (dxsin + -dycos);
+    q.x[2] = cx + (dxcos - dysin);   q.y[2] = cy + (dxsin + dycos);
+    q.x[3] = cx + (-dxcos - dysin);  q.y[3] = cy + (-dxsin + dycos);
+    return q;
+}
+
+// some edge line of p has all of q on its right or on it (p counter-clockwise: its inside is on the left)
+__device__ inline bool separated_by_an_edge_of(const Quad &p, const Quad &q) {
+    bool sep = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double ax = p.x[e], ay = p.y[e], ex = (double)p.x[(e + 1) & 3] - ax, ey = (double)p.y[(e + 1) & 3] - ay;
+        bool all_out = true;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) all_out = all_out && (ex * ((double)q.y[v] - ay) - ey * ((double)q.x[v] - ax) <= 0.0);
+        sep = sep || all_out;
+    }
+    return sep;
+}
+
+__global__ void __launch_bounds__(CBLOCK) overlap_count_kernel(const float *__restrict__ boxes, const float *__restrict__ sc,
+                                                               const uint8_t *__restrict__ present, double *__restrict__ out, int A) {
+    extern __shared__ float lds[];                      // A x 8 corner coordinates of the scene
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *bx = boxes + (size_t)b * A * 5, *bs = sc + (size_t)b * A * 2;
+    const uint8_t *pr = present + (size_t)b * A;
+    for (int j = tid; j < A; j += CBLOCK) {
+        const Quad q = rectangle_vertices(bx[5 * j], bx[5 * j + 1], bx[5 * j + 2], bx[5 * j + 3], bs[2 * j], bs[2 * j + 1]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lds[8 * j + 2 * k] = q.x[k]; lds[8 * j + 2 * k + 1] = q.y[k]; }
+    }
+    __syncthreads();
+    for (int i = blockIdx.y * (CBLOCK / 64) + wave; i < A; i += gridDim.y * (CBLOCK / 64)) {
+        Quad p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { p.x[k] = lds[8 * i + 2 * k]; p.y[k] = lds[8 * i + 2 * k + 1]; }
+        int count = 0;
+        for (int j0 = 0; j0 < A; j0 += 64) {
+            const int j = j0 + lane;
+            bool hit = false;
+            if (j < A && j != i && pr[j]) {
+                Quad q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { q.x[k] = lds[8 * j + 2 * k]; q.y[k] = lds[8 * j + 2 * k + 1]; }
+                hit = !(separated_by_an_edge_of(p, q) || separated_by_an_edge_of(q, p));
+            }
+            count += __popcll(__ballot(hit));
+        }
+        if (lane == 0) out[(size_t)b * A + i] = pr[i] ? (double)count : 0.0;
+    }
+}
+
+}  // namespace
+
+TDS_EXPORT int tds_overlap_count_f32(const float *boxes, const float *sc, const uint8_t *present, double *out, int64_t B, int64_t A,
+                                     void *stream) {
+    TDS_CHECK_ARG(B >= 0 && A >= 0, "tds_overlap_count_f32: bad sizes B=%lld A=%lld", (long long)B, (long long)A);
+    if (B == 0 || A == 0) return TDS_OK;
+    TDS_CHECK_ARG(boxes && sc && present && out, "tds_overlap_count_f32: null pointer");
+    TDS_CHECK_ARG(A <= 4096 && B < 65536 * 32768ll, "tds_overlap_count_f32: A=%lld too large (the corners of a scene are staged in LDS)", (long long)A);
+    const size_t lds = (size_t)A * 8 * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)overlap_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int rows_per_block = CBLOCK / 64;
+    unsigned gy = (unsigned)std::min<int64_t>((A + rows_per_block - 1) / rows_per_block, 64);
+    // the scene index rides on grid.x (2^31 - 1 blocks)
+    hipLaunchKernelGGL(overlap_count_kernel, dim3((unsigned)B, gy), dim3(CBLOCK), lds, (hipStream_t)stream, boxes, sc, present, out, (int)A);
+    TDS_LAUNCH_CHECK("overlap_count_kernel");
     return TDS_OK;
 }
 

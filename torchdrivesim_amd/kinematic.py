@@ -247,6 +247,61 @@ class BicycleNoReversing(KinematicBicycle):
     _no_reversing = True
 
 
+class BicycleByDisplacement(KinematicBicycle):
+    """Bicycle driven by a directed velocity (kinematic.py:526-567): the action (dx, dy) * max_dx is turned into the bicycle action that
+    reaches `xy + (dx, dy) dt` (KinematicBicycle.fit_action) and stepped by K1."""
+
+    def __init__(self, max_dx=20, dt=0.1):
+        super().__init__(dt=dt)
+        self.max_dx = max_dx
+        self._xy_normalization_tensor = torch.tensor([self.max_dx, self.max_dx])
+
+    def copy(self, other=None):
+        if other is None:
+            other = self.__class__(max_dx=self.max_dx, dt=self.dt)
+        other._xy_normalization_tensor = self._xy_normalization_tensor.clone()
+        return super().copy(other)
+
+    def to(self, device):
+        super().to(device)
+        self._xy_normalization_tensor = self._xy_normalization_tensor.to(device)
+        return self
+
+    def step(self, action, dt=None):
+        assert action.shape[-1] == 2        # x and y displacement
+        self.step_from_xy(action[..., :2], dt=dt)
+
+    def step_from_xy(self, xy, dt=None):
+        dt = self.dt if dt is None else dt
+        action = xy * self._xy_normalization_tensor.to(xy.device).to(xy.dtype)
+        dx, dy = action[..., 0], action[..., 1]
+        x, y, psi, v = self.unpack_state(self.get_state())
+        # the bicycle fit ignores psi and v of the target; it is made with the model's OWN dt whatever `dt` is (kinematic.py:556)
+        bicycle_action = KinematicBicycle.fit_action(self, self.pack_state(x + dx * dt, y + dy * dt, psi, v))
+        KinematicBicycle.step(self, bicycle_action, dt=dt)
+
+    def fit_action(self, future_state, current_state=None, dt=None):
+        dt = self.dt if dt is None else dt
+        xf, yf, _, _ = self.unpack_state(future_state)
+        xp, yp, _, _ = self.unpack_state(self.get_state() if current_state is None else current_state)
+        action = torch.stack([(xf - xp) / dt, (yf - yp) / dt], dim=-1)
+        return action / self._xy_normalization_tensor.to(action.device)
+
+
+class BicycleByOrientedDisplacement(BicycleByDisplacement):
+    """BicycleByDisplacement with the displacement given in the agent's own frame (kinematic.py:570-587)."""
+
+    def step_from_xy(self, xy, dt=None):
+        psi = self.get_state()[..., 2:3]
+        super().step_from_xy(rotate(xy, psi), dt=dt)
+
+    def fit_action(self, future_state, current_state=None, dt=None):
+        action = super().fit_action(future_state, current_state=current_state, dt=dt)
+        if current_state is None:
+            current_state = self.get_state()
+        return rotate(action[..., :2], -current_state[..., 2:3])
+
+
 class UnicycleModel(KinematicModel):
     """Unicycle named by the north star (absent from the reference): action = (acceleration, yaw rate),
     v += a dt; x += v cos(psi) dt; y += v sin(psi) dt; psi += w dt."""

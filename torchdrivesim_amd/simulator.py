@@ -874,18 +874,10 @@ class Simulator:
             return _ops.collision(boxes, self._collision_mask(agent_types), n_exposed=A, metric=metric.value, sc=sc)
         if metric == CollisionMetric.nograd:
             assert agent_types is None, 'The argument `agent_types` is not supported by the selected collision metric.'
-            # count of other present exposed agents whose rectangle overlaps (simulator.py:1111-1149, shapely); here the
-            # overlap flags of the IoU kernel (touching rectangles do not count; parity unpinned -- shapely is absent)
+            # count of other present exposed agents whose rectangle shares area with the agent's (simulator.py:1111-1149 ->
+            # infractions.py:352-375, where shapely answers `intersection(...).area != 0` on the host): one kernel, exact predicate in
+            # float64 on the float32 corners of infractions.rectangle_vertices; NPCs are not counted, as in the reference (:1124)
             state, size, present = self.get_state().detach(), self.get_agent_size(), self.get_present_mask()
             boxes = torch.cat([state[..., :2], size, state[..., 2:3]], dim=-1)
-            if A > 64:
-                # the bit masks hold 64 partners: larger scenes evaluate the A x A pairs with the element-wise kernel instead
-                b = torch.nan_to_num(boxes, nan=0.0)
-                o = _ops.pairwise_overlap(b.unsqueeze(2).expand(-1, -1, A, -1).contiguous(), b.unsqueeze(1).expand(-1, A, -1, -1).contiguous(), 'iou')
-                hit = (torch.nan_to_num(o, nan=0.0) > 0) & present.unsqueeze(1) & ~torch.eye(A, dtype=torch.bool, device=o.device)
-                return (hit.sum(-1) * present).to(torch.float64)
-            _, bits, _ = _ops.collision_forward(boxes, _ops.metric_sc(torch.nan_to_num(boxes, nan=0.0), 'iou'), present, A, 'iou', want_overlap=True)
-            shifts = torch.arange(A, device=bits.device)
-            counts = ((bits.unsqueeze(-1) >> shifts) & 1).sum(-1)
-            return (counts * present).to(torch.float64)
+            return _ops.overlap_count(boxes, present)
         raise ValueError('Unrecognized collision metric: ' + str(metric))
