@@ -139,14 +139,16 @@ def stamped_traffic(B, A, mode='f32'):
 
 class _ImageProbe(torch.autograd.Function):
     """The image term of config 5's loss: <image, w> for a fixed dense random field w -- what the first layer of a policy network would
-    hand back.  Forward: one batched dot product (both tensors read once); backward: w itself goes to the rasteriser's backward (the
+    hand back.  Forward: dot products over slices of the batch (both tensors read once); backward: w itself goes to the rasteriser's backward (the
     probe is the last term of the loss, its upstream gradient is 1), so that no 12.9 GB temporary is produced by the LOSS."""
 
     @staticmethod
     def forward(ctx, img, w):
         ctx.save_for_backward(w)
-        B = img.shape[0]
-        return torch.bmm(img.reshape(B, 1, -1), w.reshape(B, -1, 1)).sum()
+        # dot products over slices of the batch (each below 2^31 elements), summed on the device
+        a, b = img.flatten(), w.flatten()
+        step = 1 << 30
+        return torch.stack([torch.dot(a[i:i + step], b[i:i + step]) for i in range(0, a.numel(), step)]).sum()
 
     @staticmethod
     def backward(ctx, g):

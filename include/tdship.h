@@ -196,17 +196,33 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  * extra_tri / extra_key / n_extra: optional per-camera triangles, B x Nc x n_extra x 3 x 2 float32 WORLD coordinates and
  * B x Nc x n_extra uint32 keys (0 = no triangle) -- the fused form of generate()'s waypoint discs (mesh.py:1120-1145), which differ
  * from camera to camera.  Their keys must be listed in `actor_keys` for the bit-plane kernel to be used. */
+/* aux (may be NULL): optional outputs for a later backward pass (tds_raster_scene_bwd_idx_f32).
+ *   index_slices  DEVICE buffer of tds_raster_index_slices_bytes(B * Nc, res) bytes, or NULL.  When given, the call must be servable by
+ *                 the bit-plane kernel (float32 output, res a multiple of 4, at most 15 distinct keys with `actor_keys` listed) -- else
+ *                 TDS_ELIMIT -- and receives, per pixel, the 1-based position of the winning key in `keys` (0 = background) as bit-slices:
+ *                 uint32 [camera][x / 32][y / 4][slice 0..3][y % 4], bit x % 32; 64 B per (word column, row quad), slices >= index_bits
+ *                 unwritten.  x, y = OpenCV pixel coordinates = the last two axes of `out`.
+ *   keys, n_keys, index_bits   filled by the call (HOST): the ascending key table of the launch (n_keys = 0 when another kernel ran) */
+typedef struct tds_raster_aux {
+    uint32_t *index_slices;
+    int64_t index_slices_bytes;
+    uint32_t keys[16];
+    int32_t n_keys;
+    int32_t index_bits;
+} tds_raster_aux_t;
+int tds_raster_index_slices_bytes(int64_t n_img, int res, int64_t *bytes);
+
 int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                      const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc,
                      int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera,
-                     const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream);
+                     const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream);
 /* tds_raster_scene for scenes with different maps: scene b is drawn over map scene_map[b] of the set (one launch for the batch) */
 int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, const float *state, const float *agent_sc, const float *tmpl,
                            const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc,
                            int64_t N, float scale, int res, int out_mode, void *out, void *workspace, int64_t workspace_bytes,
                            const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera,
-                           const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream);
+                           const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream);
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 
@@ -221,6 +237,16 @@ int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                              const float *cam_sc, const float *image, const float *grad_out, int64_t B, int64_t Nc, int64_t N,
                              float scale, int res, float *grad_agent, float *grad_cam, void *stream);
+
+/* The same gradient computed from the forward's key-index slices (tds_raster_aux_t) instead of the forward image: the incoming gradient
+ * is read only next to colour boundaries.  keys / n_keys: HOST, the key table the forward launch reported.
+ * grad_color (optional, NULL to skip): B x Nc x 16 x 4 -- entry [i][ch] (ch 0..2 = R, G, B; [3] = 0) is the gradient with respect to
+ * channel ch of the colour shown for key index i (0 = background, i >= 1: keys[i - 1]) in that camera: the sum of grad_out over the
+ * pixels whose winning key it is (exact: the image is colour[index] pixel by pixel).  Asking for it reads grad_out in full. */
+int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
+                                 const float *cam_sc, const uint32_t *index_slices, const uint32_t *keys, int n_keys, const float *grad_out,
+                                 int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent, float *grad_cam,
+                                 float *grad_color, void *stream);
 
 /* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
  *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,

@@ -142,6 +142,79 @@ def test_kernel_matches_numpy_definition(ops, oracle, res):   # of a row in two 
     np.testing.assert_allclose(csc.grad.cpu().numpy(), gc[..., 2:], atol=2e-4 * max(np.abs(gc[..., 2:]).max(), 1e-9), rtol=2e-3)
 
 
+@pytest.mark.parametrize('res', [64, 256, 288, 512])      # one word column .. two strips (288) .. more than 64 row quads per column (512)
+def test_index_slice_backward_equals_the_image_backward(ops, oracle, res):
+    """The two backward kernels compute the same sums: tds_raster_scene_bwd_idx_f32 from the forward's key-index slices (reading the
+    incoming gradient next to colour boundaries only) and tds_raster_scene_bwd_f32 from the forward image."""
+    gen = np.random.default_rng(17)
+    verts, faces, state, size, cam_xy, cam_psi, mask = scene(gen, B=2, N=6, Nc=4)
+    smap = make_map(ops, verts, faces, MAP_VC, MAP_CATS)
+    tmpl = dev(oracle.actor_template(size))
+    B, N = state.shape[:2]
+    cpsi = dev(cam_psi)
+    gout = None
+    grads = []
+    for use in (True, False):
+        ops.use_index_slices = use
+        try:
+            st, cxy = dev(state).requires_grad_(True), dev(cam_xy).requires_grad_(True)
+            csc = torch.cat([torch.sin(cpsi), torch.cos(cpsi)], -1).requires_grad_(True)
+            sc = ops.heading_sc(st[..., 2]).detach().requires_grad_(True)
+            img = ops.raster_scene_diff(smap, st, sc, tmpl, actor_keys(smap, B, N), dev(mask), cxy, csc, 35.0, res)
+            if gout is None:
+                gout = torch.randn(img.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+            img.backward(gout)
+            grads.append([t.grad.double().cpu().numpy() for t in (st, sc, cxy, csc)])
+        finally:
+            ops.use_index_slices = True
+    for a, b in zip(*grads):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(np.abs(b).max(), 1e-9))
+    assert np.abs(grads[0][2]).max() > 0 and np.abs(grads[0][0]).max() > 0
+
+
+def test_colour_gradient_is_the_per_key_sum_of_the_incoming_gradient(ops, oracle):
+    """R6: dL/dcolour of a key = sum of the incoming gradient over the pixels where that key wins, exact (integer-valued gradients make every
+    float32 sum exact whatever its order)"""
+    gen = np.random.default_rng(23)
+    verts, faces, state, size, cam_xy, cam_psi, mask = scene(gen, B=2, N=6, Nc=3)
+    smap = make_map(ops, verts, faces, MAP_VC, MAP_CATS)
+    tmpl = dev(oracle.actor_template(size))
+    B, N, res = state.shape[0], state.shape[1], 128
+    akeys = actor_keys(smap, B, N)
+    cpsi = dev(cam_psi)
+    csc = torch.cat([torch.sin(cpsi), torch.cos(cpsi)], -1)
+    st = dev(state)
+    sc = ops.heading_sc(st[..., 2])
+    img, slices, keys = ops.raster_scene(smap, st, sc, tmpl, akeys, dev(mask), dev(cam_xy), csc, 35.0, res, index_slices=True)
+    assert slices is not None and keys == sorted(keys) and 3 <= len(keys) <= 15
+    # the slices decode to the image: pixel = colour of the key whose 1-based position they hold
+    sl = slices.view(B * 3, (res + 31) // 32, res // 4, 4, 4).cpu().numpy().astype(np.uint32)
+    idx = np.zeros((B * 3, res, res), np.int64)
+    xs = np.arange(res)
+    for bit in range(4 if len(keys) > 7 else (3 if len(keys) > 3 else 2)):
+        words = sl[:, :, :, bit, :].reshape(B * 3, (res + 31) // 32, res)                   # [img][x word][y]
+        idx |= (((words[:, xs // 32, :] >> (xs % 32)[None, :, None].astype(np.uint32)) & 1).astype(np.int64)) << bit      # [img][x][y]
+    table = np.array([[0, 0, 0]] + [[(k >> 16) & 255, (k >> 8) & 255, k & 255] for k in keys], np.float32)
+    np.testing.assert_array_equal(table[idx].transpose(0, 3, 1, 2).reshape(img.shape), img.cpu().numpy())
+    # gradient with respect to the colours of three of the keys (and of one key that is not in the scene)
+    color_keys = [keys[0], keys[-1], keys[1], 0x05123456]
+    kc = torch.tensor([[(k >> 16) & 255, (k >> 8) & 255, k & 255] for k in color_keys], dtype=torch.float32, device=DEV, requires_grad=True)
+    st2 = dev(state).requires_grad_(True)
+    out = ops.raster_scene_diff(smap, st2, ops.heading_sc(st2[..., 2]), tmpl, akeys, dev(mask), dev(cam_xy), csc, 35.0, res, key_colors=kc, color_keys=color_keys)
+    gout = torch.randint(-3, 4, out.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).float()
+    out.backward(gout)
+    g = gout.cpu().numpy().reshape(B * 3, 3, res, res)
+    expect = np.stack([np.stack([g[:, ch][idx == (keys.index(k) + 1 if k in keys else -1)].sum() for ch in range(3)]) for k in color_keys])
+    np.testing.assert_array_equal(kc.grad.cpu().numpy(), expect.astype(np.float32))
+    assert np.abs(expect[:3]).sum() > 0 and not expect[3].any()
+    with pytest.raises(RuntimeError, match='colour gradients need'):
+        ops.use_index_slices = False
+        try:
+            ops.raster_scene_diff(smap, st2, ops.heading_sc(st2[..., 2]), tmpl, akeys, dev(mask), dev(cam_xy), csc, 35.0, res, key_colors=kc, color_keys=color_keys)
+        finally:
+            ops.use_index_slices = True
+
+
 def fine_weight(res, seed, n=3):
     """a smooth function of the normalised image coordinates, sampled at `res` (so that it can be evaluated at any resolution)"""
     gen = np.random.default_rng(seed)
@@ -156,9 +229,10 @@ def fine_weight(res, seed, n=3):
 
 @pytest.mark.parametrize('param', ['x', 'y', 'psi', 'cam_x', 'cam_y', 'cam_psi'])
 def test_gradient_follows_finite_differences(ops, oracle, param):
-    """L = sum f I with a smooth f.  The image is piecewise constant, so the reference is a central difference of the hard
-    rasterisation rendered at 4x the resolution (same f, weights / 16) over a step of several fine pixels.  The comparison is
-    statistical -- the gradient is a boundary integral sampled once per pixel against an OpenCV-style raster: 30 % of the scale."""
+    """L = sum f I with a smooth f.  The image is piecewise constant, so the reference is a central difference of the hard rasterisation
+    rendered at 4x the resolution (same f, weights / 16) over a step of a few pixels.  A single pose compares a once-per-pixel boundary
+    sample against an OpenCV-style raster (2 - 15 % apart, the phase of the edges against the pixel grid); both sides are therefore
+    AVERAGED over 12 sub-pixel shifts of the whole scene -- the gradient of the shift-averaged loss -- and must agree within 10 % of the scale."""
     gen = np.random.default_rng(11)
     verts, faces, state, size, cam_xy, cam_psi, mask = scene(gen, B=1, N=3, Nc=1, big=True)
     mask[:] = True
@@ -178,26 +252,34 @@ def test_gradient_follows_finite_differences(ops, oracle, param):
         img = render(ops, smap, oracle, st, size, mask, cxy, csc, fov, r, diff)
         return (img.double() * f.double()).sum(), st, cxy, cpsi
 
-    L, st, cxy, cpsi = loss_of(res, state, cam_xy, cam_psi, True)
-    L.backward()
-    grads = dict(x=st.grad[0, :, 0], y=st.grad[0, :, 1], psi=st.grad[0, :, 2], cam_x=cxy.grad[0, :, 0], cam_y=cxy.grad[0, :, 1],
-                 cam_psi=cpsi.grad[0, :, 0])
     h = 0.05 if 'psi' in param else 0.3
     n = 1 if param.startswith('cam') else state.shape[1]
-    fd = np.zeros(n)
-    for i in range(n):
-        vals = []
-        for sgn in (+1, -1):
-            s2, c2, p2 = state.copy(), cam_xy.copy(), cam_psi.copy()
-            tgt, col = dict(x=(s2, 0), y=(s2, 1), psi=(s2, 2), cam_x=(c2, 0), cam_y=(c2, 1), cam_psi=(p2, 0))[param]
-            tgt[0, i, col] += sgn * h
-            vals.append(loss_of(res * ss, s2, c2, p2)[0].item())
-        fd[i] = (vals[0] - vals[1]) / (2 * h)
-    g = grads[param].cpu().numpy().astype(np.float64)
+    shifts = np.random.default_rng(2).uniform(-0.5, 0.5, (12, 2)) * (fov / res)          # within one pixel
+    g_sum, fd_sum = np.zeros(n), np.zeros(n)
+    for sh in shifts:
+        # actors and camera parameters under test move against the static map and the image grid by a fraction of a pixel
+        st0, cx0 = state.copy(), cam_xy.copy()
+        st0[0, :, :2] += sh
+        if param.startswith('cam'):
+            cx0[0, :, :] += sh[::-1] * 0.5
+        L, st, cxy, cpsi = loss_of(res, st0, cx0, cam_psi, True)
+        L.backward()
+        grads = dict(x=st.grad[0, :, 0], y=st.grad[0, :, 1], psi=st.grad[0, :, 2], cam_x=cxy.grad[0, :, 0], cam_y=cxy.grad[0, :, 1],
+                     cam_psi=cpsi.grad[0, :, 0])
+        g_sum += grads[param].cpu().numpy().astype(np.float64)
+        for i in range(n):
+            vals = []
+            for sgn in (+1, -1):
+                s2, c2, p2 = st0.copy(), cx0.copy(), cam_psi.copy()
+                tgt, col = dict(x=(s2, 0), y=(s2, 1), psi=(s2, 2), cam_x=(c2, 0), cam_y=(c2, 1), cam_psi=(p2, 0))[param]
+                tgt[0, i, col] += sgn * h
+                vals.append(loss_of(res * ss, s2, c2, p2)[0].item())
+            fd_sum[i] += (vals[0] - vals[1]) / (2 * h)
+    g, fd = g_sum / len(shifts), fd_sum / len(shifts)
     # (a camera move shifts the static map as well: its lane stripes contribute to the camera gradient)
     scale = max(np.abs(fd).max(), np.abs(g).max())
     assert scale > 1.0, 'degenerate test'
-    assert np.abs(g - fd).max() <= 0.3 * scale, (param, g, fd)
+    assert np.abs(g - fd).max() <= 0.10 * scale, (param, g, fd)
 
 
 def test_gradients_reach_simulator_state(ops):

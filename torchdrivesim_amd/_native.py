@@ -22,6 +22,13 @@ OUT_F32, OUT_U8 = 0, 1
 
 _lib = None
 
+
+class RasterAux(ctypes.Structure):
+    """tds_raster_aux_t (include/tdship.h): optional outputs of tds_raster_scene for a later backward pass"""
+    _fields_ = [('index_slices', ctypes.c_void_p), ('index_slices_bytes', ctypes.c_int64), ('keys', ctypes.c_uint32 * 16),
+                ('n_keys', ctypes.c_int32), ('index_bits', ctypes.c_int32)]
+
+
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
 # name -> argtypes  (mirrors include/tdship.h; tests/test_abi.py checks that every declared symbol is exported)
@@ -48,10 +55,12 @@ _SIGNATURES = {
     'tds_mapset_destroy': [_vp],
     'tds_offroad_multi_f32': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     'tds_offroad_multi_bwd_f32': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
-    'tds_raster_scene_multi': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
+    'tds_raster_scene_multi': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
     'tds_offroad_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     'tds_offroad_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
-    'tds_raster_scene': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
+    'tds_raster_scene': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
+    'tds_raster_index_slices_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
+    'tds_raster_scene_bwd_idx_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
     'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp],
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
     'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp],

@@ -405,6 +405,7 @@ _workspaces = collections.OrderedDict()
 _WORKSPACES_MAX = 8
 use_workspace = True
 use_bitplanes = True      # test hook: False forces the packed-key kernels
+use_index_slices = True   # test hook: False makes the raster backward read the forward image (the path of the packed-key kernels)
 
 
 def _raster_workspace(dev, n_img, res):
@@ -430,11 +431,14 @@ raster_bwd_events = None
 
 
 def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None,
-                 extra_tri=None, extra_key=None):
+                 extra_tri=None, extra_key=None, index_slices=False):
     """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns -- or (B,Nc,N,2)
     when every camera sees its own colours (custom_agent_colors) --, mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2)
     -> (B,Nc,3,res,res) float32 [0,255] or uint8.  extra_tri (B,Nc,K,3,2) world-space triangles with keys extra_key (B,Nc,K) int32
-    (0 = none) are drawn per camera (waypoint discs); their keys belong into `key_table` too."""
+    (0 = none) are drawn per camera (waypoint discs); their keys belong into `key_table` too.
+    index_slices=True: returns (image, slices, keys) -- the per-pixel key index as bit-slices (int32 tensor, layout in include/tdship.h)
+    and the ascending key table of the launch, what the backward pass reads instead of the image; (image, None, None) when the call
+    cannot be served by the bit-plane kernel."""
     B, Nc = cam_xy.shape[:2]
     N = state.shape[1]
     dev = cam_xy.device
@@ -473,37 +477,70 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     multi = isinstance(smap, StaticMapSet)
     if multi and smap.scene_map.shape[0] != B:
         raise RuntimeError(f'the StaticMapSet is for {smap.scene_map.shape[0]} scenes, the cameras for {B}')
+    aux = slices = None
+    if index_slices and kt is not None and out_dtype == torch.float32 and res % 4 == 0 and B * Nc > 0:
+        nbytes = ctypes.c_int64(0)
+        nat.call('tds_raster_index_slices_bytes', dev, B * Nc, int(res), ctypes.byref(nbytes))
+        slices = torch.empty(nbytes.value // 4, dtype=i32, device=dev)
+        aux = nat.RasterAux(index_slices=slices.data_ptr(), index_slices_bytes=nbytes.value)
     head = ('tds_raster_scene_multi', dev, smap.handle, nat.dev_ptr(smap.scene_map, i32, 'scene_map')) if multi else ('tds_raster_scene', dev, smap.handle)
-    nat.call(*head, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
+    def launch(aux):
+        nat.call(*head, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
              p(actor_key, i32, 'actor_key'), p(mask, u8, 'mask'), nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
              B, Nc, N, float(2.0 / fov), int(res), mode, nat.dev_ptr(out, out_dtype, 'out'),
              None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel(),
              None if kt is None else ctypes.cast(kt, ctypes.c_void_p), 0 if kt is None else len(key_table),
              1 if (N > 0 and actor_key.dim() == 4) else 0,
              nat.dev_ptr(extra_tri, f32, 'extra_tri') if K > 0 else None, nat.dev_ptr(extra_key, i32, 'extra_key') if K > 0 else None, K,
-             nat.stream_ptr(dev))
+             None if aux is None else ctypes.cast(ctypes.pointer(aux), ctypes.c_void_p), nat.stream_ptr(dev))
+
+    try:
+        launch(aux)
+    except RuntimeError as e:
+        if aux is None or 'index slices' not in str(e):
+            raise
+        aux = slices = None                 # more than 15 keys, or planes too large: another kernel serves the call, without slices
+        launch(None)
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         raster_events.append(ev)
+    if index_slices:
+        if aux is None or aux.n_keys == 0:
+            return out, None, None
+        return out, slices, [int(aux.keys[i]) for i in range(aux.n_keys)]
     return out
 
 
 class _RasterScene(torch.autograd.Function):
-    """Differentiable wrapper of the fused scene rasteriser.  Forward: tds_raster_scene (CV2 pixel semantics).  Backward:
-    tds_raster_scene_bwd_f32, the build-defined edge-sampling gradient with respect to actor position / heading and camera position /
-    heading (DESIGN.md "K3 backward"); the reference's CV2 backend has none (rendering/cv2.py:27-70)."""
+    """Differentiable wrapper of the fused scene rasteriser.  Forward: tds_raster_scene (CV2 pixel semantics).  Backward: the build-defined
+    edge-sampling gradient with respect to actor position / heading and camera position / heading (DESIGN.md "K3 backward"); the
+    reference's CV2 backend has none (rendering/cv2.py:27-70).  When the bit-plane kernel serves the forward it also leaves the per-pixel key
+    index as bit-slices (3 % of the image), and the backward (tds_raster_scene_bwd_idx_f32) reads those and the incoming gradient next
+    to colour boundaries only; otherwise the forward image is kept and tds_raster_scene_bwd_f32 streams image and gradient in full."""
 
     @staticmethod
-    def forward(ctx, state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key):
-        out = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table, extra_tri=extra_tri,
-                           extra_key=extra_key)
-        ctx.save_for_backward(state, agent_sc, cam_xy, cam_sc, tmpl, mask, out)
-        ctx.fov, ctx.res = fov, res
+    def forward(ctx, state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key, color_keys):
+        out, slices, keys = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table,
+                                         extra_tri=extra_tri, extra_key=extra_key, index_slices=True) if use_index_slices else \
+            (raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table, extra_tri=extra_tri,
+                          extra_key=extra_key), None, None)
+        if slices is not None:
+            ctx.save_for_backward(state, agent_sc, cam_xy, cam_sc, tmpl, mask, slices)
+        else:
+            ctx.save_for_backward(state, agent_sc, cam_xy, cam_sc, tmpl, mask, out)
+        ctx.fov, ctx.res, ctx.keys = fov, res, keys
+        ctx.color_keys = None
+        if key_colors is not None:
+            if keys is None:
+                raise RuntimeError('colour gradients need the key-index slices of the bit-plane kernel (at most 15 distinct keys, float32 output, '
+                                   'resolution a multiple of 4, no per-camera colours)')
+            assert len(color_keys) == key_colors.shape[0] and key_colors.shape[-1] == 3, 'key_colors is (len(color_keys), 3)'
+            ctx.color_keys = [int(k) & 0xffffffff for k in color_keys]
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        state, agent_sc, cam_xy, cam_sc, tmpl, mask, out = ctx.saved_tensors
+        state, agent_sc, cam_xy, cam_sc, tmpl, mask, kept = ctx.saved_tensors
         B, Nc = cam_xy.shape[:2]
         N = state.shape[1]
         dev = cam_xy.device
@@ -516,10 +553,18 @@ class _RasterScene(torch.autograd.Function):
         if raster_bwd_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
-        nat.call('tds_raster_scene_bwd_f32', dev, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
-                 None if N == 0 else nat.dev_ptr(m8, u8, 'mask'), nat.dev_ptr(_c(cam_xy), f32, 'cam_xy'), nat.dev_ptr(_c(cam_sc), f32, 'cam_sc'),
-                 nat.dev_ptr(out, f32, 'image'), nat.dev_ptr(gout, f32, 'grad_out'), B, Nc, N, float(2.0 / ctx.fov), int(ctx.res),
-                 nat.dev_ptr(g_agent, f32, 'grad_agent'), nat.dev_ptr(g_cam, f32, 'grad_cam'), nat.stream_ptr(dev))
+        poses = (p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'), None if N == 0 else nat.dev_ptr(m8, u8, 'mask'),
+                 nat.dev_ptr(_c(cam_xy), f32, 'cam_xy'), nat.dev_ptr(_c(cam_sc), f32, 'cam_sc'))
+        tail = (B, Nc, N, float(2.0 / ctx.fov), int(ctx.res), nat.dev_ptr(g_agent, f32, 'grad_agent'), nat.dev_ptr(g_cam, f32, 'grad_cam'), nat.stream_ptr(dev))
+        g_color = None
+        if ctx.keys is not None:
+            kt = (ctypes.c_uint32 * 16)(*ctx.keys)
+            if ctx.color_keys is not None and ctx.needs_input_grad[4]:
+                g_color = torch.empty((B, Nc, 16, 4), dtype=f32, device=dev)
+            nat.call('tds_raster_scene_bwd_idx_f32', dev, *poses, nat.dev_ptr(kept, i32, 'index_slices'), ctypes.cast(kt, ctypes.c_void_p), len(ctx.keys),
+                     nat.dev_ptr(gout, f32, 'grad_out'), *tail[:-1], nat.dev_ptr(g_color, f32, 'grad_color'), tail[-1])
+        else:
+            nat.call('tds_raster_scene_bwd_f32', dev, *poses, nat.dev_ptr(kept, f32, 'image'), nat.dev_ptr(gout, f32, 'grad_out'), *tail)
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))
             raster_bwd_events.append(ev)
@@ -529,12 +574,25 @@ class _RasterScene(torch.autograd.Function):
             g_state = torch.zeros_like(state)
             g_state[..., :2] = ga[..., :2]
             g_sc = ga[..., 2:].contiguous()
-        return g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), None, None, None, None, None, None, None, None, None
+        g_key_colors = None
+        if g_color is not None:
+            # rows of the launch's key table (index i + 1 <-> keys[i]) -> the caller's rows; a key that was not part of the launch shows nowhere
+            per_key = g_color.sum(dim=(0, 1))[:, :3]                  # over cameras: (16, 3)
+            pos = {k: i + 1 for i, k in enumerate(ctx.keys)}
+            rows = torch.tensor([pos.get(k, -1) for k in ctx.color_keys], device=dev)
+            g_key_colors = torch.where((rows >= 0)[:, None], per_key[rows.clamp(min=0)], torch.zeros((), device=dev))
+        return (g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), g_key_colors,
+                None, None, None, None, None, None, None, None, None, None)
 
 
-def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None, extra_tri=None, extra_key=None):
-    """raster_scene with a backward pass (float32 output only; the per-camera triangles get no gradient)"""
-    return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, smap, tmpl, actor_key, mask, float(fov), int(res), key_table, extra_tri, extra_key)
+def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None, extra_tri=None, extra_key=None,
+                      key_colors=None, color_keys=None):
+    """raster_scene with a backward pass (float32 output only; the per-camera triangles get no gradient).
+    key_colors (K,3) float tensor + color_keys (K packed keys): a handle for COLOUR gradients -- row r stands for the colour the image shows
+    where key color_keys[r] wins; the forward takes its pixels from the keys' own RGB bits (the caller keeps the two consistent), the
+    backward returns d loss / d key_colors[r] = the sum of the incoming gradient over those pixels, all cameras (exact)."""
+    return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, float(fov), int(res), key_table, extra_tri,
+                              extra_key, color_keys)
 
 
 def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32):

@@ -80,6 +80,8 @@ struct CommonArgs {
     int strips;
     int64_t n_img;
     void *out;
+    uint32_t *slices;           // optional: bit-slices of the winning key index per pixel, kept for the backward pass (bit-plane kernel
+                                // only; layout in include/tdship.h, tds_raster_aux_t)
     int debug;                  // ablation switches for profiling (tds_raster_set_debug): 1 no static, 2 no actors, 4 no store,
                                 // 8 no outline edges, 16 no scan conversion
 };
@@ -1536,9 +1538,9 @@ template <int NB> struct PairTab<NB, uint8_t> { using E = uint32_t; };        //
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return __builtin_rotateleft32(v, (unsigned)n & 31u); }
 
-template <int BBLOCK, int NB, typename OutT>
+template <int BBLOCK, int NB, typename OutT, bool EMIT>
 __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typename PairTab<NB, OutT>::E *tab, int K, OutT *out, int64_t img, int res,
-                                      int X0, int TWp, int wpr, int tid) {
+                                      int X0, int TWp, int wpr, int tid, uint32_t *slices) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int P = 1 << (2 * NB);
     const int H = res, W = res;
@@ -1570,6 +1572,12 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
 #pragma unroll
                     for (int b = 0; b < NB; ++b) s[b][j] |= ((idx >> b) & 1) ? sn : 0u;
                 }
+            }
+            if constexpr (EMIT) {
+                // the resolved index of these 4 rows x 32 columns, as NB bit-slices: 16 B per slice, 64 B apart per (word column, row quad)
+                uint4 *dst = (uint4 *)(slices + ((((size_t)img * (size_t)((W + 31) >> 5) + (size_t)((X0 >> 5) + xw)) * (size_t)quads + (size_t)rq) << 4));
+#pragma unroll
+                for (int b = 0; b < NB; ++b) dst[b] = make_uint4(s[b][0], s[b][1], s[b][2], s[b][3]);
             }
             uint32_t R0[2 * NB], R1[2 * NB];                         // pair (rows 0,1) and pair (rows 2,3)
 #pragma unroll
@@ -1634,7 +1642,8 @@ template <int NB, typename OutT>
 constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename PairTab<NB, OutT>::E) / 4; }
 
 // one workgroup per (camera, strip); for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
-template <int BWAVES, int NB, typename OutT, typename SA>
+// EMIT: also store the key-index slices for the backward pass (a separate instantiation: the plain kernel sits exactly at its VGPR limit)
+template <int BWAVES, int NB, typename OutT, typename SA, bool EMIT = false>
 __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
@@ -1696,7 +1705,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
-    if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid);
+    if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, EMIT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, c.slices);
 }
 
 inline int bits_index_bits(int K) { return K <= 3 ? 2 : (K <= 7 ? 3 : 4); }
@@ -1833,6 +1842,13 @@ inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
 }
 }  // namespace
 
+TDS_EXPORT int tds_raster_index_slices_bytes(int64_t n_img, int res, int64_t *bytes) {
+    TDS_CHECK_ARG(bytes, "tds_raster_index_slices_bytes: null output");
+    TDS_CHECK_ARG(n_img >= 0 && res > 0 && res <= 4096, "tds_raster_index_slices_bytes: bad sizes");
+    *bytes = (res & 3) ? 0 : n_img * (int64_t)((res + 31) / 32) * (int64_t)(res / 4) * 64;
+    return TDS_OK;
+}
+
 TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes) {
     TDS_CHECK_ARG(bytes, "tds_raster_scene_workspace_bytes: null output");
     TDS_CHECK_ARG(res > 0 && res <= 4096 && n_img >= 0, "tds_raster_scene_workspace_bytes: bad arguments");
@@ -1855,39 +1871,40 @@ struct MapSource {
 };
 int raster_scene_impl(const MapSource &ms, const float *state, const float *agent_sc, const float *tmpl, const uint32_t *actor_key, const uint8_t *mask,
                       const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out,
-                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream);
+                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream);
 }  // namespace
 
 TDS_EXPORT int tds_raster_scene(const tds_map_t *map, const float *state, const float *agent_sc, const float *tmpl,
                                 const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                 int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream) {
+                                int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream) {
     TDS_CHECK_ARG(map, "tds_raster_scene: null map");
     MapSource ms;
     ms.one = map->view; ms.views = nullptr; ms.scene_map = nullptr; ms.uniq_keys = map->uniq_keys; ms.n_uniq = map->n_uniq;
     ms.renders = map->n_levels > 0 || map->view.nx == 0;
     return raster_scene_impl(ms, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, B, Nc, N, scale, res, out_mode, out, workspace, workspace_bytes,
-                             actor_keys, n_actor_keys, actor_key_per_camera, extra_tri, extra_key, n_extra, stream);
+                             actor_keys, n_actor_keys, actor_key_per_camera, extra_tri, extra_key, n_extra, aux, stream);
 }
 
 TDS_EXPORT int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, const float *state, const float *agent_sc, const float *tmpl,
                                       const uint32_t *actor_key, const uint8_t *mask, const float *cam_xy, const float *cam_sc, int64_t B,
                                       int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out, void *workspace,
-                                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream) {
+                                      int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream) {
     TDS_CHECK_ARG(set && set->n > 0, "tds_raster_scene_multi: null or empty map set");
     TDS_CHECK_ARG(scene_map || B == 0, "tds_raster_scene_multi: null scene -> map index array");
     MapSource ms;
     ms.one = tds::MapView{}; ms.views = set->d_views; ms.scene_map = scene_map; ms.uniq_keys = set->uniq_keys; ms.n_uniq = set->n_uniq;
     ms.renders = set->n_levels > 0;
     return raster_scene_impl(ms, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, B, Nc, N, scale, res, out_mode, out, workspace, workspace_bytes,
-                             actor_keys, n_actor_keys, actor_key_per_camera, extra_tri, extra_key, n_extra, stream);
+                             actor_keys, n_actor_keys, actor_key_per_camera, extra_tri, extra_key, n_extra, aux, stream);
 }
 
 namespace {
 int raster_scene_impl(const MapSource &ms, const float *state, const float *agent_sc, const float *tmpl, const uint32_t *actor_key, const uint8_t *mask,
                       const float *cam_xy, const float *cam_sc, int64_t B, int64_t Nc, int64_t N, float scale, int res, int out_mode, void *out,
-                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, void *stream) {
+                      void *workspace, int64_t workspace_bytes, const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera, const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream) {
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene: bad sizes");
+    if (aux) { aux->n_keys = 0; aux->index_bits = 0; }
     TDS_CHECK_ARG(ms.renders, "tds_raster_scene: the map was created without rendering data");
     int64_t n_img = B * Nc;
     int tw = 0;
@@ -1905,7 +1922,15 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     a.extra_tri = extra_tri; a.extra_key = extra_key; a.K = (int)n_extra;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = TDS_DBG(g_debug);
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
+    const bool want_slices = aux && aux->index_slices;
+    if (want_slices) {
+        int64_t need = 0;
+        (void)tds_raster_index_slices_bytes(n_img, res, &need);
+        TDS_CHECK_ARG(need > 0 && out_mode == TDS_OUT_F32, "tds_raster_scene: index slices need a float32 image whose resolution is a multiple of 4");
+        TDS_CHECK_ARG(aux->index_slices_bytes >= need, "tds_raster_scene: index slices buffer too small (%lld < %lld bytes)",
+                      (long long)aux->index_slices_bytes, (long long)need);
+    }
     // fastest path: bit planes, when the scene uses at most MAX_KEYS distinct keys and the caller listed the actors' keys
     if (((N == 0 && n_extra == 0) || (actor_keys && n_actor_keys > 0)) && ms.n_uniq >= 0 && !(TDS_DBG(g_debug) & 64)) {
         KeyTable kt;
@@ -1931,6 +1956,8 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
             if (lds <= 150 * 1024) {
                 CommonArgs cb = cm;
                 cb.strips = (res + twp - 1) / twp;
+                cb.slices = want_slices ? aux->index_slices : nullptr;
+                if (aux) { aux->n_keys = kt.n; aux->index_bits = bits_index_bits(kt.n); for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
                 dim3 grid((unsigned)(n_img * cb.strips));
                 const SceneArgs base = a;
                 auto launch_b = [&](auto kern) {            // scenes without per-camera triangles
@@ -1948,12 +1975,21 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
         else if (nwv == 4) { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, T, SceneArgsEx>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, T, SceneArgsEx>); else launch(raster_scene_bits_kernel<4, 4, T, SceneArgsEx>); } \
         else { if (nb == 2) launch(raster_scene_bits_kernel<8, 2, T, SceneArgsEx>); else if (nb == 3) launch(raster_scene_bits_kernel<8, 3, T, SceneArgsEx>); else launch(raster_scene_bits_kernel<8, 4, T, SceneArgsEx>); } \
     } while (0)
-                if (out_mode == TDS_OUT_F32) TDS_BITS_DISPATCH(float); else TDS_BITS_DISPATCH(uint8_t);
+                if (cb.slices != nullptr) {
+                    // differentiable calls: float32, four waves; the instantiation that also stores the index slices
+                    if (nwv != 4) { tds::set_error("tds_raster_scene: index slices need the 4-wave bit-plane kernel"); return TDS_ELIMIT; }
+                    if (a.K == 0) { if (nb == 2) launch_b(raster_scene_bits_kernel<4, 2, float, SceneArgs, true>); else if (nb == 3) launch_b(raster_scene_bits_kernel<4, 3, float, SceneArgs, true>); else launch_b(raster_scene_bits_kernel<4, 4, float, SceneArgs, true>); }
+                    else { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, float, SceneArgsEx, true>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, float, SceneArgsEx, true>); else launch(raster_scene_bits_kernel<4, 4, float, SceneArgsEx, true>); }
+                } else if (out_mode == TDS_OUT_F32) TDS_BITS_DISPATCH(float); else TDS_BITS_DISPATCH(uint8_t);
 #undef TDS_BITS_DISPATCH
                 TDS_LAUNCH_CHECK("raster_scene_bits_kernel");
                 return TDS_OK;
             }
         }
+    }
+    if (want_slices) {
+        tds::set_error("tds_raster_scene: index slices are produced by the bit-plane kernel only (at most %d distinct keys, listed by the caller)", MAX_KEYS);
+        return TDS_ELIMIT;
     }
     // general path: bin once per camera (K3a), then rasterise per strip from the lists (K3b)
     if (workspace && !(TDS_DBG(g_debug) & 32) && cm.strips <= MAX_STRIPS) {
@@ -2008,7 +2044,7 @@ TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int
     for (int i = 1; i < n_levels; ++i) TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_raster_mesh: levels must be strictly descending");
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.debug = TDS_DBG(g_debug);
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
     TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
     TDS_LAUNCH_CHECK("raster_mesh_kernel");
     return TDS_OK;

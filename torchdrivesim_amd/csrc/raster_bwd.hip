@@ -16,6 +16,7 @@
 // same integral over every colour boundary of the image (neighbouring pixel pairs), static map included.  NOT produced: gradients
 // with respect to actor sizes (templates) and colours.
 #include "tds_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -249,6 +250,366 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
     if (tid < 4) a.grad_cam[img * 4 + tid] = cam_acc[tid];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The same gradient from the forward's KEY-INDEX SLICES instead of the forward image (tds_raster_aux_t::index_slices: per pixel the
+// 1-based position of the winning key, as bit-slices, 3 % of the image's bytes).  The image is a function of that index alone --
+// I[ch](p) = colour[ch][idx(p)] -- so every term  f (I_B - I_A)  vanishes unless the two pixels differ in idx, and colour boundaries are
+// found 32 pixel pairs at a time by XOR-ing slice words.  The incoming gradient is then read only where a boundary is: 16-byte pieces
+// (four pixels of the output's fastest axis), a row of the image per wave instruction when every lane takes part.
+//   index_slices  uint32 [camera][x / 32][y / 4][slice][y % 4], bit x % 32     (x, y: OpenCV pixel coordinates; out[ch][x][y])
+// One workgroup per camera.  Camera part: a wave owns a slab of 32 columns x, lane = row quad; it walks the columns, keeps the previous
+// column's gradient in registers (pairs along x) and takes the first row of the next quad from the next lane (pairs along y).
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline void wave_sync_bwd() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#ifndef TDS_BWD_ABLATE
+#define TDS_BWD_ABLATE 0      // tuning builds: 1 no actor pass, 2 no cell processing, 4 no cell queue either
+#endif
+
+struct BwdIdxArgs {
+    const float4 *state;
+    const float2 *agent_sc;
+    const float2 *tmpl;
+    const uint8_t *mask;
+    const float2 *cam_xy, *cam_sc;
+    const uint32_t *slices;
+    const float *grad_out;
+    float *grad_agent, *grad_cam;
+    float *grad_color;          // optional: B x Nc x 16 x 4: per key index (0 = background) the sum of the incoming gradient per channel
+    int N, Nc, res, nb;         // nb: slices in use (index bits)
+    float scale;
+    uint32_t keys[16];          // ascending key table of the forward launch
+    int n_keys;
+};
+
+template <int NB>
+__global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxArgs a) {
+    __shared__ float cam_acc[4];
+    __shared__ float4 col_tab[16];                                       // colour of key index i (w unused)
+    // dynamic LDS: per wave the owner records + cell queue of the camera pass; then (only when grad_color is asked for) reused as
+    // [16 keys][3 channels][BW_BLOCK threads] private sums of the colour pass
+    extern __shared__ __attribute__((aligned(16))) float col_priv[];
+    const int64_t img = blockIdx.x;
+    const int64_t b = img / a.Nc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int res = a.res, quads = res >> 2, wprT = (res + 31) >> 5;
+    const float k = a.scale * (float)res * 0.5f, half = (float)res * 0.5f;
+    const float2 cxy = a.cam_xy[img], csc = a.cam_sc[img];
+    const float cs = csc.x, cc = csc.y;
+    const int64_t plane = (int64_t)res * res;
+    const float *G = a.grad_out + img * 3 * plane;
+    const uint32_t *S = a.slices + (size_t)img * wprT * quads * 16;
+    if (tid < 4) cam_acc[tid] = 0.0f;
+    if (tid < 16) {
+        uint32_t key = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) key = (tid == i + 1 && i < a.n_keys) ? a.keys[i] : key;       // a.keys lives in SGPRs
+        col_tab[tid] = make_float4((float)((key >> 16) & 255u), (float)((key >> 8) & 255u), (float)(key & 255u), 0.0f);
+    }
+    __syncthreads();
+    auto idx_at = [&](int x, int y) {
+        const uint32_t *w = S + (((size_t)(x >> 5) * quads + (size_t)(y >> 2)) << 4) + (y & 3);
+        int idx = 0;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) idx |= (int)((w[4 * q] >> (x & 31)) & 1u) << q;
+        return idx;
+    };
+    float gcam[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float view_r = 1.05f * 1.41421356f / a.scale;
+    // ---- actors: the definition of raster_scene_bwd_kernel (same samples, same taps), the two taps of a sample read the key index instead
+    // of the image.  Few of a scene's agents are in a camera's view: thread j culls agent j and the survivors go to an LDS list; a whole
+    // wave then takes one listed agent at a time -- 8 lanes per outline edge, which share the edge's samples -- so that a 33-pixel edge
+    // costs five dependent round trips to memory instead of 33.
+    __shared__ int vis_list[BW_BLOCK];
+    __shared__ int vis_count;
+    for (int j0 = 0; j0 < a.N; j0 += BW_BLOCK) {
+        if (tid == 0) vis_count = 0;
+        __syncthreads();
+        const int jc = j0 + tid;
+        if (jc < a.N) {
+            bool vis = false;
+            if (!(TDS_BWD_ABLATE & 1) && a.mask[img * a.N + jc] != 0) {
+                const int64_t ia = b * a.N + jc;
+                const float4 s = a.state[ia];
+                const float2 t0 = a.tmpl[ia * 7];
+                const float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y) + 2.0f / a.scale;
+                const float ddx = s.x - cxy.x, ddy = s.y - cxy.y;
+                vis = ddx * ddx + ddy * ddy <= reach * reach;
+            }
+            if (vis) vis_list[atomicAdd(&vis_count, 1)] = jc;
+            else *(float4 *)(a.grad_agent + (img * a.N + jc) * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // out of sight or masked
+        }
+        __syncthreads();
+        const int nvis = vis_count;
+        for (int vi = wave; vi < nvis; vi += BW_BLOCK / 64) {
+            const int j = vis_list[vi];
+            const int e = lane >> 3, sl = lane & 7;                       // edge 0..6 (7 idles), position among the edge's 8 lanes
+            float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (e < 7) {
+                const int64_t ia = b * a.N + j;
+                const float4 s = a.state[ia];
+                const float2 sc = a.agent_sc[ia];
+                const float2 t0 = a.tmpl[ia * 7];
+                const int ea = e, eb = e < 4 ? ((e + 1) & 3) : (e == 6 ? 4 : e + 1);
+                const float2 ta = a.tmpl[ia * 7 + ea], tb = a.tmpl[ia * 7 + eb];
+                float2 ctr;
+                if (e < 4) {
+                    const float2 q1 = a.tmpl[ia * 7 + 1], q2 = a.tmpl[ia * 7 + 2], q3 = a.tmpl[ia * 7 + 3];
+                    ctr = make_float2(0.25f * (t0.x + q1.x + q2.x + q3.x), 0.25f * (t0.y + q1.y + q2.y + q3.y));
+                } else {
+                    const float2 q4 = a.tmpl[ia * 7 + 4], q5 = a.tmpl[ia * 7 + 5], q6 = a.tmpl[ia * 7 + 6];
+                    ctr = make_float2((q4.x + q5.x + q6.x) / 3.0f, (q4.y + q5.y + q6.y) / 3.0f);
+                }
+                auto to_rel = [&](float2 t) { return make_float2(sc.y * t.x - sc.x * t.y + s.x - cxy.x, sc.x * t.x + sc.y * t.y + s.y - cxy.y); };
+                auto to_pix = [&](float2 v) { return make_float2(-k * (cc * v.x + cs * v.y) + half, -k * (-cs * v.x + cc * v.y) + half); };
+                const float2 va = to_rel(ta), vb = to_rel(tb), pc = to_pix(to_rel(ctr));
+                float2 pa = to_pix(va), pb = to_pix(vb);
+                pa = make_float2(floorf(pa.x) + 0.5f, floorf(pa.y) + 0.5f);
+                pb = make_float2(floorf(pb.x) + 0.5f, floorf(pb.y) + 0.5f);
+                const float ex = pb.x - pa.x, ey = pb.y - pa.y, len = sqrtf(ex * ex + ey * ey);
+                if (len > 1e-6f && len < 1e5f) {
+                    float nx = ey / len, ny = -ex / len;
+                    if (nx * (0.5f * (pa.x + pb.x) - pc.x) + ny * (0.5f * (pa.y + pb.y) - pc.y) < 0.0f) { nx = -nx; ny = -ny; }
+                    const int ns = max(1, min(4096, (int)ceilf(len)));
+                    const float dl = len / (float)ns;
+                    float A0 = 0.0f, A1 = 0.0f;
+                    for (int si = sl; si < ns; si += 8) {
+                        const float u = ((float)si + 0.5f) / (float)ns;
+                        const float px = pa.x + u * ex, py = pa.y + u * ey;
+                        const float xi = floorf(px - SIDE_IN * nx), yi = floorf(py - SIDE_IN * ny), xo = floorf(px + SIDE_OUT * nx), yo = floorf(py + SIDE_OUT * ny);
+                        if (xi < 0.0f || yi < 0.0f || xo < 0.0f || yo < 0.0f || xi >= (float)res || yi >= (float)res || xo >= (float)res || yo >= (float)res)
+                            continue;
+                        const int ki = idx_at((int)xi, (int)yi), ko = idx_at((int)xo, (int)yo);
+                        if (ki == ko) continue;
+                        const float4 ci = col_tab[ki], co = col_tab[ko];
+                        const int64_t oi = (int64_t)xi * res + (int64_t)yi, oo = (int64_t)xo * res + (int64_t)yo;
+                        const float D = 0.5f * (G[oi] + G[oo]) * (ci.x - co.x) + 0.5f * (G[plane + oi] + G[plane + oo]) * (ci.y - co.y) +
+                                        0.5f * (G[2 * plane + oi] + G[2 * plane + oo]) * (ci.z - co.z);
+                        const float wgt = D * dl;
+                        A0 += wgt * (1.0f - u); A1 += wgt * u;
+                    }
+                    // the edge's samples were shared by 8 lanes
+                    A0 += __shfl_xor(A0, 1); A0 += __shfl_xor(A0, 2); A0 += __shfl_xor(A0, 4);
+                    A1 += __shfl_xor(A1, 1); A1 += __shfl_xor(A1, 2); A1 += __shfl_xor(A1, 4);
+                    auto nM = [&](float qx, float qy) { return -k * (nx * (cc * qx + cs * qy) + ny * (-cs * qx + cc * qy)); };
+                    const float At = A0 + A1;
+                    const float Tx = A0 * ta.x + A1 * tb.x, Ty = A0 * ta.y + A1 * tb.y;
+                    if (sl == 0) {
+                        g[0] = At * nM(1.0f, 0.0f);
+                        g[1] = At * nM(0.0f, 1.0f);
+                        g[2] = nM(-Ty, Tx);
+                        g[3] = nM(Tx, Ty);
+                    }
+                }
+            }
+            // sum the seven edges (their first lanes hold the values, every other lane holds zero)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                for (int d = 1; d < 64; d <<= 1) g[q] += __shfl_xor(g[q], d);
+            if (lane == 0) *(float4 *)(a.grad_agent + (img * a.N + j) * 4) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+    }
+    // ---- camera: every colour boundary of the image (see raster_scene_bwd_kernel for the formulas)
+    // Only about one in seven (quad, column) cells of a Town01 view touches a boundary, but nine columns in ten do somewhere along their
+    // 256 rows: walking the columns with a lane per quad would keep the wave busy on empty cells.  Instead every lane lists the columns of
+    // its quad that hold the FIRST pixel of a differing pair -- (x, y)-(x+1, y) or (x, y)-(x, y+1) -- into a per-wave LDS queue, the slice
+    // words go to LDS beside it, and the wave then takes the queued cells 64 at a time, whoever they belong to.
+    {
+        float Sx = 0.0f, Sy = 0.0f, Cc = 0.0f, Cs = 0.0f;
+        constexpr int OWN_DW = (NB * 5 + 1 + 3) & ~3;                         // per quad: its NB x 4 slice words, row 0 of the quad below, bit 0 of the next word column (16-byte records)
+        uint32_t *wl = (uint32_t *)col_priv + wave * (64 * OWN_DW + 1024);    // per wave: 64 owner records, then up to 2048 cells as uint16
+        unsigned short *cells = (unsigned short *)(wl + 64 * OWN_DW);
+        const int qblocks = (quads + 63) >> 6;
+        for (int slab = wave; slab < wprT * qblocks; slab += BW_BLOCK / 64) {
+            const int xw = slab / qblocks, rq0 = (slab - xw * qblocks) * 64, rq = rq0 + lane;
+            const bool live = rq < quads;
+            const int xbase = xw * 32;
+            const int ncol = min(32, res - xbase);                      // columns of this word that exist
+            const bool has_next_word = xw + 1 < wprT;
+            uint32_t s[NB][4], nxt = 0, below[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                uint4 v = make_uint4(0, 0, 0, 0), vn = make_uint4(0, 0, 0, 0);
+                if (live) {
+                    v = *(const uint4 *)(S + (((size_t)xw * quads + (size_t)rq) << 4) + 4 * q);
+                    if (has_next_word) vn = *(const uint4 *)(S + (((size_t)(xw + 1) * quads + (size_t)rq) << 4) + 4 * q);
+                }
+                s[q][0] = v.x; s[q][1] = v.y; s[q][2] = v.z; s[q][3] = v.w;
+                nxt |= ((vn.x & 1u) | ((vn.y & 1u) << 1) | ((vn.z & 1u) << 2) | ((vn.w & 1u) << 3)) << (4 * q);
+            }
+            const bool has_below = live && rq + 1 < quads;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                below[q] = (uint32_t)__shfl_down((int)s[q][0], 1);
+                if (lane == 63 && has_below) below[q] = S[(((size_t)xw * quads + (size_t)(rq + 1)) << 4) + 4 * q];
+            }
+            const uint32_t colmask = ncol == 32 ? 0xffffffffu : ((1u << ncol) - 1u);
+            uint32_t xvalid = colmask >> 1;                               // pair (x, x+1) inside this word's existing columns ...
+            if (has_next_word && ncol == 32) xvalid |= 0x80000000u;       // ... or reaching into the next word
+            uint32_t m = 0;                                               // bit x: some pair starting in column x of this quad differs
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t dx = 0, dy = 0;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    dx |= s[q][j] ^ ((s[q][j] >> 1) | (((nxt >> (4 * q + j)) & 1u) << 31));
+                    dy |= s[q][j] ^ (j < 3 ? s[q][j + 1] : below[q]);
+                }
+                m |= (dx & xvalid) | ((j < 3 || has_below) ? (dy & colmask) : 0u);
+            }
+            if (!live || (TDS_BWD_ABLATE & 4)) m = 0;
+            // owner records and the queue of cells
+            wave_sync_bwd();
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wl[lane * OWN_DW + q * 4 + j] = s[q][j];
+                wl[lane * OWN_DW + NB * 4 + q] = below[q];
+            }
+            wl[lane * OWN_DW + NB * 4 + NB] = nxt;
+            int cnt = __popc(m), incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            const int total = __shfl(incl, 63);
+            int pos = incl - cnt;
+            while (m) {
+                const int x = __ffs((int)m) - 1;
+                m &= m - 1;
+                cells[pos++] = (unsigned short)((lane << 5) | x);
+            }
+            wave_sync_bwd();
+            for (int base = 0; base < ((TDS_BWD_ABLATE & 2) ? 0 : total); base += 64) {
+                const int it = base + lane;
+                if (it >= total) continue;
+                const int cell = cells[it], o = cell >> 5, x = cell & 31;
+                const uint32_t *rec = wl + o * OWN_DW;
+                const int rqo = rq0 + o, y0 = rqo * 4;
+                int i0[4], i1[4], ib = 0;
+                const uint32_t nx = rec[NB * 4 + NB];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { i0[j] = 0; i1[j] = 0; }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const uint4 w4 = *(const uint4 *)(rec + 4 * q);           // records are 16-byte aligned
+                    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        i0[j] |= (int)((w[j] >> x) & 1u) << q;
+                        i1[j] |= (int)(x < 31 ? ((w[j] >> (x + 1)) & 1u) : ((nx >> (4 * q + j)) & 1u)) << q;
+                    }
+                    ib |= (int)((rec[NB * 4 + q] >> x) & 1u) << q;
+                }
+                const bool xok = xbase + x + 1 < res && (x < 31 || has_next_word), bok = rqo + 1 < quads;
+                const float *gp = G + (int64_t)(xbase + x) * res + y0;
+                const float4 a0 = *(const float4 *)gp, a1 = *(const float4 *)(gp + plane), a2 = *(const float4 *)(gp + 2 * plane);
+                const float g0[4][3] = {{a0.x, a1.x, a2.x}, {a0.y, a1.y, a2.y}, {a0.z, a1.z, a2.z}, {a0.w, a1.w, a2.w}};
+                const bool anyx = xok && (i0[0] != i1[0] || i0[1] != i1[1] || i0[2] != i1[2] || i0[3] != i1[3]);
+                float4 c0[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c0[j] = col_tab[i0[j]];
+                if (anyx) {
+                    const float4 b0 = *(const float4 *)(gp + res), b1 = *(const float4 *)(gp + res + plane), b2 = *(const float4 *)(gp + res + 2 * plane);
+                    const float g1[4][3] = {{b0.x, b1.x, b2.x}, {b0.y, b1.y, b2.y}, {b0.z, b1.z, b2.z}, {b0.w, b1.w, b2.w}};
+                    const float dx = (float)(xbase + x + 1) - half;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (i0[j] == i1[j]) continue;
+                        const float4 c1 = col_tab[i1[j]];
+                        const float D = 0.5f * (g0[j][0] + g1[j][0]) * (c1.x - c0[j].x) + 0.5f * (g0[j][1] + g1[j][1]) * (c1.y - c0[j].y) +
+                                        0.5f * (g0[j][2] + g1[j][2]) * (c1.z - c0[j].z);
+                        const float dy = (float)(y0 + j) + 0.5f - half;
+                        Sx += D; Cc += D * (cc * dx - cs * dy); Cs += D * (cs * dx + cc * dy);
+                    }
+                }
+                const float dxr = (float)(xbase + x) + 0.5f - half;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (i0[j] == i0[j + 1]) continue;
+                    const float D = 0.5f * (g0[j][0] + g0[j + 1][0]) * (c0[j + 1].x - c0[j].x) + 0.5f * (g0[j][1] + g0[j + 1][1]) * (c0[j + 1].y - c0[j].y) +
+                                    0.5f * (g0[j][2] + g0[j + 1][2]) * (c0[j + 1].z - c0[j].z);
+                    const float dy = (float)(y0 + j + 1) - half;
+                    Sy += D; Cc += D * (cs * dxr + cc * dy); Cs += -D * (cc * dxr - cs * dy);
+                }
+                if (bok && i0[3] != ib) {
+                    const float4 cb = col_tab[ib];
+                    const float D = 0.5f * (g0[3][0] + gp[4]) * (cb.x - c0[3].x) + 0.5f * (g0[3][1] + gp[plane + 4]) * (cb.y - c0[3].y) +
+                                    0.5f * (g0[3][2] + gp[2 * plane + 4]) * (cb.z - c0[3].z);
+                    const float dy = (float)(y0 + 4) - half;
+                    Sy += D; Cc += D * (cs * dxr + cc * dy); Cs += -D * (cc * dxr - cs * dy);
+                }
+            }
+        }
+        gcam[0] = -k * (cc * Sx - cs * Sy);
+        gcam[1] = -k * (cs * Sx + cc * Sy);
+        gcam[2] = -Cs;
+        gcam[3] = -Cc;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = gcam[q];
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if ((tid & 63) == 0) atomicAdd(&cam_acc[q], v);
+    }
+    __syncthreads();
+    if (tid < 4) a.grad_cam[img * 4 + tid] = cam_acc[tid];
+    // ---- colours (optional): dL/dcolour[key][ch] = sum of the incoming gradient over the pixels that show the key -- exact, the image
+    // being colour[key index] pixel by pixel.  This pass reads the whole gradient.  Every thread sums runs of equal index along x in
+    // registers and adds finished runs to its private column of an LDS table (no atomics: the order of the additions is fixed).
+    if (a.grad_color != nullptr) {
+        __syncthreads();                                                 // the camera pass is done with the LDS it shares
+        for (int e = tid; e < 48 * BW_BLOCK; e += BW_BLOCK) col_priv[e] = 0.0f;
+        const int qblocks = (quads + 63) >> 6;
+        for (int slab = wave; slab < wprT * qblocks; slab += BW_BLOCK / 64) {
+            const int xw = slab / qblocks, rq = (slab - xw * qblocks) * 64 + lane;
+            if (rq >= quads) continue;
+            const int y0 = rq * 4, xbase = xw * 32, ncol = min(32, res - xbase);
+            uint32_t s[NB][4];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const uint4 v = *(const uint4 *)(S + (((size_t)xw * quads + (size_t)rq) << 4) + 4 * q);
+                s[q][0] = v.x; s[q][1] = v.y; s[q][2] = v.z; s[q][3] = v.w;
+            }
+            int run[4] = {0, 0, 0, 0};
+            float acc[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            for (int x = 0; x < ncol; ++x) {
+                const float *gp = G + (int64_t)(xbase + x) * res + y0;
+                const float4 g0 = *(const float4 *)gp, g1 = *(const float4 *)(gp + plane), g2 = *(const float4 *)(gp + 2 * plane);
+                const float gv[4][3] = {{g0.x, g1.x, g2.x}, {g0.y, g1.y, g2.y}, {g0.z, g1.z, g2.z}, {g0.w, g1.w, g2.w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int v = 0;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) v |= (int)((s[q][j] >> x) & 1u) << q;
+                    if (v != run[j]) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { col_priv[(run[j] * 3 + ch) * BW_BLOCK + tid] += acc[j][ch]; acc[j][ch] = 0.0f; }
+                        run[j] = v;
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[j][ch] += gv[j][ch];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) col_priv[(run[j] * 3 + ch) * BW_BLOCK + tid] += acc[j][ch];
+        }
+        __syncthreads();
+        // 48 rows of BW_BLOCK partial sums: one wave per row, four values per lane, then a butterfly
+        for (int row = wave; row < 48; row += BW_BLOCK / 64) {
+            float v = 0.0f;
+            for (int e = lane; e < BW_BLOCK; e += 64) v += col_priv[row * BW_BLOCK + e];
+            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+            if (lane == 0) a.grad_color[img * 64 + (row / 3) * 4 + (row % 3)] = v;
+        }
+        if (tid < 16) a.grad_color[img * 64 + tid * 4 + 3] = 0.0f;
+    }
+}
+
 }  // namespace
 
 TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
@@ -268,5 +629,34 @@ TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_s
     a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
     hipLaunchKernelGGL(raster_scene_bwd_kernel, dim3((unsigned)n_img), dim3(BW_BLOCK), 0, (hipStream_t)stream, a);
     TDS_LAUNCH_CHECK("raster_scene_bwd_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
+                                            const float *cam_sc, const uint32_t *index_slices, const uint32_t *keys, int n_keys, const float *grad_out,
+                                            int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent, float *grad_cam, float *grad_color, void *stream) {
+    TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene_bwd_idx_f32: bad sizes");
+    TDS_CHECK_ARG(res > 0 && res <= 4096 && (res & 3) == 0, "tds_raster_scene_bwd_idx_f32: the resolution must be a multiple of 4");
+    TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene_bwd_idx_f32: scale must be positive");
+    TDS_CHECK_ARG(keys && n_keys >= 1 && n_keys <= 15, "tds_raster_scene_bwd_idx_f32: the key table of the forward launch (1..15 keys) is required");
+    const int64_t n_img = B * Nc;
+    if (n_img == 0) return TDS_OK;
+    TDS_CHECK_ARG(n_img < (1ll << 31), "tds_raster_scene_bwd_idx_f32: too many cameras");
+    TDS_CHECK_ARG(cam_xy && cam_sc && index_slices && grad_out && grad_cam, "tds_raster_scene_bwd_idx_f32: null array");
+    TDS_CHECK_ARG(N == 0 || (state && agent_sc && tmpl && mask && grad_agent), "tds_raster_scene_bwd_idx_f32: null agent array");
+    BwdIdxArgs a;
+    a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl; a.mask = mask;
+    a.cam_xy = (const float2 *)cam_xy; a.cam_sc = (const float2 *)cam_sc; a.slices = index_slices; a.grad_out = grad_out;
+    a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.grad_color = grad_color; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
+    a.n_keys = n_keys;
+    for (int i = 0; i < 16; ++i) a.keys[i] = i < n_keys ? keys[i] : 0u;
+    a.nb = n_keys <= 3 ? 2 : (n_keys <= 7 ? 3 : 4);                 // as bits_index_bits of the forward
+    // camera pass: per wave 64 owner records (NB * 5 + 1 words each, padded to 16 bytes) + 2048 uint16 cells; colour pass: 48 x BW_BLOCK floats
+    const size_t lds_cam = (size_t)(BW_BLOCK / 64) * (64 * ((a.nb * 5 + 1 + 3) & ~3) + 1024) * sizeof(uint32_t);
+    const size_t lds = std::max(lds_cam, grad_color ? (size_t)48 * BW_BLOCK * sizeof(float) : (size_t)0);
+    if (a.nb == 2) hipLaunchKernelGGL(raster_scene_bwd_idx_kernel<2>, dim3((unsigned)n_img), dim3(BW_BLOCK), lds, (hipStream_t)stream, a);
+    else if (a.nb == 3) hipLaunchKernelGGL(raster_scene_bwd_idx_kernel<3>, dim3((unsigned)n_img), dim3(BW_BLOCK), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(raster_scene_bwd_idx_kernel<4>, dim3((unsigned)n_img), dim3(BW_BLOCK), lds, (hipStream_t)stream, a);
+    TDS_LAUNCH_CHECK("raster_scene_bwd_idx_kernel");
     return TDS_OK;
 }
