@@ -202,13 +202,16 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  *                 TDS_ELIMIT -- and receives, per pixel, the 1-based position of the winning key in `keys` (0 = background) as bit-slices:
  *                 uint32 [camera][x / 32][y / 4][slice 0..3][y % 4], bit x % 32; 64 B per (word column, row quad), slices >= index_bits
  *                 unwritten.  x, y = OpenCV pixel coordinates = the last two axes of `out`.
- *   keys, n_keys, index_bits   filled by the call (HOST): the ascending key table of the launch (n_keys = 0 when another kernel ran) */
+ *   keys, n_keys, index_bits   filled by the call (HOST): the ascending key table of the launch (n_keys = 0 when another kernel ran)
+ *   flags         input: TDS_RASTER_NO_TRIM draws every face as the reference does with trim_mesh_before_rendering = False */
+#define TDS_RASTER_NO_TRIM 1   /* trim_mesh_before_rendering = False (rendering/cv2.py:15,32-41): keep faces without a vertex in view */
 typedef struct tds_raster_aux {
     uint32_t *index_slices;
     int64_t index_slices_bytes;
     uint32_t keys[16];
     int32_t n_keys;
     int32_t index_bits;
+    int32_t flags;              /* in: TDS_RASTER_* */
 } tds_raster_aux_t;
 int tds_raster_index_slices_bytes(int64_t n_img, int res, int64_t *bytes);
 
@@ -251,10 +254,11 @@ int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, cons
 /* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
  *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,
  *   levels: n_levels HOST floats sorted descending containing every z in use (<= 255)
- *   out   n_img x 3 x H x W  (CHW, i.e. already permuted as render_frame returns it, base.py:202-203) */
+ *   out   n_img x 3 x H x W  (CHW, i.e. already permuted as render_frame returns it, base.py:202-203)
+ *   flags TDS_RASTER_* (0: the trim rule of cv2.py:32-41 is applied) */
 int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces, int64_t n_img, int64_t V, int64_t F,
                     const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,
-                    int out_mode, void *out, void *stream);
+                    int out_mode, void *out, int flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Wrong-way query           simulator.py:607-630 (compute_wrong_way); infractions.py:232-304 (lanelet_orientation_loss);

@@ -259,6 +259,11 @@ def occlusion_mask(state, size, present, n_exposed):
     return out.astype(bool)
 
 
+def set_trim_mesh(on: bool):
+    """CV2RendererConfig.trim_mesh_before_rendering (cv2.py:15) for every render call that follows"""
+    lib().orc_set_trim_mesh(ctypes.c_int(1 if on else 0))
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(ctypes.c_int(int(n)))
 

@@ -713,6 +713,11 @@ static void quantise_color(const float *attr, float col[3], uint32_t *packed) { 
     }
 }
 
+/* CV2RendererConfig.trim_mesh_before_rendering (cv2.py:15): 1 = mesh.trim(viewing_polygon) before drawing (cv2.py:32-41, the default),
+ * 0 = every face goes to fillConvexPoly.  A process-wide switch of the oracle (test infrastructure). */
+static int g_trim_mesh = 1;
+ORC_API void orc_set_trim_mesh(int on) { g_trim_mesh = on; }
+
 /* CV2Renderer.render_rgb_mesh, rendering/cv2.py:27-70, for ONE image.
  * verts V x 3 (x,y,z), attrs V x 3 in [0,1], faces F x 3, camera (cx,cy,sin,cos).
  * image: H x W x 3 float, ALREADY transposed as the reference returns it: image[px][py][ch].
@@ -733,7 +738,7 @@ ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, 
     int64_t nk = 0;
     for (int64_t f = 0; f < F; ++f) {                                 /* mesh.trim: keep iff >= 1 vertex inside */
         const int32_t *fv = faces + 3 * f;
-        if (ins[fv[0]] || ins[fv[1]] || ins[fv[2]]) {
+        if (!g_trim_mesh || ins[fv[0]] || ins[fv[1]] || ins[fv[2]]) {
             float tmpc[3];
             order[nk].z = verts[3 * fv[0] + 2]; order[nk].f = (int32_t)f;
             quantise_color(attrs + 3 * fv[0], tmpc, &order[nk].rgb);

@@ -389,6 +389,49 @@ def render_both(ops, oracle, smap, static, state, size, mask, cam_xy, cam_sc, fo
     return img.cpu().numpy(), ref
 
 
+@pytest.mark.parametrize('bits', [True, False])
+def test_k3_untrimmed_rendering_equals_the_oracle(ops, oracle, town, bits):
+    """CV2RendererConfig(trim_mesh_before_rendering=False), cv2.py:15,32-41: faces without a vertex in the view are drawn too -- long
+    triangles that cross the image.  A hand-made map of huge triangles (which the trim rule drops entirely) over a crop of Town01."""
+    gen = np.random.default_rng(41)
+    B, A, res, fov = 2, 5, 128, 35.0
+    crop = np.linalg.norm(town['verts'][town['faces']].mean(1) - np.array([100.0, 60.0]), axis=1) < 60
+    faces = town['faces'][crop]
+    used, inv = np.unique(faces, return_inverse=True)
+    verts, vcat = town['verts'][used], town['vert_category'][used]
+    faces = inv.reshape(-1, 3).astype(np.int32)
+    big = np.array([[-400, -300], [600, -250], [150, 700], [-350, 500], [700, 400], [90, 55]], np.float32) + np.float32(0.25)
+    nv = len(verts)
+    verts = np.concatenate([verts, big]).astype(np.float32)
+    vcat = np.concatenate([vcat, np.full(len(big), town['categories'].index('road'), vcat.dtype)])
+    faces = np.concatenate([np.array([[nv, nv + 1, nv + 2], [nv + 3, nv + 4, nv + 5]], np.int32), faces])
+    smap = make_map(ops, verts, faces, vcat, town['categories'])
+    static = oracle_static(oracle, verts, faces, vcat, town['categories'])
+    xy = np.array([100.0, 60.0]) + gen.uniform(-30, 30, (B, A, 2))
+    st = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
+    sz = np.tile(np.array([4.5, 2.0], np.float32), (B, A, 1))
+    mask = np.ones((B, A, A), bool)
+    cam_sc = sc_np(ops.heading_sc(dev(st)[..., 2]))
+    sd = dev(st)
+    args = (smap, sd, ops.heading_sc(sd[..., 2]), dev(oracle.actor_template(sz)), actor_keys(smap, B, A), dev(mask), dev(st[..., :2].copy()), dev(cam_sc), fov, res)
+    ops.use_bitplanes = bits
+    try:
+        trimmed = ops.raster_scene(*args).cpu().numpy()
+        untrimmed = ops.raster_scene(*args, trim=False).cpu().numpy()
+    finally:
+        ops.use_bitplanes = True
+    sv, sa, sf = static
+    ref_t = oracle.render_scenes(st, sz, mask, st[..., :2].copy(), cam_sc, sv, sa, sf, fov, res, agent_sc=cam_sc)
+    oracle.set_trim_mesh(False)
+    try:
+        ref_u = oracle.render_scenes(st, sz, mask, st[..., :2].copy(), cam_sc, sv, sa, sf, fov, res, agent_sc=cam_sc)
+    finally:
+        oracle.set_trim_mesh(True)
+    np.testing.assert_array_equal(trimmed, ref_t)
+    np.testing.assert_array_equal(untrimmed, ref_u)
+    assert (ref_u != ref_t).mean() > 0.05                         # the huge triangles fill the background only when nothing is trimmed
+
+
 def test_k3_golden_scenes_bit_exact(ops, oracle, town, testing_lib):
     g = load_golden('g45_mesh_preraster.npz')
     for m in json.loads(str(g['g5_meta'])):

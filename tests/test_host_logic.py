@@ -233,8 +233,7 @@ def test_a_configuration_for_the_opencv_backend_selects_the_rasteriser():
     r = renderer_from_config(CV2RendererConfig(left_handed_coordinates=True))
     assert isinstance(r, HipRenderer) and r.cfg.left_handed_coordinates and r.cfg.out_dtype == 'float32'
     assert isinstance(renderer_from_config(RendererConfig()), HipRenderer)          # backend 'default'
-    with pytest.raises(NotImplementedError):
-        renderer_from_config(CV2RendererConfig(trim_mesh_before_rendering=False))
+    assert r.trim and not renderer_from_config(CV2RendererConfig(trim_mesh_before_rendering=False)).trim       # cv2.py:15, honoured since round 2
 
 
 def test_heading_cache_follows_the_live_state():

@@ -19,6 +19,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 
 METRIC_IOU, METRIC_DISCS = 0, 1
 OUT_F32, OUT_U8 = 0, 1
+RASTER_NO_TRIM = 1
 
 _lib = None
 
@@ -26,7 +27,7 @@ _lib = None
 class RasterAux(ctypes.Structure):
     """tds_raster_aux_t (include/tdship.h): optional outputs of tds_raster_scene for a later backward pass"""
     _fields_ = [('index_slices', ctypes.c_void_p), ('index_slices_bytes', ctypes.c_int64), ('keys', ctypes.c_uint32 * 16),
-                ('n_keys', ctypes.c_int32), ('index_bits', ctypes.c_int32)]
+                ('n_keys', ctypes.c_int32), ('index_bits', ctypes.c_int32), ('flags', ctypes.c_int32)]
 
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
@@ -63,7 +64,7 @@ _SIGNATURES = {
     'tds_raster_scene_bwd_idx_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
     'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp],
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
-    'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp],
+    'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _i32, _vp],
     'tds_lanelet_centerline_f64': [_vp, _i32, _vp, _i32, _vp, ctypes.POINTER(_i32)],
     'tds_lanes_create': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, ctypes.POINTER(_vp)],
     'tds_lanes_destroy': [_vp],

@@ -431,7 +431,7 @@ raster_bwd_events = None
 
 
 def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None,
-                 extra_tri=None, extra_key=None, index_slices=False):
+                 extra_tri=None, extra_key=None, index_slices=False, trim=True):
     """Fused Simulator.render: state (B,N,4), agent_sc (B,N,2), tmpl (B,N,7,2), actor_key (B,N,2) int32 bit patterns -- or (B,Nc,N,2)
     when every camera sees its own colours (custom_agent_colors) --, mask (B,Nc,N) bool/uint8, cam_xy / cam_sc (B,Nc,2)
     -> (B,Nc,3,res,res) float32 [0,255] or uint8.  extra_tri (B,Nc,K,3,2) world-space triangles with keys extra_key (B,Nc,K) int32
@@ -483,6 +483,9 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
         nat.call('tds_raster_index_slices_bytes', dev, B * Nc, int(res), ctypes.byref(nbytes))
         slices = torch.empty(nbytes.value // 4, dtype=i32, device=dev)
         aux = nat.RasterAux(index_slices=slices.data_ptr(), index_slices_bytes=nbytes.value)
+    if not trim:
+        aux = aux if aux is not None else nat.RasterAux()
+        aux.flags = nat.RASTER_NO_TRIM
     head = ('tds_raster_scene_multi', dev, smap.handle, nat.dev_ptr(smap.scene_map, i32, 'scene_map')) if multi else ('tds_raster_scene', dev, smap.handle)
     def launch(aux):
         nat.call(*head, p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'),
@@ -499,13 +502,14 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     except RuntimeError as e:
         if aux is None or 'index slices' not in str(e):
             raise
-        aux = slices = None                 # more than 15 keys, or planes too large: another kernel serves the call, without slices
-        launch(None)
+        slices = None                       # more than 15 keys, or planes too large: another kernel serves the call, without slices
+        aux = None if trim else nat.RasterAux(flags=nat.RASTER_NO_TRIM)
+        launch(aux)
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         raster_events.append(ev)
     if index_slices:
-        if aux is None or aux.n_keys == 0:
+        if slices is None or aux is None or aux.n_keys == 0:
             return out, None, None
         return out, slices, [int(aux.keys[i]) for i in range(aux.n_keys)]
     return out
@@ -519,11 +523,11 @@ class _RasterScene(torch.autograd.Function):
     to colour boundaries only; otherwise the forward image is kept and tds_raster_scene_bwd_f32 streams image and gradient in full."""
 
     @staticmethod
-    def forward(ctx, state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key, color_keys):
+    def forward(ctx, state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key, color_keys, trim):
         out, slices, keys = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table,
-                                         extra_tri=extra_tri, extra_key=extra_key, index_slices=True) if use_index_slices else \
+                                         extra_tri=extra_tri, extra_key=extra_key, index_slices=True, trim=trim) if use_index_slices else \
             (raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table, extra_tri=extra_tri,
-                          extra_key=extra_key), None, None)
+                          extra_key=extra_key, trim=trim), None, None)
         if slices is not None:
             ctx.save_for_backward(state, agent_sc, cam_xy, cam_sc, tmpl, mask, slices)
         else:
@@ -582,20 +586,20 @@ class _RasterScene(torch.autograd.Function):
             rows = torch.tensor([pos.get(k, -1) for k in ctx.color_keys], device=dev)
             g_key_colors = torch.where((rows >= 0)[:, None], per_key[rows.clamp(min=0)], torch.zeros((), device=dev))
         return (g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), g_key_colors,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None, extra_tri=None, extra_key=None,
-                      key_colors=None, color_keys=None):
+                      key_colors=None, color_keys=None, trim=True):
     """raster_scene with a backward pass (float32 output only; the per-camera triangles get no gradient).
     key_colors (K,3) float tensor + color_keys (K packed keys): a handle for COLOUR gradients -- row r stands for the colour the image shows
     where key color_keys[r] wins; the forward takes its pixels from the keys' own RGB bits (the caller keeps the two consistent), the
     backward returns d loss / d key_colors[r] = the sum of the incoming gradient over those pixels, all cameras (exact)."""
     return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, float(fov), int(res), key_table, extra_tri,
-                              extra_key, color_keys)
+                              extra_key, color_keys, bool(trim))
 
 
-def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32):
+def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32, trim=True):
     """Generic render_rgb_mesh: verts (n,V,3), attrs (n,V,3), faces (n,F,3) -> (n,3,res,res)"""
     n = cam_xy.shape[0]
     dev = cam_xy.device
@@ -606,7 +610,8 @@ def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dty
     nat.call('tds_raster_mesh', dev, nat.dev_ptr(verts, f32, 'verts'), nat.dev_ptr(attrs, f32, 'attrs'), nat.dev_ptr(faces, i32, 'faces'),
              n, verts.shape[1], faces.shape[1], nat.dev_ptr(cam_xy, f32, 'cam_xy'), nat.dev_ptr(cam_sc, f32, 'cam_sc'),
              ctypes.cast(lv, ctypes.c_void_p), len(levels), float(scale), int(res),
-             nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8, nat.dev_ptr(out, out_dtype, 'out'), nat.stream_ptr(dev))
+             nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8, nat.dev_ptr(out, out_dtype, 'out'), 0 if trim else nat.RASTER_NO_TRIM,
+             nat.stream_ptr(dev))
     return out
 
 

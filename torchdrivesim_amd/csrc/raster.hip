@@ -80,6 +80,7 @@ struct CommonArgs {
     int strips;
     int64_t n_img;
     void *out;
+    int no_trim;                // trim_mesh_before_rendering = False (cv2.py:15,32): faces are kept whether or not a vertex is in view
     uint32_t *slices;           // optional: bit-slices of the winning key index per pixel, kept for the backward pass (bit-plane kernel
                                 // only; layout in include/tdship.h, tds_raster_aux_t)
     int debug;                  // ablation switches for profiling (tds_raster_set_debug): 1 no static, 2 no actors, 4 no store,
@@ -494,7 +495,7 @@ __device__ __forceinline__ void process_batch(WaveCtx &w, int n) {
 // (>= 1 vertex inside the 1.05x view polygon, cv2.py:32-41).  The cheap exact rejection comes first.
 // `ins` receives one bit per vertex that passed the trim test.
 __device__ inline bool trim_project(const Camera &cam, float scale, int res, int X0, int TW, const float *sx, const float *sy,
-                                    int *px, int *py, unsigned &ins) {
+                                    int *px, int *py, unsigned &ins, int no_trim = 0) {
     ins = 0;
     float fx[3], fy[3];
 #pragma unroll
@@ -502,6 +503,9 @@ __device__ inline bool trim_project(const Camera &cam, float scale, int res, int
     int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
     int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
     if (xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res) return false;
+    // untrimmed (cv2.py:32 off): every face goes to fillConvexPoly; one whose pixel bounding box misses the image paints nothing, the others
+    // are all candidates of the scan (a triangle that meets the window lies over a scanned grid cell)
+    if (no_trim) { ins = 7u; return true; }
     // The trim polygon is the image square scaled by 1.05 about its centre, i.e. pixel coordinates in [-0.025 res, 1.025 res]^2.
     // The two fp32 formulations (pixel coordinates here, the reference's half-plane tests in world coordinates) agree to well
     // below 1e-2 pixel, so only vertices within `band` of the border need the reference's own test (NaNs end up there too).
@@ -818,7 +822,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
                                              ((sc.y * tc.x + (-sc.x) * tc.y) + s.x) + (-cam.cx)};
                         const float fy[3] = {((sc.x * ta.x + sc.y * ta.y) + s.y) + (-cam.cy), ((sc.x * tb.x + sc.y * tb.y) + s.y) + (-cam.cy),
                                              ((sc.x * tc.x + sc.y * tc.y) + s.y) + (-cam.cy)};
-                        acc = trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
+                        acc = trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins, c.no_trim);
                         edges = edge_mask(f == 1 ? 2u : 0u, ins);      // body faces [0,1,3] and [1,3,2] share the edge 1-3 (edge 1 of the second)
                     }
                 }
@@ -837,7 +841,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
             float2 t0 = a.tmpl[b * a.N * 7];
             float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
             float fx[3] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[3] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
-            acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
+            acc = (lane == 0) && trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins, c.no_trim);
             key = a.actor_key[2 * (a.key_per_cam ? img * a.N : b * a.N)];
         }
         st.phase = 2;
@@ -853,7 +857,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
                 const float2 *v = (const float2 *)a.extra_tri + (img * a.K + t) * 3;
                 const float2 va = v[0], vb = v[1], vc = v[2];
                 const float fx[3] = {va.x + (-cam.cx), vb.x + (-cam.cx), vc.x + (-cam.cx)}, fy[3] = {va.y + (-cam.cy), vb.y + (-cam.cy), vc.y + (-cam.cy)};
-                acc = trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins);
+                acc = trim_project(cam, c.scale, res, X0, TWw, fx, fy, px, py, ins, c.no_trim);
                 edges = edge_mask(0u, ins);
             }
         }
@@ -883,7 +887,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
                 float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
                 float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
                 key = u1.z;
-                acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins);
+                acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins, c.no_trim);
                 edges = edge_mask(own >> 29, ins);
             }
         }
@@ -1011,7 +1015,7 @@ constexpr int BITS_WAVE_LDS_DW = Q_DW + 64 + 2 * EQCAP;   // per wave: face queu
 struct KeyTable { uint32_t key[16]; int n; };      // ascending = painter order (later wins)
 
 struct BitCtx {
-    uint32_t *planes;   // [K][H][wpr]
+    uint32_t *planes;   // [K][wpr][H]: plane, word column, row (see paint_span_bits)
     uint32_t *q;        // [4][QCAP]: plane index, then the three packed vertices
     uint32_t *slots;    // [64] owner markers of wave_owner()
     uint32_t *eq;       // [2][EQCAP] ring of outline edges waiting to be drawn: end points + plane index (pack_xyk)
@@ -1023,16 +1027,19 @@ __device__ __forceinline__ uint32_t pack_xyk(int x, int y, uint32_t k2) { return
 __device__ __forceinline__ int unpack_xk(uint32_t p) { return (int)(p << 15) >> 17; }
 __device__ __forceinline__ int unpack_yk(uint32_t p) { return (int)p >> 17; }
 
-// bits [s0, s1] (strip-local columns) of one row of one plane
-__device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int s0, int s1) {
+// bits [s0, s1] (strip-local columns) of one row of one plane.  Layout: plane[k][word column][row] -- the rows of a word column are
+// consecutive dwords, so the lanes that paint neighbouring row chunks of one face (same word column, rows 4 apart) fall on different LDS
+// banks (the row-major layout put them 32 dwords apart: one bank), and the write-out reads 4 rows of a word with one ds_read_b128.
+// `rowp` points at (word column 0, row y); the words of a row are H dwords apart.
+__device__ __forceinline__ void paint_span_bits(uint32_t *rowp, int H, int s0, int s1) {
     const int w0 = s0 >> 5, w1 = s1 >> 5;
     const uint32_t m0 = 0xffffffffu << (s0 & 31), m1 = 0xffffffffu >> (31 - (s1 & 31));
-    atomicOr(rowp + w0, w0 == w1 ? (m0 & m1) : m0);
+    atomicOr(rowp + __umul24((unsigned)w0, (unsigned)H), w0 == w1 ? (m0 & m1) : m0);
     if (w1 > w0) {
-        atomicOr(rowp + w1, m1);
+        atomicOr(rowp + __umul24((unsigned)w1, (unsigned)H), m1);
         // words in between become all ones (a volatile store through the generic pointer would become a flat store that waits for
         // every outstanding global load of the wave: the OR stays in the LDS pipe)
-        for (int wd = w0 + 1; wd < w1; ++wd) atomicOr(rowp + wd, 0xffffffffu);
+        for (int wd = w0 + 1; wd < w1; ++wd) atomicOr(rowp + __umul24((unsigned)wd, (unsigned)H), 0xffffffffu);
     }
 }
 
@@ -1072,11 +1079,11 @@ __device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int
     const int lim = X0 + TWp;
     if (vert) {
         // y-major: one pixel per row, every step lands in another word
-        uint32_t *rowp = plane + py * wpr;
-        const int rstep = step_y * wpr;
+        uint32_t *rowp = plane + py;
+        const int rstep = step_y;
         for (; k <= kend && px < lim; ++k) {
             const int lx = px - X0;
-            atomicOr(rowp + (lx >> 5), 1u << (lx & 31));
+            atomicOr(rowp + (lx >> 5) * H, 1u << (lx & 31));
             const bool neg = err < 0;
             err += minus_delta + (neg ? plus_delta : 0);
             rowp += rstep;
@@ -1086,11 +1093,11 @@ __device__ inline void draw_line_bits(uint32_t *plane, int H, int W, int X0, int
         // x-major: consecutive pixels of a row that share a word are merged into one ds_or
         int cur = -1;
         uint32_t mask = 0;
-        int rowoff = py * wpr;
-        const int rstep = step_y * wpr;
+        int rowoff = py;
+        const int rstep = step_y;
         for (; k <= kend && px < lim; ++k) {
             const int lx = px - X0;
-            const int addr = rowoff + (lx >> 5);
+            const int addr = rowoff + (lx >> 5) * H;
             const uint32_t bit = 1u << (lx & 31);
             if (addr != cur) {
                 if (mask) atomicOr(plane + cur, mask);
@@ -1155,7 +1162,7 @@ __device__ __noinline__ void fill_generic_bits(uint32_t *plane, int H, int W, in
             if (xx2 >= 0 && xx1 < W) {
                 int s0 = (int)(xx1 < 0 ? 0 : xx1), s1 = (int)(xx2 >= W ? W - 1 : xx2);
                 s0 = max(s0, X0); s1 = min(s1, X0 + TWp - 1);
-                if (s0 <= s1) paint_span_bits(plane + y * wpr, s0 - X0, s1 - X0);
+                if (s0 <= s1) paint_span_bits(plane + y, H, s0 - X0, s1 - X0);
             }
         }
         ex[0] += edx[0];
@@ -1338,7 +1345,7 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                 int xa = chain_x32((int)(short)(ga & 0xffff), adx1, aysw, axs2, adx2, ymin, y0);
                 int xb = chain_x32((int)(short)(gb & 0xffff), bdx1, bysw, bxs2, bdx2, ymin, y0);
                 int da = y0 >= aysw ? adx2 : adx1, db = y0 >= bysw ? bdx2 : bdx1;
-                uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(gn >> 16), (unsigned)H) + (unsigned)y0, (unsigned)wpr);
+                uint32_t *rowp = w.planes + (size_t)(__umul24(__umul24((unsigned)(gn >> 16), (unsigned)H), (unsigned)wpr) + (unsigned)y0);
 #pragma unroll
                 for (int i = 0; i < CHUNK; ++i) {
                     const int y = y0 + i;
@@ -1346,12 +1353,12 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                         const int xx1 = (min(xa, xb) + 32768) >> 16, xx2 = (max(xa, xb) + 32768) >> 16;
                         // OpenCV draws [xx1, xx2] clamped to the image unless it lies entirely outside
                         const int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TWp - 1);
-                        if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
+                        if (s0 <= s1) paint_span_bits(rowp, H, s0 - X0, s1 - X0);
                     }
                     xa += da; xb += db;
                     if (y + 1 == aysw) { xa = axs2 << 16; da = adx2; }
                     if (y + 1 == bysw) { xb = bxs2 << 16; db = bdx2; }
-                    rowp += wpr;
+                    rowp += 1;
                 }
             }
         }
@@ -1365,8 +1372,26 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
         for (int l = 0; l < 4; ++l) {
             if (l < 3) {
                 // push edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) of every face that has to draw it
-                const bool has = lane < n && ((em >> l) & 1u);
+                bool has = lane < n && ((em >> l) & 1u);
                 const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
+                // A y-major edge that needs no clipping, with an ODD number of rows |dy| < 256, of a face that is scan-converted here: every
+                // pixel of cv::Line except its end points is the end of a scan-converted span already.  Row tau of the line holds the pixel
+                // x0 +- floor((2 dx tau + c) / (2 |dy|)), i.e. x0 + dx tau / |dy| rounded to nearest (|dy| odd: 2 dx tau + |dy| is odd, never a tie,
+                // at least 1 / (2 |dy|) away from one); the span ends at the edge's 16.16 chain x0 + tau * slope, slope rounded to 2^-16, which
+                // strays from the exact line by tau * 2^-17 < 1 / (2 |dy|) and so rounds to the same pixel.  Only the end points (the bottom
+                // vertex row is never scan-converted) are painted, here.
+                if (has && r.nrows > 0) {
+                    const int xa = unpack_x(pa), ya = unpack_y(pa), xb = unpack_x(pb), yb = unpack_y(pb);
+                    const int adx = abs(xb - xa), ady = abs(yb - ya);
+                    const bool inside = (unsigned)xa < (unsigned)W && (unsigned)xb < (unsigned)W && (unsigned)ya < (unsigned)H && (unsigned)yb < (unsigned)H;
+                    if (inside && ady > adx && (ady & 1) && ady < 256) {
+                        uint32_t *pl = w.planes + (size_t)__umul24(__umul24(kidx, (unsigned)H), (unsigned)wpr);
+                        const int la = xa - X0, lb = xb - X0;
+                        if ((unsigned)la < (unsigned)TWp) atomicOr(pl + __umul24((unsigned)(la >> 5), (unsigned)H) + ya, 1u << (la & 31));
+                        if ((unsigned)lb < (unsigned)TWp) atomicOr(pl + __umul24((unsigned)(lb >> 5), (unsigned)H) + yb, 1u << (lb & 31));
+                        has = false;
+                    }
+                }
                 const unsigned long long bm = __ballot(has);
                 if (has) {
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
@@ -1425,16 +1450,16 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                     if (live) {
                         const int gx0 = g1 >> 16, ytop_e = (int)(short)(g1 & 0xffff);
                         const int nrow = min(VCHUNK, gady - tau0 + 1);
-                        uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H) + (unsigned)(ytop_e + tau0), (unsigned)wpr);
+                        uint32_t *rowp = w.planes + (size_t)(__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H), (unsigned)wpr) + (unsigned)(ytop_e + tau0));
 #pragma unroll
                         for (int i = 0; i < VCHUNK; ++i) {
                             const int lx = (gup ? gx0 - q : gx0 + q) - X0;
-                            if (i < nrow && (unsigned)lx < (unsigned)TWp) atomicOr(rowp + (lx >> 5), 1u << (lx & 31));
+                            if (i < nrow && (unsigned)lx < (unsigned)TWp) atomicOr(rowp + __umul24((unsigned)(lx >> 5), (unsigned)H), 1u << (lx & 31));
                             rem += A;
                             const bool carry = rem >= D;
                             rem -= carry ? D : 0;
                             q += carry ? 1 : 0;
-                            rowp += wpr;
+                            rowp += 1;
                         }
                     }
                 }
@@ -1466,21 +1491,21 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                         }
                         const int gx0 = g1 >> 16, ytop_e = (int)(short)(g1 & 0xffff);
                         const int nrow = min(HCHUNK, gady - tau0 + 1);
-                        uint32_t *rowp = w.planes + (size_t)__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H) + (unsigned)(ytop_e + tau0), (unsigned)wpr);
+                        uint32_t *rowp = w.planes + (size_t)(__umul24(__umul24((unsigned)(g4 & 15), (unsigned)H), (unsigned)wpr) + (unsigned)(ytop_e + tau0));
 #pragma unroll
                         for (int i = 0; i < HCHUNK; ++i) {
                             if (i < nrow) {
                                 const int h0 = min(q - 1, gdx);
                                 const int xs = gup ? gx0 - h0 : gx0 + lo, xe = gup ? gx0 - lo : gx0 + h0;
                                 const int s0 = max(xs, X0), s1 = min(xe, X0 + TWp - 1);
-                                if (s0 <= s1) paint_span_bits(rowp, s0 - X0, s1 - X0);
+                                if (s0 <= s1) paint_span_bits(rowp, H, s0 - X0, s1 - X0);
                             }
                             lo = q;
                             rem += gib;
                             const bool carry = rem >= D;
                             rem -= carry ? D : 0;
                             q += gia + (carry ? 1 : 0);
-                            rowp += wpr;
+                            rowp += 1;
                         }
                     }
                 }
@@ -1550,12 +1575,10 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
     if ((H & 3) == 0) {
         const int quads = H >> 2;
         const bool full = (cols & 31) == 0;                          // wave-uniform: no partial 32-column word
-        const int XW = (wpr & 1) == 0 ? 2 : 1;                      // words side by side in a wave (see below)
         for (int item = tid; item < quads * wpr; item += BBLOCK) {
-            // A wave takes 32 consecutive row quads of TWO neighbouring words: its plane reads use two LDS banks instead of one (the rows of
-            // a word are 32 bytes apart) and a store instruction writes two runs of 512 contiguous bytes.  Measured: -1 %; four words
-            // (runs of 256 bytes) cost +12 %.
-            const int xwl = item % XW, t_ = item / XW, rq = t_ % quads, xw = (t_ / quads) * XW + xwl, y0 = rq * 4;
+            // A wave takes 64 consecutive row quads of one word column: its plane reads are consecutive 16-byte pieces of LDS (conflict-free
+            // ds_read_b128) and a store instruction writes one run of 1 KiB.
+            const int rq = item % quads, xw = item / quads, y0 = rq * 4;
             if (xw * 32 >= cols) continue;
             uint32_t s[NB][4], cov[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1564,9 +1587,12 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
                 for (int j = 0; j < 4; ++j) s[b][j] = 0;
             for (int k = K - 1; k >= 0; --k) {                       // wave-uniform
                 const int idx = k + 1;
+                // four rows of one word column: 16 contiguous bytes (H and y0 are multiples of 4), consecutive row quads in consecutive lanes
+                const uint4 w4 = *(const uint4 *)(planes + ((size_t)k * wpr + xw) * H + y0);
+                const uint32_t wds[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    uint32_t wd = planes[((size_t)k * H + y0 + j) * wpr + xw];
+                    uint32_t wd = wds[j];
                     uint32_t sn = wd & ~cov[j];
                     cov[j] |= wd;
 #pragma unroll
@@ -1627,7 +1653,7 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
         const int lx = i / H, y = i - lx * H;
         int idx = 0;
         for (int k = K - 1; k >= 0 && idx == 0; --k)
-            if ((planes[((size_t)k * H + y) * wpr + (lx >> 5)] >> (lx & 31)) & 1) idx = k + 1;
+            if ((planes[((size_t)k * wpr + (lx >> 5)) * H + y] >> (lx & 31)) & 1) idx = k + 1;
         const int64_t off = (int64_t)(X0 + lx) * H + y;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -1734,7 +1760,7 @@ __global__ void __launch_bounds__(RBLOCK, 4) raster_mesh_kernel(MeshArgs a, Comm
             float sxv[3] = {V[3 * v0] + (-cam.cx), V[3 * v1] + (-cam.cx), V[3 * v2] + (-cam.cx)};
             float syv[3] = {V[3 * v0 + 1] + (-cam.cy), V[3 * v1 + 1] + (-cam.cy), V[3 * v2 + 1] + (-cam.cy)};
             unsigned ins;
-            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py, ins);
+            acc = trim_project(cam, c.scale, res, X0, TW, sxv, syv, px, py, ins, c.no_trim);
             if (acc) {
                 float z = V[3 * v0 + 2];                                         // level of the first vertex, cv2.py:44-46
                 int rank = 0;
@@ -1923,6 +1949,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
+    cm.no_trim = (aux && (aux->flags & TDS_RASTER_NO_TRIM)) ? 1 : 0;
     const bool want_slices = aux && aux->index_slices;
     if (want_slices) {
         int64_t need = 0;
@@ -2028,7 +2055,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
 
 TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int32_t *faces, int64_t n_img, int64_t V, int64_t F,
                                const float *cam_xy, const float *cam_sc, const float *levels, int n_levels, float scale, int res,
-                               int out_mode, void *out, void *stream) {
+                               int out_mode, void *out, int flags, void *stream) {
     TDS_CHECK_ARG(V >= 0 && F >= 0, "tds_raster_mesh: negative size");
     int tw = 0;
     int rc = common_checks("tds_raster_mesh", n_img, res, out_mode, out, tw);
@@ -2045,6 +2072,7 @@ TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
     cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
+    cm.no_trim = (flags & TDS_RASTER_NO_TRIM) ? 1 : 0;
     TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
     TDS_LAUNCH_CHECK("raster_mesh_kernel");
     return TDS_OK;

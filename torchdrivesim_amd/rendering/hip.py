@@ -31,7 +31,7 @@ class CV2RendererConfig(HipRendererConfig):
     """The reference's name for the configuration of its OpenCV backend (rendering/cv2.py:12-15).  A configuration written for that
     backend selects the MI355X rasteriser here: same pixel semantics, no OpenCV involved."""
     backend: str = 'cv2'
-    trim_mesh_before_rendering: bool = True      #: the rasteriser always applies the reference's trim rule; False is refused
+    trim_mesh_before_rendering: bool = True      #: cv2.py:15; False keeps the faces that have no vertex in view (cv2.py:32-41)
 
 
 def level_table(*level_sources) -> list:
@@ -46,9 +46,11 @@ class HipRenderer(BirdviewRenderer):
     def __init__(self, cfg: HipRendererConfig, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)
         self.cfg: HipRendererConfig = cfg
-        if not getattr(cfg, 'trim_mesh_before_rendering', True):
-            # untrimmed, faces without a vertex in view are drawn too (cv2.py:32-41): other pixels than the kernels produce
-            raise NotImplementedError('trim_mesh_before_rendering=False is not available: the rasteriser culls with the trim rule')
+
+    @property
+    def trim(self) -> bool:
+        """cv2.py:32-41: with trim_mesh_before_rendering (the default) a face is drawn only if one of its vertices lies in the 1.05 x view"""
+        return bool(getattr(self.cfg, 'trim_mesh_before_rendering', True))
 
     @property
     def out_dtype(self) -> torch.dtype:
@@ -64,7 +66,7 @@ class HipRenderer(BirdviewRenderer):
         if verts.shape[-1] == 2:
             verts = torch.cat([verts, torch.zeros_like(verts[..., :1])], dim=-1)
         levels = level_table(torch.unique(verts[..., 2]).tolist()) if verts.shape[1] > 0 else [0.0]
-        img = _ops.raster_mesh(verts, attrs, faces, cameras.xy, cameras.sc, levels, cameras.scale, res.height, out_dtype=self.out_dtype)
+        img = _ops.raster_mesh(verts, attrs, faces, cameras.xy, cameras.sc, levels, cameras.scale, res.height, out_dtype=self.out_dtype, trim=self.trim)
         return img.permute(0, 2, 3, 1)        # (n,H,W,3) view; render_frame permutes it back to CHW without a copy
 
     def make_static_map(self, rgb_mesh: RGBMesh, extra_levels=(), device=None) -> _ops.StaticMap:
@@ -94,6 +96,6 @@ class HipRenderer(BirdviewRenderer):
             if self.out_dtype != torch.float32:
                 raise RuntimeError('the differentiable path renders float32 images')
             return _ops.raster_scene_diff(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, key_table=key_table,
-                                          extra_tri=extra_tri, extra_key=extra_key, key_colors=key_colors, color_keys=color_keys)
+                                          extra_tri=extra_tri, extra_key=extra_key, key_colors=key_colors, color_keys=color_keys, trim=self.trim)
         return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype,
-                                 key_table=key_table, extra_tri=extra_tri, extra_key=extra_key)
+                                 key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim)
