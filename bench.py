@@ -155,7 +155,7 @@ class _ImageProbe(torch.autograd.Function):
         return ctx.saved_tensors[0], None
 
 
-def other_configs(device, steps, warmup):
+def other_configs(device, steps, warmup, only=None):
     """BASELINE.json's other single-GPU configurations (2, 3, 5) and the uint8 output mode of the headline kernel, measured in
     this run after the timed region: ms/step, agent-steps/s, the dominant kernel and its fraction of the HBM roof."""
     from torchdrivesim_amd import _ops, lanelet2
@@ -181,6 +181,8 @@ def other_configs(device, steps, warmup):
 
     B, A = 256, 64
     for name in ('config2', 'config3', 'config5'):
+        if only is not None and name != only:
+            continue
         sim, actions, _ = build_simulator(B, A, device, seed=1234, lanelet_map=lanes)
         state0 = sim.get_state().clone()
 

@@ -340,3 +340,98 @@ def test_waypoint_goals_are_drawn_by_the_fused_path(oracle):
     assert c.requires_grad and torch.equal(c.detach(), imgs[1])
     c.sum().backward()
     assert torch.isfinite(st.grad).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's configurations 2, 3 and 5 at their FULL size (B = 256 x A = 64, 256 x 256), through size-independent properties plus the
+# slice of the batch the oracle can afford (these sizes had only been run by the benchmark scripts)
+# ------------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def full_size():
+    import bench
+    from oracle import lanelet_oracle
+    from torchdrivesim_amd import lanelet2
+    import os
+    osm = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'carla_Town01.osm.gz')
+    lanes = lanelet2.load_lanelet_map(osm, origin=(0.0, 0.0))
+    sim, actions, host = bench.build_simulator(256, 64, torch.device(DEV), seed=77, lanelet_map=lanes)
+    sim.step(actions[0])
+    return sim, actions, host, lanelet_oracle.load_osm(osm, origin=(0.0, 0.0))
+
+
+def test_config2_full_size_render_and_collision(full_size, oracle):
+    from torchdrivesim_amd.rendering import HipRendererConfig, renderer_from_config
+    from torchdrivesim_amd.utils import Resolution
+    sim, actions, host, _ = full_size
+    state0, size, present, act, verts, faces, vcat, cats = host
+    res = Resolution(256, 256)
+    img = sim.render_egocentric(res=res, fov=35.0)
+    col = sim.compute_collision()
+    assert img.shape == (256, 64, 3, 256, 256) and img.dtype == torch.float32 and col.shape == (256, 64)
+    # scenes are independent: any sub-batch renders / collides to the same bits as inside the full batch
+    pick = [3, 100, 255]
+    sub = sim.select_batch_elements(torch.tensor(pick), in_place=False)
+    assert torch.equal(sub.render_egocentric(res=res, fov=35.0), img[pick])
+    assert torch.equal(sub.compute_collision(), col[pick])
+    # the uint8 mode shows the same values
+    u8 = sim.copy()
+    u8.renderer = renderer_from_config(HipRendererConfig(out_dtype='uint8'), res=res, fov=35.0)
+    u8._scene_cache = None
+    assert torch.equal(u8.render_egocentric(res=res, fov=35.0)[pick].float(), img[pick])
+    # the oracle on what it can afford: one scene of images, eight scenes of collisions
+    s1 = sim.get_state().cpu().numpy()
+    sc = torch.stack([torch.sin(sim.get_state()[..., 2]), torch.cos(sim.get_state()[..., 2])], -1).cpu().numpy()
+    sv, sa, sf = oracle.static_mesh_arrays(verts, faces, vcat, cats)
+    k = 1
+    mask = np.ascontiguousarray(np.broadcast_to(present[:k, None, :], (k, 64, 64)))
+    ref = oracle.render_scenes(s1[:k], size[:k], mask, s1[:k, :, :2].copy(), sc[:k], sv, sa, sf, 35.0, 256, agent_sc=sc[:k])
+    np.testing.assert_array_equal(img[:k].cpu().numpy(), ref)
+    boxes = np.concatenate([s1[..., :2], size, s1[..., 2:3]], -1)
+    np.testing.assert_array_equal(col[:8].cpu().numpy(), oracle.collision(boxes[:8], present[:8], metric='iou', sc=sc[:8]))
+    assert (col > 0).float().mean() > 0.01 and 0.2 < (img[:4] > 0).float().mean() < 0.9
+
+
+def test_config3_full_size_offroad_and_wrong_way(full_size, oracle):
+    from oracle import lanelet_oracle
+    sim, actions, host, oracle_lanes = full_size
+    state0, size, present, act, verts, faces, vcat, cats = host
+    off, ww = sim.compute_offroad(), sim.compute_wrong_way()
+    assert off.shape == ww.shape == (256, 64)
+    pick = [0, 17, 200]
+    sub = sim.select_batch_elements(torch.tensor(pick), in_place=False)
+    assert torch.equal(sub.compute_offroad(), off[pick]) and torch.equal(sub.compute_wrong_way(), ww[pick])
+    s1 = sim.get_state().cpu().numpy()
+    sc = torch.stack([torch.sin(sim.get_state()[..., 2]), torch.cos(sim.get_state()[..., 2])], -1).cpu().numpy()
+    np.testing.assert_array_equal(off[:4].cpu().numpy(), oracle.offroad(s1[:4], size[:4], verts, faces, 0.5, present=present[:4], sc=sc[:4]))
+    ref = lanelet_oracle.lanelet_orientation_loss([oracle_lanes], s1[:1]) * present[:1]
+    np.testing.assert_allclose(ww[:1].cpu().numpy(), ref, rtol=0, atol=2e-6)
+    assert not off[~torch.from_numpy(present).to(off.device)].any() and (off > 0).any() and (ww > 0).any()
+
+
+def test_config5_full_size_backward(full_size):
+    """gradients through kinematics, IoU, off-road and the rasteriser at B = 256: finite everywhere, zero for the speed column of the image
+    term, and equal (to float32 summation order) to the gradients of a sub-batch run on its own"""
+    from torchdrivesim_amd.utils import Resolution
+    sim, actions, host, _ = full_size
+    res = Resolution(256, 256)
+    w = torch.rand(256, 64, 3, 256, 256, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+
+    def grads(s, act, weight):
+        s0 = s.get_state().detach().clone().requires_grad_(True)
+        a = act.clone().requires_grad_(True)
+        s.kinematic_model.set_state(s0)
+        s.step(a)
+        img = s.render_egocentric(res=res, fov=35.0)
+        loss = (img * weight).sum() / 255.0 + s.compute_collision().sum() + s.compute_offroad().sum()
+        loss.backward()
+        return s0.grad, a.grad
+
+    full = sim.copy()
+    pick = [5, 128, 254]
+    part = sim.select_batch_elements(torch.tensor(pick), in_place=False)
+    g_state, g_act = grads(full, actions[1], w)
+    assert g_state.shape == (256, 64, 4) and g_act.shape == (256, 64, 2)
+    assert torch.isfinite(g_state).all() and torch.isfinite(g_act).all() and g_state.abs().sum() > 0 and g_act.abs().sum() > 0
+    p_state, p_act = grads(part, actions[1][pick], w[pick])
+    np.testing.assert_allclose(p_state.cpu().numpy(), g_state[pick].cpu().numpy(), rtol=2e-4, atol=2e-4 * float(g_state[pick].abs().max()))
+    np.testing.assert_allclose(p_act.cpu().numpy(), g_act[pick].cpu().numpy(), rtol=2e-4, atol=2e-4 * float(g_act[pick].abs().max()))

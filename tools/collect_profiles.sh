@@ -1,22 +1,31 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): rocprofv3 evidence for the round.
-#   1. kernel trace + stats of the default bench command  -> gpurun_out/profiles/bench_kernel_stats.csv
-#   2. PMC passes (separate runs, counters only) over the raster kernel at the bench shape -> gpurun_out/profiles/raster_pmc.json
+# Run on the GPU box (via gpurun): rocprofv3 evidence for the round, written under gpurun_out/profiles/ (tools/make_profiles.py turns it
+# into the committed files under profiles/).
+#   1. kernel trace + stats of the default bench command and of configurations 2, 3 and 5 (one run each)
+#   2. PMC passes (separate runs, counters only -- never combined with tracing) over the raster kernel at the bench shape, float32 and uint8
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof.log 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 rm -rf $OUT/kt
-i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --kernel-include-regex "raster" --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py --batch 1024 --iters 2 > $OUT/p$i.log 2>&1
+for cfg in config2 config3 config5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/tools/bench_configs.py --only $cfg --steps 20 --warmup 3 > $OUT/${cfg}_under_rocprof.log 2>&1
+  cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${cfg}_kernel_stats.csv
+  rm -rf $OUT/kt
 done
-python3 $R/tools/pmc_summary.py $OUT raster > $OUT/raster_pmc.json
-rm -rf $OUT/p[0-9] $OUT/p[0-9].log
+for mode in f32 u8; do
+  extra=""; [ $mode = u8 ] && extra="--u8"
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --kernel-include-regex "raster" --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py --batch 1024 --iters 2 $extra > $OUT/p$i.log 2>&1
+  done
+  python3 $R/tools/pmc_summary.py $OUT raster > $OUT/raster_pmc_$mode.json
+  rm -rf $OUT/p[0-9] $OUT/p[0-9].log
+done
 head -5 $OUT/bench_kernel_stats.csv | cut -c1-160
 tail -1 $OUT/bench_under_rocprof.log | cut -c1-400

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--tw', type=int, nargs='*', default=[0])
     ap.add_argument('--debug', type=int, nargs='*', default=[0])
     ap.add_argument('--u8', action='store_true')
+    ap.add_argument('--res', type=int, default=0, help='resolution (default: the bench resolution)')
     ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
     ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
     ap.add_argument('--no-ws', action='store_true', help='fused per-strip kernel instead of the binned persistent kernel')
@@ -44,7 +45,7 @@ def main():
         sim.renderer.cfg.out_dtype = 'uint8'
     for i in range(args.steps_before):
         sim.step(actions[i % 8])
-    res = Resolution(bench.RES, bench.RES)
+    res = Resolution(args.res or bench.RES, args.res or bench.RES)
     img = sim.render_egocentric(res=res, fov=bench.FOV)
     torch.cuda.synchronize()
     nbytes = img.numel() * img.element_size()

@@ -274,6 +274,36 @@ __device__ __forceinline__ Box load_box(const float *boxes, const float *sc, int
     return b;
 }
 
+// Row reduction of K2a on a wavefront (north star: "wavefront ballot/reduce for overlap flags"): the lanes hold the overlaps o_ij of 64
+// consecutive partners j.  collision_i = sum_j o_ij - max_j o_ij (simulator.py:1105-1108) keeps the reference's INDEX-ORDER sum bit for bit:
+// the overlaps are >= 0 and all but a few are exactly 0, and x + 0 = x, so lane 0 adds only the non-zero ones (ballot), in index order.
+// The maximum, the overlap bit mask (ballot of o > 0, j != i) and the arg-max partner (lowest j attaining the largest o > 0) are
+// order-independent wave reductions.
+struct RowAcc { float sum, mx, best; int arg; uint64_t bits; };
+__device__ __forceinline__ RowAcc row_acc_init() { RowAcc a; a.sum = 0.0f; a.mx = -__builtin_inff(); a.best = 0.0f; a.arg = -1; a.bits = 0; return a; }
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+// o: this lane's overlap (already scrubbed and masked), valid: j = j0 + lane < N.  Every lane returns the same accumulator.
+__device__ __forceinline__ void row_acc_chunk(RowAcc &a, float o, bool valid, int i, int j0, int lane) {
+    const int j = j0 + lane;
+    const unsigned long long nz = __ballot(valid && o != 0.0f);
+    for (unsigned long long m = nz; m != 0; m &= m - 1) {                 // wave-uniform loop over the non-zero overlaps, ascending j
+        const int l = (int)__ffsll((long long)m) - 1;
+        a.sum = a.sum + __shfl(o, l);
+    }
+    a.mx = fmaxf(a.mx, wave_max_f32(valid ? o : -__builtin_inff()));
+    const bool hit = valid && j != i && o > 0.0f;
+    if (j0 == 0) a.bits = __ballot(hit);
+    const float cm = wave_max_f32(hit ? o : 0.0f);
+    if (cm > a.best) {                                                    // wave-uniform
+        a.best = cm;
+        a.arg = j0 + (int)__ffsll((long long)__ballot(hit && o == cm)) - 1;
+    }
+}
+
 // grid = (B, ceil(A / (4 waves * ROWS_PER_WAVE))), dynamic LDS = 4 * (16*64 + Npad) floats
 template <int METRIC>
 __global__ void __launch_bounds__(CBLOCK) collision_kernel(const float *__restrict__ boxes, const float *__restrict__ sc,
@@ -283,7 +313,6 @@ __global__ void __launch_bounds__(CBLOCK) collision_kernel(const float *__restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int npad = (N + 63) & ~63;
     float *scr = smem + wave * (16 * 64 + npad);
-    float *rowbuf = scr + 16 * 64;
     const int64_t b = blockIdx.x;
     const int row0 = (blockIdx.y * (CBLOCK / 64) + wave) * ROWS_PER_WAVE;
     for (int r = 0; r < ROWS_PER_WAVE; ++r) {
@@ -291,6 +320,7 @@ __global__ void __launch_bounds__(CBLOCK) collision_kernel(const float *__restri
         if (i >= A) break;                                           // wave-uniform
         Box bi = load_box(boxes, sc, b * N + i);
         Corners ci = corners_of(bi);
+        RowAcc acc = row_acc_init();
         for (int j0 = 0; j0 < N; j0 += 64) {
             int j = j0 + lane;
             float o = 0.0f;
@@ -304,28 +334,13 @@ __global__ void __launch_bounds__(CBLOCK) collision_kernel(const float *__restri
                 }
                 o = scrub(o) * (present[b * N + j] ? 1.0f : 0.0f);   // simulator.py:1103-1104
             }
-            rowbuf[j] = o;
+            row_acc_chunk(acc, o, j < N, i, j0, lane);
         }
-        __builtin_amdgcn_wave_barrier();
-        // sum_j o_ij in index order and max_j (simulator.py:1105-1108); lane 0 carries the result
         if (lane == 0) {
-            float sum = 0.0f, mx = -__builtin_inff(), best = 0.0f;
-            int arg = -1;
-            uint64_t bits = 0;
-            for (int j = 0; j < N; ++j) {
-                float o = rowbuf[j];
-                sum = sum + o;
-                mx = fmaxf(mx, o);
-                if (j != i && o > 0.0f) {
-                    if (j < 64) bits |= (uint64_t)1 << j;
-                    if (o > best) { best = o; arg = j; }
-                }
-            }
-            out[b * A + i] = sum - mx;
-            if (overlap) overlap[b * A + i] = bits;
-            if (partner) partner[b * A + i] = arg;
+            out[b * A + i] = acc.sum - acc.mx;
+            if (overlap) overlap[b * A + i] = acc.bits;
+            if (partner) partner[b * A + i] = acc.arg;
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -371,23 +386,18 @@ __global__ void __launch_bounds__(CBLOCK) collision_scene_iou_kernel(const float
         O[p] = scrub(o) * (present[b * N + j] ? 1.0f : 0.0f);       // simulator.py:1103-1104
     }
     __syncthreads();
-    // sum_j o_ij in index order and max_j (simulator.py:1105-1108), one thread per row
-    for (int i = tid; i < A; i += CBLOCK) {
-        float sum = 0.0f, mx = -__builtin_inff(), best = 0.0f;
-        int arg = -1;
-        uint64_t bits = 0;
-        for (int j = 0; j < N; ++j) {
-            const float o = O[i * N + j];
-            sum = sum + o;
-            mx = fmaxf(mx, o);
-            if (j != i && o > 0.0f) {
-                if (j < 64) bits |= (uint64_t)1 << j;
-                if (o > best) { best = o; arg = j; }
-            }
+    // sum_j o_ij in index order and max_j (simulator.py:1105-1108): one wavefront per row, lanes = partners (row_acc_chunk)
+    for (int i = wave; i < A; i += CBLOCK / 64) {
+        RowAcc acc = row_acc_init();
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int j = j0 + lane;
+            row_acc_chunk(acc, j < N ? O[i * N + j] : 0.0f, j < N, i, j0, lane);
         }
-        out[b * A + i] = sum - mx;
-        if (overlap) overlap[b * A + i] = bits;
-        if (partner) partner[b * A + i] = arg;
+        if (lane == 0) {
+            out[b * A + i] = acc.sum - acc.mx;
+            if (overlap) overlap[b * A + i] = acc.bits;
+            if (partner) partner[b * A + i] = acc.arg;
+        }
     }
 }
 

@@ -1374,17 +1374,24 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                 // push edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) of every face that has to draw it
                 bool has = lane < n && ((em >> l) & 1u);
                 const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
-                // A y-major edge that needs no clipping, with an ODD number of rows |dy| < 256, of a face that is scan-converted here: every
-                // pixel of cv::Line except its end points is the end of a scan-converted span already.  Row tau of the line holds the pixel
-                // x0 +- floor((2 dx tau + c) / (2 |dy|)), i.e. x0 + dx tau / |dy| rounded to nearest (|dy| odd: 2 dx tau + |dy| is odd, never a tie,
-                // at least 1 / (2 |dy|) away from one); the span ends at the edge's 16.16 chain x0 + tau * slope, slope rounded to 2^-16, which
-                // strays from the exact line by tau * 2^-17 < 1 / (2 |dy|) and so rounds to the same pixel.  Only the end points (the bottom
-                // vertex row is never scan-converted) are painted, here.
-                if (has && r.nrows > 0) {
+                // A y-major edge that needs no clipping, |dy| < 256, whose exact line never passes midway between two pixel centres, of a face
+                // that is scan-converted here: every pixel of cv::Line except its end points is the end of a scan-converted span already.
+                // Row tau of the line holds the pixel x0 +- floor((2 dx tau + c) / (2 |dy|)), i.e. x0 + dx tau / |dy| rounded to nearest, ties
+                // (2 |dy| dividing 2 dx tau + |dy|) broken by c.  The span ends at the edge's 16.16 chain x0 + tau * slope, slope rounded to
+                // 2^-16, which strays from the exact line by tau * 2^-17 < 1 / (2 |dy|): it rounds to the same pixel in every row that is
+                // no tie, a non-tie being at least 1 / (2 |dy|) away from one.  A tie needs |dy| (2 m - 1) = 2 dx tau, which has a solution
+                // 0 < tau < |dy| exactly when |dy| / gcd(dx, |dy|) is even, i.e. when |dy| holds more factors of two than dx: edges with
+                // ctz(dx) >= ctz(|dy|) (all odd |dy|, all vertical edges) have none.  Only the end points (the bottom vertex row is never
+                // scan-converted) are painted, here.
+                // Likewise an edge between neighbouring pixels (|dx|, |dy| <= 1: the short sides of the lane-marking slivers) IS its two end
+                // points, and a horizontal edge along the top row of a scan-converted face is that row's span (both chains start in its
+                // end points).
+                if (has) {
                     const int xa = unpack_x(pa), ya = unpack_y(pa), xb = unpack_x(pb), yb = unpack_y(pb);
                     const int adx = abs(xb - xa), ady = abs(yb - ya);
                     const bool inside = (unsigned)xa < (unsigned)W && (unsigned)xb < (unsigned)W && (unsigned)ya < (unsigned)H && (unsigned)yb < (unsigned)H;
-                    if (inside && ady > adx && (ady & 1) && ady < 256) {
+                    const bool covered = r.nrows > 0 && ((ady > adx && ady < 256 && (adx == 0 || __ffs(adx) >= __ffs(ady))) || (ady == 0 && ya == r.ymin));
+                    if (inside && (covered || (adx <= 1 && ady <= 1))) {
                         uint32_t *pl = w.planes + (size_t)__umul24(__umul24(kidx, (unsigned)H), (unsigned)wpr);
                         const int la = xa - X0, lb = xb - X0;
                         if ((unsigned)la < (unsigned)TWp) atomicOr(pl + __umul24((unsigned)(la >> 5), (unsigned)H) + ya, 1u << (la & 31));
