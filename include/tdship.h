@@ -245,11 +245,13 @@ int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const fl
  * is read only next to colour boundaries.  keys / n_keys: HOST, the key table the forward launch reported.
  * grad_color (optional, NULL to skip): B x Nc x 16 x 4 -- entry [i][ch] (ch 0..2 = R, G, B; [3] = 0) is the gradient with respect to
  * channel ch of the colour shown for key index i (0 = background, i >= 1: keys[i - 1]) in that camera: the sum of grad_out over the
- * pixels whose winning key it is (exact: the image is colour[index] pixel by pixel).  Asking for it reads grad_out in full. */
+ * pixels whose winning key it is (exact: the image is colour[index] pixel by pixel).  Asking for it reads grad_out in full.
+ * grad_out_stride: floats between the gradient images of consecutive cameras -- 3 res^2 for a dense B x Nc x 3 x H x W gradient, 0 when
+ * ONE 3 x H x W image is the gradient of every camera (losses like image.sum() or a fixed linear read-out hand back a broadcast). */
 int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                                  const float *cam_sc, const uint32_t *index_slices, const uint32_t *keys, int n_keys, const float *grad_out,
-                                 int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent, float *grad_cam,
-                                 float *grad_color, void *stream);
+                                 int64_t grad_out_stride, int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent,
+                                 float *grad_cam, float *grad_color, void *stream);
 
 /* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
  *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,

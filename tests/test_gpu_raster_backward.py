@@ -170,6 +170,16 @@ def test_index_slice_backward_equals_the_image_backward(ops, oracle, res):
     for a, b in zip(*grads):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(np.abs(b).max(), 1e-9))
     assert np.abs(grads[0][2]).max() > 0 and np.abs(grads[0][0]).max() > 0
+    # a gradient that is ONE image broadcast over all cameras (stride 0) is read as such: same result as its dense copy
+    one = torch.randn(img.shape[2:], device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    res2 = []
+    for g in (one.expand_as(img), one.expand_as(img).contiguous()):
+        st, cxy = dev(state).requires_grad_(True), dev(cam_xy).requires_grad_(True)
+        csc = torch.cat([torch.sin(cpsi), torch.cos(cpsi)], -1)
+        out = ops.raster_scene_diff(smap, st, ops.heading_sc(st[..., 2]), tmpl, actor_keys(smap, B, N), dev(mask), cxy, csc, 35.0, res)
+        out.backward(g)
+        res2.append((st.grad.clone(), cxy.grad.clone()))
+    assert torch.equal(res2[0][0], res2[1][0]) and torch.equal(res2[0][1], res2[1][1])
 
 
 def test_colour_gradient_is_the_per_key_sum_of_the_incoming_gradient(ops, oracle):

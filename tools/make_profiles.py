@@ -1,38 +1,73 @@
 #!/usr/bin/env python3
 """Turn the raw output of tools/collect_profiles.sh (gpurun_out/profiles/) into the committed evidence under profiles/.
-   python tools/make_profiles.py r01"""
-import csv, json, os, sys
+   python tools/make_profiles.py r02
+Writes  profiles/<tag>_bench_kernel_stats.csv, <tag>_config{2,3,5}_kernel_stats.csv (rocprofv3 --kernel-trace --stats, top kernels),
+        profiles/<tag>_raster_pmc.json (counters of the raster kernel, float32 and uint8 output, HBM traffic with the gfx950 corrections)
+        profiles/raster_traffic.json   (what bench.py reports as roofline.traffic -- stamped with the hash of the kernel's sources and
+                                        refused by bench.py for any other build)"""
+import csv
+import json
+import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src, dst = os.path.join(ROOT, 'gpurun_out', 'profiles'), os.path.join(ROOT, 'profiles')
 B, A, RES = 1024, 64, 256
-ALGO = B * A * 3 * RES * RES * 4
+stamp = bench.kernel_source_stamp()
 
-rows = list(csv.reader(open(os.path.join(src, 'bench_kernel_stats.csv'))))
-with open(os.path.join(dst, f'{tag}_bench_kernel_stats.csv'), 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline   (MI355X; top 15 kernels by total time)\n')
-    w = csv.writer(f)
-    for r in rows[:16]:
-        r[0] = r[0][:110]
-        w.writerow(r)
-log = open(os.path.join(src, 'bench_under_rocprof.log')).read().splitlines()
-open(os.path.join(dst, f'{tag}_bench_under_rocprof.log'), 'w').write('\n'.join(l for l in log if l.startswith('{')) + '\n')
+commands = dict(bench='python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs',
+                config2='python3 tools/bench_configs.py --only config2 --steps 20 --warmup 3',
+                config3='python3 tools/bench_configs.py --only config3 --steps 20 --warmup 3',
+                config5='python3 tools/bench_configs.py --only config5 --steps 20 --warmup 3')
+for name, cmd in commands.items():
+    path = os.path.join(src, f'{name}_kernel_stats.csv')
+    if not os.path.exists(path):
+        print('missing', path)
+        continue
+    rows = list(csv.reader(open(path)))
+    with open(os.path.join(dst, f'{tag}_{name}_kernel_stats.csv'), 'w') as f:
+        f.write(f'# rocprofv3 --kernel-trace --stats -- {cmd}   (MI355X; top 15 kernels by total time; kernel source {stamp})\n')
+        w = csv.writer(f)
+        for r in rows[:16]:
+            r[0] = r[0][:110]
+            w.writerow(r)
+    log = os.path.join(src, f'{name}_under_rocprof.log')
+    if os.path.exists(log):
+        lines = [l for l in open(log).read().splitlines() if l.startswith('{')]
+        open(os.path.join(dst, f'{tag}_{name}_under_rocprof.log'), 'w').write('\n'.join(lines) + '\n')
 
-pmc = json.load(open(os.path.join(src, 'raster_pmc.json')))
-key = max(pmc, key=lambda k: pmc[k].get('WRITE_SIZE', {}).get('mean', 0))
-c = {n: v['mean'] for n, v in pmc[key].items()}
-wb, fb = c['WRITE_SIZE'] * 1024, c['FETCH_SIZE'] * 1024
-out = dict(kernel='raster_scene_bits_kernel<4, 3, float, SceneArgs>', batch=B, agents=A, res=RES,
-           command='tools/collect_profiles.sh: rocprofv3 --pmc <set> --kernel-include-regex raster -- python3 tools/profile_raster.py --batch 1024 '
-                   '--iters 2 (one pass per counter set, counters only)',
-           counters=c, write_bytes_per_launch=wb, fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch_corrected=2 * fb,
-           hbm_bytes_per_launch=wb + 2 * fb, algorithmic_bytes_per_launch=ALGO,
-           notes='WRITE_SIZE / FETCH_SIZE are reported in KiB. FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (an upper '
-                 'bound here: part of the reads are 32-byte grid-entry gathers). traffic = WRITE_SIZE + 2 FETCH_SIZE = '
-                 f'{(wb + 2 * fb) / ALGO:.3f} x the algorithmic bytes (WRITE_SIZE alone: {wb / ALGO:.3f} x).')
+out, traffic = dict(kernel_source_sha=stamp, batch=B, agents=A, res=RES,
+                    command='tools/collect_profiles.sh: rocprofv3 --pmc <set> --kernel-include-regex raster -- python3 tools/profile_raster.py '
+                            '--batch 1024 --iters 2 [--u8]  (one pass per counter set, counters only, the PRODUCT library)'), {}
+for mode, bpp in (('f32', 4), ('u8', 1)):
+    path = os.path.join(src, f'raster_pmc_{mode}.json')
+    if not os.path.exists(path):
+        continue
+    pmc = json.load(open(path))
+    key = max(pmc, key=lambda k: pmc[k].get('WRITE_SIZE', {}).get('mean', 0))
+    c = {n: v['mean'] for n, v in pmc[key].items()}
+    algo = B * A * 3 * RES * RES * bpp
+    wb, fb = c['WRITE_SIZE'] * 1024, c['FETCH_SIZE'] * 1024
+    waves = c.get('SQ_WAVES', 0) or 1
+    ent = dict(kernel=key, counters=c, write_bytes_per_launch=wb, fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch_corrected=2 * fb,
+               hbm_bytes_per_launch=wb + 2 * fb, algorithmic_bytes_per_launch=algo, traffic_over_algorithmic=(wb + 2 * fb) / algo,
+               valu_instructions_per_wave=c.get('SQ_INSTS_VALU', 0) / waves,
+               lds_bank_conflict_share=c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1),
+               valu_utilisation=c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / max(c.get('SQ_BUSY_CYCLES', 0), 1) if c.get('SQ_BUSY_CYCLES') else None)
+    out[mode] = ent
+    traffic[mode] = dict(batch=B, agents=A, res=RES, hbm_bytes_per_launch=wb + 2 * fb, kernel_source_sha=stamp, source=f'profiles/{tag}_raster_pmc.json')
+out['notes'] = ('WRITE_SIZE / FETCH_SIZE are reported in KiB. FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (an upper bound here: part '
+                'of the reads are 32-byte grid-entry gathers). traffic = WRITE_SIZE + 2 FETCH_SIZE. lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / '
+                'SQ_LDS_IDX_ACTIVE (round 1: 0.49 with the row-major plane layout).')
 json.dump(out, open(os.path.join(dst, f'{tag}_raster_pmc.json'), 'w'), indent=1)
-json.dump(dict(batch=B, agents=A, res=RES, hbm_bytes_per_launch=wb + 2 * fb, source=f'profiles/{tag}_raster_pmc.json'),
-          open(os.path.join(dst, 'raster_traffic.json'), 'w'), indent=1)
-print(open(os.path.join(dst, f'{tag}_bench_kernel_stats.csv')).read()[:900])
-print(json.dumps({k: out[k] for k in ('write_bytes_per_launch', 'fetch_bytes_per_launch_raw', 'hbm_bytes_per_launch')}))
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, 'raster_traffic.json'), 'w'), indent=1)
+for mode in ('f32', 'u8'):
+    if mode in out:
+        e = out[mode]
+        print(mode, {k: e[k] for k in ('write_bytes_per_launch', 'fetch_bytes_per_launch_raw', 'traffic_over_algorithmic', 'valu_instructions_per_wave',
+                                       'lds_bank_conflict_share')})

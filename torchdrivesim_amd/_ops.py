@@ -548,7 +548,12 @@ class _RasterScene(torch.autograd.Function):
         B, Nc = cam_xy.shape[:2]
         N = state.shape[1]
         dev = cam_xy.device
-        gout = _c(gout)
+        # a gradient that is one image broadcast over the cameras (image.sum(), a fixed linear read-out ...) stays one image
+        gstride = 3 * int(ctx.res) * int(ctx.res)
+        if ctx.keys is not None and gout.dim() == 5 and gout.stride(0) == 0 and gout.stride(1) == 0 and B * Nc > 1:
+            gout, gstride = _c(gout[0, 0]), 0
+        else:
+            gout = _c(gout)
         g_agent = torch.empty((B, Nc, max(N, 1), 4), dtype=f32, device=dev)
         g_cam = torch.empty((B, Nc, 4), dtype=f32, device=dev)
         m8 = mask.contiguous().view(u8) if mask.dtype == torch.bool else _c(mask, u8)
@@ -566,7 +571,7 @@ class _RasterScene(torch.autograd.Function):
             if ctx.color_keys is not None and ctx.needs_input_grad[4]:
                 g_color = torch.empty((B, Nc, 16, 4), dtype=f32, device=dev)
             nat.call('tds_raster_scene_bwd_idx_f32', dev, *poses, nat.dev_ptr(kept, i32, 'index_slices'), ctypes.cast(kt, ctypes.c_void_p), len(ctx.keys),
-                     nat.dev_ptr(gout, f32, 'grad_out'), *tail[:-1], nat.dev_ptr(g_color, f32, 'grad_color'), tail[-1])
+                     nat.dev_ptr(gout, f32, 'grad_out'), gstride, *tail[:-1], nat.dev_ptr(g_color, f32, 'grad_color'), tail[-1])
         else:
             nat.call('tds_raster_scene_bwd_f32', dev, *poses, nat.dev_ptr(kept, f32, 'image'), nat.dev_ptr(gout, f32, 'grad_out'), *tail)
         if ev is not None:

@@ -281,6 +281,7 @@ struct BwdIdxArgs {
     float *grad_agent, *grad_cam;
     float *grad_color;          // optional: B x Nc x 16 x 4: per key index (0 = background) the sum of the incoming gradient per channel
     int N, Nc, res, nb;         // nb: slices in use (index bits)
+    int64_t gstride;            // floats between the gradient images of consecutive cameras (3 res^2; 0 = one image shared by all)
     float scale;
     uint32_t keys[16];          // ascending key table of the forward launch
     int n_keys;
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
     const float2 cxy = a.cam_xy[img], csc = a.cam_sc[img];
     const float cs = csc.x, cc = csc.y;
     const int64_t plane = (int64_t)res * res;
-    const float *G = a.grad_out + img * 3 * plane;
+    const float *G = a.grad_out + img * a.gstride;
     const uint32_t *S = a.slices + (size_t)img * wprT * quads * 16;
     if (tid < 4) cam_acc[tid] = 0.0f;
     if (tid < 16) {
@@ -634,7 +635,8 @@ TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_s
 
 TDS_EXPORT int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                                             const float *cam_sc, const uint32_t *index_slices, const uint32_t *keys, int n_keys, const float *grad_out,
-                                            int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent, float *grad_cam, float *grad_color, void *stream) {
+                                            int64_t grad_out_stride, int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent,
+                                            float *grad_cam, float *grad_color, void *stream) {
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene_bwd_idx_f32: bad sizes");
     TDS_CHECK_ARG(res > 0 && res <= 4096 && (res & 3) == 0, "tds_raster_scene_bwd_idx_f32: the resolution must be a multiple of 4");
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene_bwd_idx_f32: scale must be positive");
@@ -648,6 +650,8 @@ TDS_EXPORT int tds_raster_scene_bwd_idx_f32(const float *state, const float *age
     a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl; a.mask = mask;
     a.cam_xy = (const float2 *)cam_xy; a.cam_sc = (const float2 *)cam_sc; a.slices = index_slices; a.grad_out = grad_out;
     a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.grad_color = grad_color; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
+    TDS_CHECK_ARG(grad_out_stride == 0 || grad_out_stride >= 3ll * res * res, "tds_raster_scene_bwd_idx_f32: grad_out_stride must be 0 or at least 3 res^2");
+    a.gstride = grad_out_stride;
     a.n_keys = n_keys;
     for (int i = 0; i < 16; ++i) a.keys[i] = i < n_keys ? keys[i] : 0u;
     a.nb = n_keys <= 3 ? 2 : (n_keys <= 7 ? 3 : 4);                 // as bits_index_bits of the forward
