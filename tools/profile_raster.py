@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--debug', type=int, nargs='*', default=[0])
     ap.add_argument('--u8', action='store_true')
     ap.add_argument('--res', type=int, default=0, help='resolution (default: the bench resolution)')
+    ap.add_argument('--six-keys', action='store_true', help='two agent types: one more distinct key than the bench scene (6 bit planes)')
     ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
     ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
     ap.add_argument('--no-ws', action='store_true', help='fused per-strip kernel instead of the binned persistent kernel')
@@ -41,6 +42,11 @@ def main():
     _ops.use_workspace = not args.no_ws
     _ops.use_bitplanes = not args.no_bits
     sim, actions, _ = bench.build_simulator(args.batch, args.agents, dev, seed=1234)
+    if args.six_keys:
+        sim._agent_types = ['vehicle', 'pedestrian']
+        sim.agent_type = sim.agent_type.clone()
+        sim.agent_type[:, ::2] = 1
+        sim._scene_cache = None
     if args.u8:
         sim.renderer.cfg.out_dtype = 'uint8'
     for i in range(args.steps_before):
