@@ -293,17 +293,26 @@ def launch(args, argv):
     deadline = time.time() + args.launch_timeout
     failed = None
     try:
-        out0 = procs[0].communicate(timeout=args.launch_timeout)[0]
+        # poll: a worker that dies must not leave the others waiting in a barrier until the timeout
+        while failed is None and any(pr.poll() is None for pr in procs):
+            for r, pr in enumerate(procs):
+                rc = pr.poll()
+                if rc is not None and rc != 0:
+                    failed = (r, rc)
+            if time.time() > deadline:
+                failed = ('timeout', -1)
+            time.sleep(0.2)
         for r, pr in enumerate(procs):
-            rc = pr.wait(timeout=max(1.0, deadline - time.time()))
-            if rc != 0 and failed is None:
-                failed = (r, rc)
-    except subprocess.TimeoutExpired:
-        failed = ('timeout', -1)
+            if failed is None and pr.poll() not in (None, 0):
+                failed = (r, pr.poll())
     finally:
         for pr in procs:                        # exact PIDs of the children this process started, nothing else
             if pr.poll() is None:
                 pr.kill()
+        try:
+            out0 = procs[0].communicate(timeout=10)[0] or b''
+        except Exception:
+            out0 = b''
     for ln in out0.decode().splitlines():       # rank 0's JSON line to stdout, anything else it printed to stderr
         (sys.stdout if ln.lstrip().startswith('{') else sys.stderr).write(ln + '\n')
     sys.stdout.flush()

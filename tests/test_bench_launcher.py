@@ -67,3 +67,16 @@ def test_traffic_figure_is_refused_for_another_build(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, 'kernel_source_stamp', lambda: 'deadbeefdeadbeef')
     val, note = bench.stamped_traffic(1024, 64)
     assert val is None and 'refused' in note
+
+
+def test_a_dying_worker_ends_the_launch_promptly(tmp_path):
+    """workers that exit with an error end the launch with an error at once: the launcher polls its children instead of waiting for
+    rank 0 (which would sit in a barrier until the timeout if another rank had died)"""
+    import time
+    t0 = time.time()
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TDS_BENCH_BACKEND'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '-5x'], capture_output=True, text=True,
+                       timeout=300, env=e)
+    assert r.returncode != 0 and time.time() - t0 < 120

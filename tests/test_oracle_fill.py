@@ -95,6 +95,32 @@ def test_live_opencv_cross_check(oracle):
     _live_opencv(oracle)
 
 
+def test_the_live_check_harness_runs(oracle, monkeypatch):
+    """oracle/opencv_check.py has never met a real OpenCV (absent here): run its harness against a stand-in `cv2` that paints with the oracle
+    itself, so that at least its plumbing (argument forms of the reference's call, the replay of the G5 call lists, shapes) is exercised;
+    and against a stand-in that is wrong by one pixel, which it must catch"""
+    import sys
+    import types
+    from oracle import opencv_check
+
+    def make(shift_x):
+        fake = types.ModuleType('cv2')
+        fake.LINE_AA = 16
+
+        def fillConvexPoly(img, points, color, shift=0, lineType=8):
+            assert img.dtype == np.float32 and img.ndim == 3 and points.dtype == np.int32 and points.shape == (3, 2) and shift == 0 and lineType == 16
+            pts = np.ascontiguousarray(points + np.array([shift_x, 0], np.int32))
+            oracle.fill_convex_poly(img, pts, tuple(color))
+            return img
+        fake.fillConvexPoly = fillConvexPoly
+        return fake
+    monkeypatch.setitem(sys.modules, 'cv2', make(0))
+    assert opencv_check.cross_check(oracle, n_random=200) > 200
+    monkeypatch.setitem(sys.modules, 'cv2', make(1))
+    with pytest.raises(AssertionError):
+        opencv_check.cross_check(oracle, n_random=200)
+
+
 def _live_opencv(oracle):
     pytest.importorskip('cv2')
     from oracle import opencv_check
