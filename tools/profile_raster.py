@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--debug', type=int, nargs='*', default=[0])
     ap.add_argument('--u8', action='store_true')
     ap.add_argument('--res', type=int, default=0, help='resolution (default: the bench resolution)')
+    ap.add_argument('--cell', type=float, default=0.0, help='grid cell size of the rendering map in metres (0: the library default)')
     ap.add_argument('--six-keys', action='store_true', help='two agent types: one more distinct key than the bench scene (6 bit planes)')
     ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
     ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
@@ -41,6 +42,9 @@ def main():
     print('library:', 'libtdship.so (product)' if plain else 'libtdship_testing.so')
     _ops.use_workspace = not args.no_ws
     _ops.use_bitplanes = not args.no_bits
+    if args.cell > 0:
+        _orig = _ops.StaticMap.__init__
+        _ops.StaticMap.__init__ = lambda self, *a, **k: _orig(self, *a, **{**k, 'cell_size': args.cell})
     sim, actions, _ = bench.build_simulator(args.batch, args.agents, dev, seed=1234)
     if args.six_keys:
         sim._agent_types = ['vehicle', 'pedestrian']

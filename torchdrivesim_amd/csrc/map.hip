@@ -269,6 +269,11 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
 
     tds_map *m = new (std::nothrow) tds_map();
     if (!m) { tds::set_error("tds_map_create: out of host memory"); return TDS_ENOMEM; }
+    if (entries.size() >= ((size_t)1 << 25)) {            // the raster scan packs an entry index and its grid row into one register (raster.hip: scan_fetch)
+        delete m;
+        tds::set_error("tds_map_create: %zu grid entries (limit 2^25): use a coarser cell size", entries.size());
+        return TDS_ELIMIT;
+    }
     m->V = V; m->F = F; m->n_entries = (int64_t)entries.size(); m->n_levels = face_z ? n_levels : 0;
     m->d_entries = nullptr; m->d_cell_start = nullptr;
     m->near = tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}; m->n_cand = 0;

@@ -651,16 +651,32 @@ __device__ __forceinline__ void drain(WaveCtx &w, bool acc, uint32_t key, const 
     }                                                                                                           \
     __syncthreads();
 
+// ---- wave-level helpers (scan, bit-plane path) ----------------------------------------------------------------------
+// Inclusive scans over the 64 lanes on DPP (row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31); all lanes active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_from(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp_from<0x111, 0xf>(v); v += dpp_from<0x112, 0xf>(v); v += dpp_from<0x114, 0xf>(v); v += dpp_from<0x118, 0xf>(v);
+    v += dpp_from<0x142, 0xa>(v); v += dpp_from<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {           // values >= 0
+    v = max(v, dpp_from<0x111, 0xf>(v)); v = max(v, dpp_from<0x112, 0xf>(v)); v = max(v, dpp_from<0x114, 0xf>(v));
+    v = max(v, dpp_from<0x118, 0xf>(v)); v = max(v, dpp_from<0x142, 0xa>(v)); v = max(v, dpp_from<0x143, 0xc>(v));
+    return v;
+}
+
 // ---- scene producer: actors, then the masked-agent dot, then the static map cells under a pixel window --------------
 constexpr int SCAN_EMPTY_ROW = (int)0xffff7fffu;     // cell range lo = 0x7fff, hi = -1
 struct ScanState {
     int phase, a0;
     bool masked_seen;
-    int cx0, cx1, cy0, nrows, row, chunk, prev_rw;       // wave-uniform: cell rectangle, grid rows to scan, position
+    int cx0, cx1, cy0, nrows, row, chunk, prev_rw;       // wave-uniform: cell rectangle, grid rows to scan, first row of the current block of 64
+                                                         // rows, this wave's next chunk of the block's entry list, cell range of the row before the block
     int rw, re0, re1, rfe;                               // lane r: grid row (block start + r): cell range lo | hi << 16, entry range, end of its first cell
-    // the chunk of entries in flight (scan_fetch): this lane's entry index (-1: none) and data, uniform facts about its grid row
-    bool have, cur_top;
-    int cur_i, cur_fe, cur_pw;
+    // the chunk of entries in flight (scan_fetch): this lane's entry index | its grid row within the block << 25 (-1: none) and data
+    bool have;
+    int cur_i;
     uint4 pu0, pu1;
     MapView map;                                         // the map of this camera's scene (wave-uniform)
 };
@@ -726,7 +742,7 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const Comm
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
-    st.have = false; st.cur_top = false; st.cur_i = -1; st.cur_fe = 0; st.cur_pw = SCAN_EMPTY_ROW;
+    st.have = false; st.cur_i = -1;
     st.pu0 = st.pu1 = make_uint4(0, 0, 0, 0);
     if (m.nx > 0 && !(TDS_DBG(c.debug) & 1)) {
         // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell rectangle
@@ -752,29 +768,38 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const Comm
     }
 }
 
-// Move to the next chunk of map entries (if any) and request this lane's entry of it.
+// Move to the next chunk of map entries (if any) and request this lane's entry of it.  The entry ranges of the (up to 64) grid rows of
+// the current block form ONE list -- lane r holds row r's range, a wave prefix sum numbers the entries -- which is cut into chunks of 64
+// dealt round-robin to the cooperating waves: every chunk but the last of a block is full whatever the rows hold (with a chunk per row
+// range the tails of 6 - 9 short ranges per view idled a third of the lanes).  A lane finds the row of its entry by bisection.
 template <int NW>
 __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, const CommonArgs &c, const Camera &cam, int lane, int X0, int TWw) {
     while (st.row < st.nrows) {
-        const int rl = st.row & 63;
-        const int e0 = __builtin_amdgcn_readlane(st.re0, rl), e1 = __builtin_amdgcn_readlane(st.re1, rl);
-        const int nchunks = (e1 - e0 + 63) >> 6;
-        if (st.chunk < nchunks) {
-            st.cur_fe = __builtin_amdgcn_readlane(st.rfe, rl);
-            st.cur_pw = rl > 0 ? __builtin_amdgcn_readlane(st.rw, rl > 0 ? rl - 1 : 0) : st.prev_rw;     // cell range of the row above
-            st.cur_top = st.row == 0;
-            const int i = e0 + st.chunk * 64 + lane;
-            st.cur_i = i < e1 ? i : -1;
-            if (i < e1) {
+        const int nblk = min(64, st.nrows - st.row);
+        const int cnt = lane < nblk ? st.re1 - st.re0 : 0;
+        const int incl = wave_scan_add(cnt), excl = incl - cnt;
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (st.chunk * 64 < total) {
+            const int v = st.chunk * 64 + lane;
+            int r = 0;                                        // the last row whose first entry number is <= v (rows without entries share the
+#pragma unroll                                                // number of the next one and lose to it)
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int cand = r + step;
+                const int ex = __shfl(excl, cand & 63);
+                if (cand < nblk && ex <= v) r = cand;
+            }
+            const int i = __shfl(st.re0, r) + (v - __shfl(excl, r));
+            st.cur_i = v < total ? (i | (r << 25)) : -1;
+            if (v < total) {
                 const uint4 *ep = (const uint4 *)(m.entries + i);
                 st.pu0 = ep[0]; st.pu1 = ep[1];
             }
             st.chunk += NW;
             return true;
         }
-        st.chunk -= nchunks;
-        ++st.row;
-        if ((st.row & 63) == 0 && st.row < st.nrows) {            // more than 64 grid rows: prepare the next block
+        st.chunk -= (total + 63) >> 6;
+        st.row += 64;
+        if (st.row < st.nrows) {                                  // more than 64 grid rows: prepare the next block
             st.prev_rw = __builtin_amdgcn_readlane(st.rw, 63);
             scan_load_rows(st, m, c, cam, lane, X0, TWw, st.row);
         }
@@ -871,12 +896,15 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
     if (!st.have) st.have = scan_fetch<NW>(st, m, c, cam, lane, X0, TWw);
     if (!st.have) return false;
     {
-        const int i = st.cur_i;
+        const int ci = st.cur_i, i = ci & 0x1ffffff, r = ci >= 0 ? ci >> 25 : 0;
         const uint4 u0 = st.pu0, u1 = st.pu1;
-        const int plo = st.cur_pw & 0xffff, phi = st.cur_pw >> 16;
-        const bool top = st.cur_top;
-        const int first_end = st.cur_fe;
-        if (i >= 0) {
+        // what the owner rule needs to know about the entry's grid row (still the rows of the chunk's block: blocks advance in scan_fetch only)
+        const int first_end = __shfl(st.rfe, r);                                       // end of the row's first scanned cell
+        const int above = __shfl(st.rw, (r + 63) & 63);
+        const int pw = r > 0 ? above : st.prev_rw;                                     // cell range of the row above
+        const int plo = pw & 0xffff, phi = pw >> 16;
+        const bool top = st.row + r == 0;
+        if (ci >= 0) {
             const unsigned own = u1.w;              // see GridEntry::own
             // Exactly one of the scanned cells emits the face: in its grid row the first scanned cell of the face's bounding
             // box; among the rows the first one where the bounding box meets the scanned cells (the row above has none).
@@ -1168,21 +1196,6 @@ __device__ __noinline__ void fill_generic_bits(uint32_t *plane, int H, int W, in
         ex[0] += edx[0];
         ex[1] += edx[1];
     } while (++y <= (int)ymax);
-}
-
-// ---- wave-level helpers of the bit-plane path ----------------------------------------------------------------------
-// Inclusive scans over the 64 lanes on DPP (row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31); all lanes active.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_from(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ int wave_scan_add(int v) {
-    v += dpp_from<0x111, 0xf>(v); v += dpp_from<0x112, 0xf>(v); v += dpp_from<0x114, 0xf>(v); v += dpp_from<0x118, 0xf>(v);
-    v += dpp_from<0x142, 0xa>(v); v += dpp_from<0x143, 0xc>(v);
-    return v;
-}
-__device__ __forceinline__ int wave_scan_max(int v) {           // values >= 0
-    v = max(v, dpp_from<0x111, 0xf>(v)); v = max(v, dpp_from<0x112, 0xf>(v)); v = max(v, dpp_from<0x114, 0xf>(v));
-    v = max(v, dpp_from<0x118, 0xf>(v)); v = max(v, dpp_from<0x142, 0xa>(v)); v = max(v, dpp_from<0x143, 0xc>(v));
-    return v;
 }
 
 // Work items are numbered by a prefix sum over their owners (lane j owns the items [excl_j, incl_j)).  For the window of 64

@@ -79,7 +79,11 @@ class HipRenderer(BirdviewRenderer):
         face_z = verts[first, 2].to(torch.float32).numpy() if faces.shape[0] else np.zeros(0, np.float32)
         face_rgb = _ops.quantise_colors(attrs[first]).numpy().astype(np.uint32) if faces.shape[0] else np.zeros(0, np.uint32)
         levels = level_table(face_z.tolist(), extra_levels)
-        return _ops.StaticMap(verts[:, :2], faces, face_z, face_rgb, levels, device=device or rgb_mesh.device)
+        # grid cells of about two thirds of the field of view: the scan walks one contiguous entry range per grid row under the view, and
+        # fewer, longer ranges beat tighter culling (measured at fov 35 m: 8 m cells 7.59 ms, 24 m 7.40, 48 m 7.64; 128 x 128: 5.53 / 5.25)
+        fov = 2.0 / float(self.scale)
+        return _ops.StaticMap(verts[:, :2], faces, face_z, face_rgb, levels, device=device or rgb_mesh.device,
+                              cell_size=min(max(0.65 * fov, 8.0), 32.0))
 
     def render_scene(self, static_map: _ops.StaticMap, state: Tensor, agent_sc: Tensor, tmpl: Tensor, actor_key: Tensor, mask: Tensor,
                      camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None,
