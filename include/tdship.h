@@ -315,7 +315,7 @@ int tds_raster_set_strip_width(int tw);
 /* waves per workgroup of the bit-plane raster kernel (4 or 8) */
 int tds_raster_set_bits_waves(int n);
 /* ablation switches of K3: 1 no static map, 2 no actors, 4 no store, 8 no outline edges, 16 no scan conversion, 32 no binned path,
- * 64 no bit planes, 128 work counters on */
+ * 64 no bit planes, 128 work counters on, 512 no per-face set-up (nothing is painted), 1024 walk the grid but project nothing */
 int tds_raster_set_debug(int flags);
 /* read and reset the 16 work counters of the bit-plane kernel */
 int tds_raster_get_stats(unsigned long long *out16);

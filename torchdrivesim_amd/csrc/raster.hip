@@ -911,7 +911,7 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
             const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
             const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
             const bool none_above = !(own & (1u << 27)) || top || bx1 < plo || bx0 > phi;
-            if (first_in_row && none_above) {
+            if (first_in_row && none_above && !(TDS_DBG(c.debug) & 1024)) {      // 1024: ablation, walk the grid but project nothing
                 float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
                 float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
                 key = u1.z;
@@ -1317,6 +1317,7 @@ constexpr int HCHUNK = TDS_HCHUNK;    // rows per item: x-major outline edges (o
 __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush) {
     const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0, TWp = w.TWp, wpr = w.wpr;
     wave_sync();
+    if (TDS_DBG(w.debug) & 512) return;                       // ablation: no per-face set-up either
     uint32_t kidx = 0, em = 0, v0 = 0, v1 = 0, v2 = 0;
     FaceRows r = {0, 0, 0, 0, 0, 0};
     Chain a = {0, 0, NO_SWITCH, 0, 0}, b = {0, 0, NO_SWITCH, 0, 0};
