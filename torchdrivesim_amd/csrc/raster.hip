@@ -1998,8 +1998,15 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
             // strip width: the whole (32-padded) image if the planes fit 64 KiB, else the widest multiple of 32 that does
             int twp = (res + 31) & ~31;
             while (twp > 32 && (size_t)kt.n * res * (twp / 8) > 64 * 1024) twp -= 32;
-            if (g_force_tw >= 32 && g_force_tw < twp) twp = g_force_tw;     // tuning hook
             const int nwv = g_bits_waves;
+            // Three workgroups per CU need at most 52 KiB each (160 KiB of LDS, allocated in 2 KiB steps): five keys at 256 x 256 just fit.
+            // A whole image that fits 64 KiB but not 52 runs at two workgroups per CU; two half-image strips at three are a little faster
+            // although each strip scans the grid for itself (six keys at 256 x 256: 10.7 -> 10.1 ms).
+            if (twp == ((res + 31) & ~31) && twp >= 128 && bits_lds_bytes(kt.n, res, twp, nwv, out_mode) > 52 * 1024) {
+                const int half = ((twp / 2) + 31) & ~31;
+                if (bits_lds_bytes(kt.n, res, half, nwv, out_mode) <= 52 * 1024) twp = half;
+            }
+            if (g_force_tw >= 32 && g_force_tw < twp) twp = g_force_tw;     // tuning hook
             size_t lds = bits_lds_bytes(kt.n, res, twp, nwv, out_mode);
             if (lds <= 150 * 1024) {
                 CommonArgs cb = cm;

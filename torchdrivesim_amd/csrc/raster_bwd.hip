@@ -43,7 +43,7 @@ struct BwdArgs {
 };
 
 __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
-    __shared__ float cam_acc[4];
+    __shared__ float cam_part[(BW_BLOCK / 64) * 4];
     const int64_t img = blockIdx.x;
     const int64_t b = img / a.Nc;
     const int tid = threadIdx.x, sub = tid & (LANES_PER_AGENT - 1);
@@ -53,7 +53,6 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
     const float cs = csc.x, cc = csc.y;
     const int64_t plane = (int64_t)res * res;
     const float *I = a.image + img * 3 * plane, *G = a.grad_out + img * 3 * plane;
-    if (tid < 4) cam_acc[tid] = 0.0f;
     __syncthreads();
     float gcam[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const float view_r = 1.05f * 1.41421356f / a.scale;
@@ -240,14 +239,20 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
         gcam[2] = -Cs;
         gcam[3] = -Cc;
     }
+    // fixed order: a butterfly inside every wave, then the waves' partial sums one after the other (no atomics: the result does not depend
+    // on which wave finishes first)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float v = gcam[q];
         for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if ((tid & 63) == 0) atomicAdd(&cam_acc[q], v);
+        if ((tid & 63) == 0) cam_part[(tid >> 6) * 4 + q] = v;
     }
     __syncthreads();
-    if (tid < 4) a.grad_cam[img * 4 + tid] = cam_acc[tid];
+    if (tid < 4) {
+        float v = 0.0f;
+        for (int wv = 0; wv < BW_BLOCK / 64; ++wv) v += cam_part[wv * 4 + tid];
+        a.grad_cam[img * 4 + tid] = v;
+    }
 }
 
 
@@ -289,7 +294,7 @@ struct BwdIdxArgs {
 
 template <int NB>
 __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxArgs a) {
-    __shared__ float cam_acc[4];
+    __shared__ float cam_part[(BW_BLOCK / 64) * 4];
     __shared__ float4 col_tab[16];                                       // colour of key index i (w unused)
     // dynamic LDS: per wave the owner records + cell queue of the camera pass; then (only when grad_color is asked for) reused as
     // [16 keys][3 channels][BW_BLOCK threads] private sums of the colour pass
@@ -304,7 +309,6 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
     const int64_t plane = (int64_t)res * res;
     const float *G = a.grad_out + img * a.gstride;
     const uint32_t *S = a.slices + (size_t)img * wprT * quads * 16;
-    if (tid < 4) cam_acc[tid] = 0.0f;
     if (tid < 16) {
         uint32_t key = 0;
 #pragma unroll
@@ -549,14 +553,20 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
         gcam[2] = -Cs;
         gcam[3] = -Cc;
     }
+    // fixed order: a butterfly inside every wave, then the waves' partial sums one after the other (no atomics: the result does not depend
+    // on which wave finishes first)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float v = gcam[q];
         for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if ((tid & 63) == 0) atomicAdd(&cam_acc[q], v);
+        if ((tid & 63) == 0) cam_part[(tid >> 6) * 4 + q] = v;
     }
     __syncthreads();
-    if (tid < 4) a.grad_cam[img * 4 + tid] = cam_acc[tid];
+    if (tid < 4) {
+        float v = 0.0f;
+        for (int wv = 0; wv < BW_BLOCK / 64; ++wv) v += cam_part[wv * 4 + tid];
+        a.grad_cam[img * 4 + tid] = v;
+    }
     // ---- colours (optional): dL/dcolour[key][ch] = sum of the incoming gradient over the pixels that show the key -- exact, the image
     // being colour[key index] pixel by pixel.  This pass reads the whole gradient.  Every thread sums runs of equal index along x in
     // registers and adds finished runs to its private column of an LDS table (no atomics: the order of the additions is fixed).
