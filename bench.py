@@ -345,6 +345,8 @@ def main():
     distributed = world > 1
     backend = os.environ.get('TDS_BENCH_BACKEND', 'nccl')
     if args.dry_run:
+        if os.environ.get('TDS_BENCH_DRY_RUN_FAIL_RANK') == str(rank):      # tests/test_bench_launcher.py: a worker that dies at start-up
+            raise SystemExit(3)
         device, backend = torch.device('cpu'), 'gloo'
     else:
         torch.cuda.set_device(local_rank)

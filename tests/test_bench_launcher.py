@@ -69,14 +69,15 @@ def test_traffic_figure_is_refused_for_another_build(tmp_path, monkeypatch):
     assert val is None and 'refused' in note
 
 
-def test_a_dying_worker_ends_the_launch_promptly(tmp_path):
-    """workers that exit with an error end the launch with an error at once: the launcher polls its children instead of waiting for
-    rank 0 (which would sit in a barrier until the timeout if another rank had died)"""
+def test_a_dying_worker_ends_the_launch_promptly():
+    """rank 1 exits at start-up while rank 0 waits for it in the rendezvous: the launcher polls its children, reports the failure and
+    ends rank 0 instead of waiting for the timeout"""
     import time
     t0 = time.time()
-    e = dict(os.environ)
+    e = dict(os.environ, TDS_BENCH_DRY_RUN_FAIL_RANK='1')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TDS_BENCH_BACKEND'):
         e.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '-5x'], capture_output=True, text=True,
-                       timeout=300, env=e)
-    assert r.returncode != 0 and time.time() - t0 < 120
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '0'], capture_output=True,
+                       text=True, timeout=300, env=e)
+    assert r.returncode != 0 and 'worker 1 failed' in (r.stderr + r.stdout) and time.time() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]          # no result line from a failed launch
