@@ -166,15 +166,30 @@ __device__ inline long long div_trunc(long long n, long long d) {
 // ---------------------------------------------------------------------------------------------------------
 struct Chain { int xs1; int dx1; int ysw; int xs2; int dx2; };     // slopes fit int32 for |dx| < 2^15 pixels
 
+// n / d for n < 2^31, 1 <= d < 2^16 and a quotient of at most 2^16: the fp32 estimate (24-bit operand, v_rcp_f32, one product: relative
+// error below 2^-22) is within 0.02 of the exact quotient, so its floor is off by at most one and one correction step in integers makes
+// it exact (q and d fit the 24-bit multiplier, q d < 2^32)
+__device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned d) {
+    unsigned q = (unsigned)((float)n * __builtin_amdgcn_rcpf((float)d));
+    int r = (int)(n - __umul24(q, d));
+    if (r < 0) --q;
+    else if (r >= (int)d) ++q;
+    return q;
+}
+
 // OpenCV's edge slope ((xe - xs) * 2 + dy) / (2 * dy) in 16.16 fixed point, C truncating division.
-// With N = (xe - xs) << 16 this is trunc(N / dy + 1/2); for |xe - xs| < 2^15 it needs one 32-bit unsigned division:
-//   N >= 0: a + (2 r >= dy);   N < 0: 0 if 2|N| <= dy else -(a - (2 r < dy)),   a, r = divmod(|N|, dy)
+// With N = (xe - xs) << 16 this is trunc(N / dy + 1/2):
+//   N >= 0: a + (2 r >= dy);   N < 0: -(a - (2 r < dy)),   a, r = divmod(|N|, dy)
+// (for N < 0 the case 2|N| <= dy -> 0 of the general formula cannot occur: |N| >= 65536 > dy).  |xe - xs| and dy are below 2^15 (packed
+// coordinate range), so divmod(|N|, dy) is two short divisions: |xe - xs| = hi dy + r1, then (r1 << 16) = lo dy + r  ->  a = hi << 16 | lo.
+// A 32-bit unsigned division costs the compiler two quarter-rate multiplies and twenty instructions; there are four per face.
 __device__ inline int edge_dx(int xs, int xe, int dyy) {
-    int N = (xe - xs) << 16;
-    unsigned Na = (unsigned)abs(N), d = (unsigned)dyy;
-    unsigned a = Na / d, r = Na - a * d;
-    if (N >= 0) return (int)(a + ((2u * r >= d) ? 1u : 0u));
-    if (2u * Na <= d) return 0;
+    const int dxs = xe - xs;
+    const unsigned D = (unsigned)abs(dxs), d = (unsigned)dyy;
+    const unsigned hi = udiv_small(D, d), r1 = D - __umul24(hi, d);
+    const unsigned lo = udiv_small(r1 << 16, d), r = (r1 << 16) - __umul24(lo, d);
+    const unsigned a = (hi << 16) + lo;
+    if (dxs >= 0) return (int)(a + ((2u * r >= d) ? 1u : 0u));
     return -(int)(a - ((2u * r < d) ? 1u : 0u));
 }
 
@@ -1214,16 +1229,6 @@ __device__ __forceinline__ int wave_owner(uint32_t *slots, int &gen, int lane, b
     if (lane == 0) m = max(m, tag | carry);
     m = wave_scan_max(m);
     return m & 63;
-}
-
-// n / d for n < 2^30, d >= 1 and a quotient below 2^16: the fp32 estimate is within 0.01 of the exact quotient, one correction
-// step in integers makes it exact
-__device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned d) {
-    unsigned q = (unsigned)((float)n * __builtin_amdgcn_rcpf((float)d));
-    int r = (int)(n - __umul24(q, d));
-    if (r < 0) --q;
-    else if (r >= (int)d) ++q;
-    return q;
 }
 
 // trunc((double)u * (double)v / (double)d) of cv::clipLine for |u v| < 2^30, 0 < |u| <= |d| < 2^16 (exact: see div_trunc)
