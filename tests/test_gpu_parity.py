@@ -432,6 +432,27 @@ def test_k3_untrimmed_rendering_equals_the_oracle(ops, oracle, town, bits):
     assert (ref_u != ref_t).mean() > 0.05                         # the huge triangles fill the background only when nothing is trimmed
 
 
+def test_k3_untrimmed_golden_scene(ops, oracle, town):
+    """the scene of G15 (whose untrimmed call list the oracle reproduces from the reference, tests/test_oracle_golden.py): kernel pixels = oracle"""
+    g = load_golden('g15_preraster_untrimmed.npz')
+    st, sz, pr = g['state'], g['size'], g['present']
+    B, A = st.shape[:2]
+    smap = make_map(ops, g['road_verts'], g['road_faces'], g['road_vert_category'], town['categories'])
+    static = oracle_static(oracle, g['road_verts'], g['road_faces'], g['road_vert_category'], town['categories'])
+    mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
+    sd = dev(st)
+    sc = ops.heading_sc(sd[..., 2])
+    for trim in (False, True):
+        img = ops.raster_scene(smap, sd, sc, dev(oracle.actor_template(sz)), actor_keys(smap, B, A), dev(mask), dev(st[..., :2].copy()), dev(g['cam_sc']),
+                               float(g['fov']), int(g['res']), trim=trim).cpu().numpy()
+        oracle.set_trim_mesh(trim)
+        try:
+            ref = oracle.render_scenes(st, sz, mask, st[..., :2].copy(), g['cam_sc'], *static, float(g['fov']), int(g['res']), agent_sc=sc_np(sc))
+        finally:
+            oracle.set_trim_mesh(True)
+        np.testing.assert_array_equal(img, ref)
+
+
 def test_k3_golden_scenes_bit_exact(ops, oracle, town, testing_lib):
     g = load_golden('g45_mesh_preraster.npz')
     for m in json.loads(str(g['g5_meta'])):

@@ -207,3 +207,35 @@ def test_preraster_call_lists_match_reference(oracle):
                 else:
                     ref_wo_pad.append(k)
             assert runs([k[6:] for k in mine]) == runs([k[6:] for k in ref_wo_pad])
+
+
+def test_untrimmed_call_lists_match_reference(oracle):
+    """G15: CV2RendererConfig(trim_mesh_before_rendering=False) (rendering/cv2.py:15,32-41) -- the reference then hands EVERY face to
+    fillConvexPoly (no padding: the call lists must be equal as multisets, painter-order runs included); with the rule on, the two huge
+    triangles of this scene (no vertex in any view) are dropped."""
+    g = load_golden('g15_preraster_untrimmed.npz')
+    town = load_golden('town01_mesh.npz')
+    cats = [str(c) for c in town['categories']]
+    st, sz, pr = g['state'], g['size'], g['present']
+    B, A = st.shape[:2]
+    sv, sa, sf = oracle.static_mesh_arrays(g['road_verts'], g['road_faces'], g['road_vert_category'], cats)
+    mask = np.broadcast_to(pr[:, None, :], (B, A, A))
+    for name, trim in (('untrimmed', False), ('trimmed', True)):
+        oracle.set_trim_mesh(trim)
+        try:
+            _, tris, cols, cnt = oracle.render_scenes(st, sz, mask, st[..., :2], g['cam_sc'], sv, sa, sf, float(g['fov']), int(g['res']),
+                                                      agent_sc=tsc(st[..., 2]), record=True, images=False)
+        finally:
+            oracle.set_trim_mesh(True)
+        gt, gc = g[f'{name}_tris'].reshape(B * A, -1, 6), g[f'{name}_cols']
+        for i in range(B * A):
+            mine = [tuple(tris[i, k]) + tuple(cols[i, k]) for k in range(cnt[i])]
+            ref = [tuple(gt[i, k]) + tuple(gc[i, k]) for k in range(gt.shape[1])]
+            cm, cr = Counter(mine), Counter(ref)
+            assert not (cm - cr), f'{name} image {i}: calls the reference never made'
+            for k in (cr - cm):                                  # trimmed lists are padded with [0,0,0] faces (mesh.py:314-317), untrimmed ones are not
+                assert trim and k[0] == k[2] == k[4] and k[1] == k[3] == k[5], f'{name} image {i}: missing call {k}'
+            runs = lambda seq: [c for j, c in enumerate(seq) if j == 0 or c != seq[j - 1]]
+            assert runs([c[6:] for c in mine]) == runs([c[6:] for c in ref if not (trim and c[0] == c[2] == c[4] and c[1] == c[3] == c[5])] if trim else [c[6:] for c in ref]), name
+        if not trim:
+            assert all(cnt[i] == gt.shape[1] for i in range(B * A)) and gt.shape[1] == len(g['road_faces']) + 3 * A

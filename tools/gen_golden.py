@@ -161,6 +161,40 @@ def gen_kinematic(out):
     print('g1', {k: v.shape for k, v in d.items()})
 
 
+def gen_preraster_untrimmed(out, cv2, town):
+    """G15: the call list of CV2Renderer with trim_mesh_before_rendering=False (rendering/cv2.py:15,32-41): EVERY face of the mesh goes to
+    fillConvexPoly, in painter order.  A file of its own (the other fixtures keep their bytes).  Two huge triangles that have no vertex in any view
+    are added to the background: trimmed they vanish, untrimmed they are drawn."""
+    from torchdrivesim.mesh import BirdviewMesh
+    from torchdrivesim.rendering import CV2RendererConfig, renderer_from_config
+    g = seeded(1501)
+    centre = (100.0, 60.0)
+    crop = crop_mesh(town, centre, 30.0)
+    v, f, vc = crop.verts[0], crop.faces[0], crop.vert_category[0]
+    big = torch.tensor([[-400.0, -300.0], [600.0, -250.0], [150.0, 700.0], [-350.0, 500.0], [700.0, 400.0], [90.0, 55.0]]) + 0.25
+    nv = v.shape[0]
+    road_i = list(crop.categories).index('road')
+    mesh = BirdviewMesh(verts=torch.cat([v, big])[None], faces=torch.cat([torch.tensor([[nv, nv + 1, nv + 2], [nv + 3, nv + 4, nv + 5]]), f])[None],
+                        categories=list(crop.categories), colors=dict(crop.colors), zs=dict(crop.zs),
+                        vert_category=torch.cat([vc, torch.full((6,), road_i, dtype=vc.dtype)])[None])
+    B, A = 1, 4
+    state = torch.cat([torch.tensor(centre) + (torch.rand(B, A, 2, generator=g) - 0.5) * 30, (torch.rand(B, A, 1, generator=g) - 0.5) * 2 * math.pi,
+                       torch.zeros(B, A, 1)], -1)
+    size = torch.tensor([4.5, 2.0]).expand(B, A, 2).clone()
+    present = torch.tensor([[True, True, False, True]])
+    d = dict(state=npy(state), size=npy(size), present=npy(present), road_verts=npy(mesh.verts[0]), road_faces=npy(mesh.faces[0]).astype(np.int32),
+             road_vert_category=npy(mesh.vert_category[0]).astype(np.uint8), res=np.array(96), fov=np.array(35.0))
+    for name, trim in (('untrimmed', False), ('trimmed', True)):
+        r = renderer_from_config(CV2RendererConfig(trim_mesh_before_rendering=trim))
+        sim = make_sim(state.clone(), size.clone(), present.clone(), road_mesh=mesh.expand(B), renderer=r)
+        tris, cols, shape = render_record(cv2, sim, 96, 35.0)
+        d[f'{name}_tris'], d[f'{name}_cols'] = tris, cols
+        print('g15', name, tris.shape)
+    psi = state[..., 2:3]
+    d['cam_sc'] = npy(torch.cat([torch.sin(psi), torch.cos(psi)], -1))
+    np.savez_compressed(os.path.join(out, 'g15_preraster_untrimmed.npz'), **d)
+
+
 def gen_kinematic_displacement(out):
     """G1b: BicycleByDisplacement / BicycleByOrientedDisplacement (kinematic.py:526-587), a file of its own so that g1_kinematic.npz keeps its bytes"""
     from torchdrivesim.kinematic import BicycleByDisplacement, BicycleByOrientedDisplacement
@@ -864,6 +898,9 @@ def main():
     if args.only == 'displacement':
         gen_kinematic_displacement(args.out)
         return
+    if args.only == 'untrimmed':
+        gen_preraster_untrimmed(args.out, cv2, load_town01())
+        return
     if args.only == 'waypoints':
         gen_waypoints(args.out, cv2, load_town01())
         return
@@ -881,6 +918,7 @@ def main():
     gen_discs_n(args.out)
     gen_noisy_perception(args.out, cv2, town)
     gen_kinematic_displacement(args.out)
+    gen_preraster_untrimmed(args.out, cv2, town)
     with open(os.path.join(args.out, 'PROVENANCE.txt'), 'w') as f:
         f.write(f'generated by tools/gen_golden.py from the reference at {REF} (torchdrivesim {torchdrivesim.__version__}), '
                 f'torch {torch.__version__} CPU, numpy {np.__version__}\n')
