@@ -388,13 +388,29 @@ __device__ float nearest_face_d2_grad_lists(const MapView &m, const tds::NearVie
     const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
     float best = __builtin_inff();
     gx = gy = 0.0f;
-    for (int i = s; i < e && best > stop; ++i) {
-        const tds::NearCand c = nv.cand[i];
-        if (c.lb >= best) break;
-        const GridEntry ge = nv.faces[c.face];
+    // as the forward walk (map.hip: nearest_face_d2_lists): four candidates in flight, a face whose bounding box is already farther than
+    // the running minimum is not evaluated
+    auto consider = [&](const tds::NearCand &c, const GridEntry &ge) {
+        if (c.lb >= best) return;
+        const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
+        const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
+        const float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
+        if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) return;
         float tgx, tgy;
-        float d = tri_d2_grad(px, py, ge, tgx, tgy);
+        const float d = tri_d2_grad(px, py, ge, tgx, tgy);
         if (d < best) { best = d; gx = tgx; gy = tgy; }
+    };
+    int i = s;
+    for (; i + 4 <= e && best > stop; i += 4) {
+        const tds::NearCand c0 = nv.cand[i], c1 = nv.cand[i + 1], c2 = nv.cand[i + 2], c3 = nv.cand[i + 3];
+        if (c0.lb >= best) return best;                         // sorted by lb: nothing further can be nearer
+        const GridEntry g0 = nv.faces[c0.face], g1 = nv.faces[c1.face], g2 = nv.faces[c2.face], g3 = nv.faces[c3.face];
+        consider(c0, g0); consider(c1, g1); consider(c2, g2); consider(c3, g3);
+    }
+    for (; i < e && best > stop; ++i) {
+        const tds::NearCand c0 = nv.cand[i];
+        if (c0.lb >= best) break;
+        consider(c0, nv.faces[c0.face]);
     }
     return best;
 }
