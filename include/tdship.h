@@ -201,7 +201,7 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  *                 the bit-plane kernel (float32 output, res a multiple of 4, at most 15 distinct keys with `actor_keys` listed) -- else
  *                 TDS_ELIMIT -- and receives, per pixel, the 1-based position of the winning key in `keys` (0 = background) as bit-slices:
  *                 uint32 [camera][x / 32][y / 4][slice 0..3][y % 4], bit x % 32; 64 B per (word column, row quad), slices >= index_bits
- *                 unwritten.  x, y = OpenCV pixel coordinates = the last two axes of `out`.
+ *                 are zero.  x, y = OpenCV pixel coordinates = the last two axes of `out`.
  *   keys, n_keys, index_bits   filled by the call (HOST): the ascending key table of the launch (n_keys = 0 when another kernel ran)
  *   flags         input: TDS_RASTER_NO_TRIM draws every face as the reference does with trim_mesh_before_rendering = False */
 #define TDS_RASTER_NO_TRIM 1   /* trim_mesh_before_rendering = False (rendering/cv2.py:15,32-41): keep faces without a vertex in view */
