@@ -81,13 +81,18 @@ def cpu_baseline(host, n_scenes, A):
     state, size, present, actions, verts, faces, vcat, cats = host
     sv, sa, sf = orc.static_mesh_arrays(verts, faces, vcat, cats)
 
+    buffers = {}                                 # image buffers by chunk size: allocated (and first touched) once, not per chunk
+
     def one_step(lo, hi):
         st, sz, pr, act = state[lo:hi], size[lo:hi], present[lo:hi], actions[0, lo:hi]
         n = hi - lo
+        if n not in buffers:
+            buffers[n] = np.empty((n, A, 3, RES, RES), np.float32)
+            buffers[n][:] = 0.0
         s1 = orc.bicycle_step(st, act, np.full((n, A), 1.5, np.float32))
         sc = np.stack([np.sin(s1[..., 2]), np.cos(s1[..., 2])], -1).astype(np.float32)
         mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (n, A, A)))
-        img = orc.render_scenes(s1, sz, mask, s1[..., :2].copy(), sc, sv, sa, sf, FOV, RES, agent_sc=sc)
+        img = orc.render_scenes(s1, sz, mask, s1[..., :2].copy(), sc, sv, sa, sf, FOV, RES, agent_sc=sc, out=buffers[n])
         boxes = np.concatenate([s1[..., :2], sz, s1[..., 2:3]], -1)
         col = orc.collision(boxes, pr, metric='iou', sc=sc)
         off = orc.offroad(s1, sz, verts, faces, 0.5, present=pr, sc=sc)

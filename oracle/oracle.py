@@ -216,7 +216,7 @@ def static_mesh_arrays(verts, faces, vert_category, categories, colors=None, lev
 
 
 def render_scenes(state, size, mask, cam_xy, cam_sc, sverts, sattrs, sfaces, fov, res, agent_sc=None,
-                  actor_levels=None, actor_colors=None, record=False, images=True):
+                  actor_levels=None, actor_colors=None, record=False, images=True, out=None):
     """Simulator.render restatement (reference dataflow).  state B x N x 4, size B x N x 2,
     mask B x Nc x N (present & rendering mask), cam_xy / cam_sc B x Nc x 2.  Returns B x Nc x 3 x H x W."""
     state, size, cam_xy, cam_sc = _f(state), _f(size), _f(cam_xy), _f(cam_sc)
@@ -236,7 +236,10 @@ def render_scenes(state, size, mask, cam_xy, cam_sc, sverts, sattrs, sfaces, fov
     sverts, sattrs = _f(sverts), _f(sattrs)
     sfaces = np.ascontiguousarray(sfaces, dtype=np.int32)
     W = H = int(res)
-    out = np.zeros((B, Nc, 3, H, W), dtype=np.float32) if images else None
+    if images and out is not None:          # a caller's buffer, reused from call to call (every element is written)
+        assert out.shape == (B, Nc, 3, H, W) and out.dtype == np.float32 and out.flags.c_contiguous
+    else:
+        out = np.zeros((B, Nc, 3, H, W), dtype=np.float32) if images else None
     cap = sfaces.shape[0] + 3 * N
     tris = np.zeros((B * Nc, cap, 6), dtype=np.int32) if record else None
     cols = np.zeros((B * Nc, cap, 3), dtype=np.uint8) if record else None

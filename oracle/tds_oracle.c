@@ -722,19 +722,31 @@ ORC_API void orc_set_trim_mesh(int on) { g_trim_mesh = on; }
  * verts V x 3 (x,y,z), attrs V x 3 in [0,1], faces F x 3, camera (cx,cy,sin,cos).
  * image: H x W x 3 float, ALREADY transposed as the reference returns it: image[px][py][ch].
  * If rec_tris != NULL the ordered pre-raster call list is written there (cap rec_cap calls): 6 ints + 3 colour. */
-ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, const int32_t *faces, int64_t V, int64_t F,
-                                        float cx, float cy, float s, float c, float scale, int W, int H,
-                                        float *image, int32_t *rec_tris, uint8_t *rec_cols, int64_t rec_cap) {
+/* scratch of one render call; render_scratch_* let a caller that renders many images of one size reuse it (large blocks come from mmap in
+ * glibc: allocating and zero-filling 2.4 MB per image from hundreds of threads serialises on the process's address-space lock) */
+typedef struct { float *sv; uint8_t *ins; zface *order; float *raw; int64_t V, F; int W, H; } render_scratch;
+static void render_scratch_init(render_scratch *rs, int64_t V, int64_t F, int W, int H) {
+    rs->V = V; rs->F = F; rs->W = W; rs->H = H;
+    rs->sv = (float *)malloc(sizeof(float) * 2 * (V > 0 ? V : 1));
+    rs->ins = (uint8_t *)malloc(V > 0 ? V : 1);
+    rs->order = (zface *)malloc(sizeof(zface) * (F > 0 ? F : 1));
+    rs->raw = (float *)malloc(sizeof(float) * (size_t)W * H * 3);
+}
+static void render_scratch_free(render_scratch *rs) { free(rs->sv); free(rs->ins); free(rs->order); free(rs->raw); }
+
+static int64_t render_rgb_mesh_one(render_scratch *rs, const float *verts, const float *attrs, const int32_t *faces, int64_t V, int64_t F,
+                                   float cx, float cy, float s, float c, float scale, int W, int H,
+                                   float *image, int32_t *rec_tris, uint8_t *rec_cols, int64_t rec_cap) {
     float poly[4][2];
     viewing_polygon(s, c, scale, W, H, poly);
-    float *sv = (float *)malloc(sizeof(float) * 2 * (V > 0 ? V : 1));
-    uint8_t *ins = (uint8_t *)malloc(V > 0 ? V : 1);
+    float *sv = rs->sv;
+    uint8_t *ins = rs->ins;
     for (int64_t v = 0; v < V; ++v) {
         sv[2 * v] = verts[3 * v] + (-cx);                             /* mesh.translate(-cameras.xy) cv2.py:29-31 */
         sv[2 * v + 1] = verts[3 * v + 1] + (-cy);
         ins[v] = (uint8_t)inside_quad(sv[2 * v], sv[2 * v + 1], poly);
     }
-    zface *order = (zface *)malloc(sizeof(zface) * (F > 0 ? F : 1));
+    zface *order = rs->order;
     int64_t nk = 0;
     for (int64_t f = 0; f < F; ++f) {                                 /* mesh.trim: keep iff >= 1 vertex inside */
         const int32_t *fv = faces + 3 * f;
@@ -746,7 +758,8 @@ ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, 
         }
     }
     qsort(order, nk, sizeof(zface), zcmp);                            /* painter order, cv2.py:44-47 */
-    float *raw = (float *)calloc((size_t)W * H * 3, sizeof(float));   /* OpenCV image: raw[y][x] */
+    float *raw = rs->raw;                                              /* OpenCV image: raw[y][x], zeroed (cv2.py:53) */
+    memset(raw, 0, sizeof(float) * (size_t)W * H * 3);
     for (int64_t k = 0; k < nk; ++k) {
         const int32_t *fv = faces + 3 * order[k].f;
         int32_t pts[6];
@@ -763,7 +776,16 @@ ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, 
     if (image)                                                        /* image.transpose(-2,-3) cv2.py:61; lh flips cancel :63-69 */
         for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
             memcpy(image + ((int64_t)x * H + y) * 3, raw + ((int64_t)y * W + x) * 3, 3 * sizeof(float));
-    free(raw); free(order); free(ins); free(sv);
+    return nk;
+}
+
+ORC_API int64_t orc_render_rgb_mesh_one(const float *verts, const float *attrs, const int32_t *faces, int64_t V, int64_t F,
+                                        float cx, float cy, float s, float c, float scale, int W, int H,
+                                        float *image, int32_t *rec_tris, uint8_t *rec_cols, int64_t rec_cap) {
+    render_scratch rs;
+    render_scratch_init(&rs, V, F, W, H);
+    int64_t nk = render_rgb_mesh_one(&rs, verts, attrs, faces, V, F, cx, cy, s, c, scale, W, H, image, rec_tris, rec_cols, rec_cap);
+    render_scratch_free(&rs);
     return nk;
 }
 
@@ -795,6 +817,8 @@ ORC_API void orc_render_scenes(const float *state, const float *agent_sc, const 
     memcpy(verts, sverts, sizeof(float) * 3 * Vs);
     memcpy(attrs, sattrs, sizeof(float) * 3 * Vs);
     memcpy(faces, sfaces, sizeof(int32_t) * 3 * Fs);
+    render_scratch rs;
+    render_scratch_init(&rs, V, F, W, H);
     #pragma omp for schedule(dynamic, 1)
     for (int64_t img = 0; img < B * Nc; ++img) {
         int64_t b = img / Nc;
@@ -815,7 +839,7 @@ ORC_API void orc_render_scenes(const float *state, const float *agent_sc, const 
                 /* masked agents: faces * 0, then + Vs in concat -> alias the first actor vertex (mesh.py:1083-1089) */
                 faces[3 * (Fs + 3 * a + f) + j] = (int32_t)(Vs + (on ? 7 * a + tf[f][j] : 0));
         }
-        int64_t n = orc_render_rgb_mesh_one(verts, attrs, faces, V, F, cam_xy[2 * img], cam_xy[2 * img + 1],
+        int64_t n = render_rgb_mesh_one(&rs, verts, attrs, faces, V, F, cam_xy[2 * img], cam_xy[2 * img + 1],
                                             cam_sc[2 * img], cam_sc[2 * img + 1], scale, W, H, out ? hwc : NULL,
                                             rec_tris ? rec_tris + img * rec_cap * 6 : NULL,
                                             rec_cols ? rec_cols + img * rec_cap * 3 : NULL, rec_cap);
@@ -826,6 +850,7 @@ ORC_API void orc_render_scenes(const float *state, const float *agent_sc, const 
         }
     }
     free(verts); free(attrs); free(faces); free(hwc);
+    render_scratch_free(&rs);
     }
 }
 
