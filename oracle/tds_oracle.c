@@ -571,6 +571,12 @@ static void orc_line(orc_img *im, int ax, int ay, int bx, int by, const float *c
     }
 }
 
+/* one directed cv::Line call on a raw image (tests/fill_rows_model.c draws single edges with it: clipLine depends on the order of the end points) */
+ORC_API void orc_line_px(float *img, int W, int H, int ax, int ay, int bx, int by, const float *col) {
+    orc_img im = { img, W, H };
+    orc_line(&im, ax, ay, bx, by, col);
+}
+
 /* cv::FillConvexPoly, shift = 0, line_type = 8 (LINE_AA is downgraded for non-8-bit images). */
 ORC_API void orc_fill_convex_poly(float *img, int W, int H, const int32_t *pts, int npts, const float *col) {
     enum { XY_SHIFT = 16 };

@@ -1319,107 +1319,198 @@ constexpr int CHUNK = TDS_FCHUNK;     // rows per item: scan conversion
 constexpr int VCHUNK = TDS_VCHUNK;    // rows per item: y-major outline edges (one pixel per row)
 constexpr int HCHUNK = TDS_HCHUNK;    // rows per item: x-major outline edges (one run per row)
 
+// ---- outline edges merged into the rows -------------------------------------------------------------------------------------
+// cv::fillConvexPoly paints Line(v2,v0) + Line(v0,v1) + Line(v1,v2) + the scan-converted rows.  For an edge that lies inside the image
+// (cv::Line does not clip it) the pixels of the edge in a row and the scan-converted span of that row are ONE run of pixels, and its
+// ends follow from the 16.16 edge chain of the scan conversion by an add and a shift -- the edge is never walked:
+//   y-major (|dy| > |dx|): cv::Line paints x(tau) = x0 + dx tau / |dy| rounded to nearest, a tie going to the LEFT pixel (either direction
+//     of the walk); the span ends at floor(chain + 1/2).  Left end: floor(chain + 1/2 - BIAS), right end unchanged.
+//   x-major: row tau holds the pixels x with x(tau - 1/2) < x <= x(tau + 1/2), cut at the edge's end points:
+//     floor(chain - slope/2 + BIAS) + 1 .. floor(chain + slope/2 + BIAS), merged with the span by min / max.
+// The chain strays from the exact line: OpenCV's slope is trunc(q + 1/2) in units of 2^-16, i.e. within 1/2 unit of q for q >= 0 but
+// between 1/2 and 3/2 units ABOVE it for q < 0, per row.  The half-row positions of the exact line are multiples of 1/(2|dy|): BIAS must
+// exceed the accumulated error and, with it, stay below 1/(2|dy|) -- 160 units for |dy| <= 100 (3/2 * 100 < 160, 160 + 150 < 32768 / 100).
+// Edges of up to 147 rows whose half-row positions are never integers (no ties) need no bias (3/2 * 147 < 32768 / 147).  Everything
+// else -- edges that cv::clipLine would touch, longer edges -- is walked exactly (edge ring below).  The rows of the three vertices are
+// painted apart, by the face's own lane (the runs are cut at the end points there); the rows in between are work items.
+// tests/fill_rows_model.c is this rule as sequential C, checked triangle by triangle against the oracle's cv::fillConvexPoly
+// (exhaustively on small grids, millions of random triangles at 64..1024 pixels).
+constexpr int MERGE_BIAS = 160, MERGE_DY_BIAS = 100, MERGE_DY_NOBIAS = 147;
+
+// bit 0: the edge is merged into the rows, bit 1: x-major, bit 2: biased
+__device__ __forceinline__ unsigned edge_class(int ax, int ay, int bx, int by, int W, int H) {
+    const bool inside = (unsigned)ax < (unsigned)W && (unsigned)bx < (unsigned)W && (unsigned)ay < (unsigned)H && (unsigned)by < (unsigned)H;
+    const int adx = abs(bx - ax), ady = abs(by - ay);
+    const bool xmaj = adx >= ady;
+    const int fx = __ffs(adx), fy = __ffs(ady);                       // 1 + trailing zeros, 0 for 0
+    const bool tiefree = xmaj ? (fx <= fy) : (adx == 0 || fx >= fy);
+    const bool merge = inside && (ady <= MERGE_DY_BIAS || (ady <= MERGE_DY_NOBIAS && tiefree));
+    return (merge ? 1u : 0u) | (xmaj ? 2u : 0u) | (ady <= MERGE_DY_BIAS ? 4u : 0u);
+}
+// row ends of a chain that follows an edge of class `cls` with 16.16 slope s: left = (x + offL) >> 16, right = (x + offR) >> 16
+__device__ __forceinline__ void edge_offsets(unsigned cls, int s, int &offL, int &offR) {
+    const int bias = (cls & 4u) ? MERGE_BIAS : 0;
+    const int h = abs(s) >> 1;
+    const bool mx = (cls & 3u) == 3u;
+    offL = mx ? min(32768, 65536 - h + bias) : ((cls & 1u) ? 32768 - bias : 32768);
+    offR = mx ? max(32768, h + bias) : 32768;
+}
+// the pixels of a merged edge in the row of its end point x0: x0 itself and, x-major, the run from x0 towards x0 + d (d = half a row's
+// advance along the edge, 16.16, signed)
+__device__ __forceinline__ void edge_reach(unsigned cls, int x0, int d, int &L, int &R) {
+    if (cls & 1u) {
+        L = min(L, x0); R = max(R, x0);
+        if (cls & 2u) {
+            const int v = ((x0 << 16) + d + ((cls & 4u) ? MERGE_BIAS : 0)) >> 16;
+            if (d >= 0) R = max(R, v); else L = min(L, v + 1);
+        }
+    }
+}
+__device__ __forceinline__ int half_slope(int s) { return s >= 0 ? (s >> 1) : -((-s) >> 1); }
+
 __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush) {
     const int lane = w.lane, H = w.H, W = w.W, X0 = w.X0, TWp = w.TWp, wpr = w.wpr;
+    const int Xhi = min(W, X0 + TWp) - 1;                              // last column of the strip (X0 = first)
     wave_sync();
     if (TDS_DBG(w.debug) & 512) return;                       // ablation: no per-face set-up either
-    uint32_t kidx = 0, em = 0, v0 = 0, v1 = 0, v2 = 0;
-    FaceRows r = {0, 0, 0, 0, 0, 0};
-    Chain a = {0, 0, NO_SWITCH, 0, 0}, b = {0, 0, NO_SWITCH, 0, 0};
+    // ---- per-face set-up (lane = face): vertices by row (T, M, B), the three 16.16 slopes, the rows of the vertices painted on the spot,
+    //      the rows in between described as two parts (T..M: chains T->M and T->B; M..B: chains M->B and T->B)
+    uint32_t kidx = 0, ring = 0;                  // ring: outline edges (bit l) that have to be walked exactly
+    int pT = 0, pM = 0, sTB = 0, sTM = 0, sMB = 0, ysn1 = 0, ysn2 = 0, nch1 = 0, nch = 0;
+    unsigned cTM = 0, cMB = 0, cTB = 0;
     if (lane < n) {
         const uint32_t q0 = w.q[lane];
-        kidx = q0 & 15u; em = (q0 >> 4) & 7u; v0 = w.q[QCAP + lane]; v1 = w.q[2 * QCAP + lane]; v2 = w.q[3 * QCAP + lane];
-        const int px[3] = {unpack_x(v0), unpack_x(v1), unpack_x(v2)}, py[3] = {unpack_y(v0), unpack_y(v1), unpack_y(v2)};
-        r = face_rows(px, py, H, W, X0, TWp);
-        if (r.nrows > 0) {
-            // vertices rotated so that the first top vertex comes first (selects: a dynamically indexed array would live in scratch)
-            const int im = r.imin;
-            const int rx[3] = {im == 0 ? px[0] : (im == 1 ? px[1] : px[2]), im == 0 ? px[1] : (im == 1 ? px[2] : px[0]), im == 0 ? px[2] : (im == 1 ? px[0] : px[1])};
-            const int ry[3] = {im == 0 ? py[0] : (im == 1 ? py[1] : py[2]), im == 0 ? py[1] : (im == 1 ? py[2] : py[0]), im == 0 ? py[2] : (im == 1 ? py[0] : py[1])};
-            a = make_chain(rx, ry, 0, 1, 2);
-            b = make_chain(rx, ry, 0, 2, 1);
+        const uint32_t v0 = w.q[QCAP + lane], v1 = w.q[2 * QCAP + lane], v2 = w.q[3 * QCAP + lane];
+        kidx = q0 & 15u;
+        const uint32_t em = (q0 >> 4) & 7u;
+        // packed vertices (x & 0xffff | y << 16) compare like (y, x): sorted by row with three instructions
+        const int i0 = (int)v0, i1 = (int)v1, i2 = (int)v2;
+        pT = min(i0, min(i1, i2));
+        const int pB = max(i0, max(i1, i2));
+        pM = max(min(i0, i1), min(max(i0, i1), i2));
+        const int xt = unpack_x((uint32_t)pT), yt = unpack_y((uint32_t)pT), xm = unpack_x((uint32_t)pM), ym = unpack_y((uint32_t)pM);
+        const int xb = unpack_x((uint32_t)pB), yb = unpack_y((uint32_t)pB);
+        const int xmin = min(xt, min(xm, xb)), xmax = max(xt, max(xm, xb));
+        const bool hit = !(xmax < X0 || xmin > Xhi || yb < 0 || yt >= H);
+        if (hit && !(TDS_DBG(w.debug) & 8)) {
+            // outline edges in OpenCV's order and direction (l = 0: v2-v0, 1: v0-v1, 2: v1-v2): the ones that are not merged
+            const unsigned m0 = edge_class(unpack_x(v2), unpack_y(v2), unpack_x(v0), unpack_y(v0), W, H) & 1u;
+            const unsigned m1 = edge_class(unpack_x(v0), unpack_y(v0), unpack_x(v1), unpack_y(v1), W, H) & 1u;
+            const unsigned m2 = edge_class(unpack_x(v1), unpack_y(v1), unpack_x(v2), unpack_y(v2), W, H) & 1u;
+            ring = em & ~(m0 | (m1 << 1) | (m2 << 2));
+            cTM = edge_class(xt, yt, xm, ym, W, H); cMB = edge_class(xm, ym, xb, yb, W, H); cTB = edge_class(xt, yt, xb, yb, W, H);
+        }
+        if (hit) {
+            uint32_t *pl = w.planes + (size_t)__umul24(__umul24(kidx, (unsigned)H), (unsigned)wpr);
+            auto paint_row = [&](int y, int L, int R) {
+                const int s0 = max(L, X0), s1 = min(R, Xhi);
+                if ((unsigned)y < (unsigned)H && s0 <= s1) paint_span_bits(pl + y, H, s0 - X0, s1 - X0);
+            };
+            if (yt == yb) {
+                // all in one row: nothing is scan-converted, the merged (horizontal) edges are spans
+                int L = 0x7fffffff, R = -0x7fffffff;
+                if (cTM & 1u) { L = min(L, min(xt, xm)); R = max(R, max(xt, xm)); }
+                if (cMB & 1u) { L = min(L, min(xm, xb)); R = max(R, max(xm, xb)); }
+                if (cTB & 1u) { L = min(L, min(xt, xb)); R = max(R, max(xt, xb)); }
+                paint_row(yt, L, R);
+            } else {
+                sTB = edge_dx(xt, xb, yb - yt);
+                sTM = ym > yt ? edge_dx(xt, xm, ym - yt) : 0;
+                sMB = yb > ym ? edge_dx(xm, xb, yb - ym) : 0;
+                if (!(TDS_DBG(w.debug) & 16)) {
+                    // the row of the top vertex (two of them: the span between them): both chains start here
+                    {
+                        int L = xt, R = xt;
+                        if (ym > yt) edge_reach(cTM, xt, half_slope(sTM), L, R);
+                        else { L = min(xt, xm); R = max(xt, xm); edge_reach(cMB, xm, half_slope(sMB), L, R); }
+                        edge_reach(cTB, xt, half_slope(sTB), L, R);
+                        paint_row(yt, L, R);
+                    }
+                    // the row of the middle vertex when it lies strictly between the others: T->M ends, M->B starts, T->B passes
+                    if (ym > yt && ym < yb) {
+                        int oL, oR;
+                        edge_offsets(cTB, sTB, oL, oR);
+                        const int xc = (xt << 16) + (ym - yt) * sTB;
+                        int L = min(xm, (xc + oL) >> 16), R = max(xm, (xc + oR) >> 16);
+                        edge_reach(cTM, xm, -half_slope(sTM), L, R);
+                        edge_reach(cMB, xm, half_slope(sMB), L, R);
+                        paint_row(ym, L, R);
+                    }
+                    // the row of the bottom vertex is never scan-converted: the last pixels of the merged edges that end there
+                    {
+                        int L = 0x7fffffff, R = -0x7fffffff;
+                        edge_reach(cTB, xb, -half_slope(sTB), L, R);
+                        if (ym < yb) edge_reach(cMB, xb, -half_slope(sMB), L, R);
+                        else {
+                            edge_reach(cTM, xm, -half_slope(sTM), L, R);
+                            if (cMB & 1u) { L = min(L, min(xm, xb)); R = max(R, max(xm, xb)); }      // the horizontal bottom edge
+                        }
+                        paint_row(yb, L, R);
+                    }
+                    // the rows in between
+                    const int ys1 = max(yt + 1, 0), n1 = max(0, min(ym - 1, H - 1) - ys1 + 1);
+                    const int ys2 = max(ym + 1, 0), n2 = max(0, min(yb - 1, H - 1) - ys2 + 1);
+                    ysn1 = ys1 | (n1 << 16); ysn2 = ys2 | (n2 << 16);
+                    nch1 = (n1 + CHUNK - 1) / CHUNK;
+                    nch = nch1 + (n2 + CHUNK - 1) / CHUNK;
+                }
+            }
         }
     }
     TDS_STAT(w, 0, 1); TDS_STAT(w, 1, n);
-    // ---- scan-converted rows ----
-    if (!(TDS_DBG(w.debug) & 16)) {
-        const int nch = (r.nrows + CHUNK - 1) / CHUNK;
+    // ---- the rows between the vertices: items of CHUNK rows of one part ----
+    {
         const int incl = wave_scan_add(nch), excl = incl - nch;
         const int total = __builtin_amdgcn_readlane(incl, 63);
         TDS_STAT(w, 2, total); TDS_STAT(w, 3, (total + 63) / 64);
-        TDS_STAT_LANES(w, 4, r.nrows); TDS_STAT_LANES(w, 15, r.nrows > 0 ? 1 : 0);
-        const int sh_a = (a.xs1 & 0xffff) | (a.xs2 << 16), sh_b = (b.xs1 & 0xffff) | (b.xs2 << 16);
-        const int sh_sw = (min(a.ysw, 0x7fff) & 0xffff) | (min(b.ysw, 0x7fff) << 16);
-        const int sh_y = (r.ymin & 0xffff) | (r.ystart << 16), sh_n = r.nrows | ((int)kidx << 16);
+        TDS_STAT_LANES(w, 4, (ysn1 >> 16) + (ysn2 >> 16)); TDS_STAT_LANES(w, 15, nch > 0 ? 1 : 0);
+        const int sh_f = (int)(kidx | (cTM << 4) | (cMB << 7) | (cTB << 10)) | (nch1 << 16);
         for (int base = 0; base < total; base += 64) {
             const int f = wave_owner(w.slots, w.gen, lane, nch > 0, excl, incl, base);
-            const int ga = __shfl(sh_a, f), gb = __shfl(sh_b, f), gsw = __shfl(sh_sw, f), gy = __shfl(sh_y, f), gn = __shfl(sh_n, f);
-            const int adx1 = __shfl(a.dx1, f), adx2 = __shfl(a.dx2, f), bdx1 = __shfl(b.dx1, f), bdx2 = __shfl(b.dx2, f);
-            const int ex = __shfl(excl, f);
+            const int gT = __shfl(pT, f), gM = __shfl(pM, f), gsTB = __shfl(sTB, f), gsTM = __shfl(sTM, f), gsMB = __shfl(sMB, f);
+            const int g1 = __shfl(ysn1, f), g2 = __shfl(ysn2, f), gf = __shfl(sh_f, f), ex = __shfl(excl, f);
             if (base + lane < total) {
-                const int ymin = (int)(short)(gy & 0xffff), ystart = gy >> 16, nrows = gn & 0xffff;
-                const int y0 = ystart + CHUNK * (base + lane - ex), y1 = min(y0 + CHUNK, ystart + nrows) - 1;
-                const int aysw = (int)(short)(gsw & 0xffff), bysw = gsw >> 16;               // 0x7fff = no second edge
-                const int axs2 = ga >> 16, bxs2 = gb >> 16;
-                int xa = chain_x32((int)(short)(ga & 0xffff), adx1, aysw, axs2, adx2, ymin, y0);
-                int xb = chain_x32((int)(short)(gb & 0xffff), bdx1, bysw, bxs2, bdx2, ymin, y0);
-                int da = y0 >= aysw ? adx2 : adx1, db = y0 >= bysw ? bdx2 : bdx1;
-                uint32_t *rowp = w.planes + (size_t)(__umul24(__umul24((unsigned)(gn >> 16), (unsigned)H), (unsigned)wpr) + (unsigned)y0);
+                const int t = base + lane - ex, n1c = gf >> 16;
+                const bool second = t >= n1c;
+                const int ysn = second ? g2 : g1, ys = ysn & 0xffff, nr = ysn >> 16;
+                const int y0 = ys + CHUNK * (second ? t - n1c : t), y1 = min(y0 + CHUNK, ys + nr) - 1;
+                const int pA = second ? gM : gT, sA = second ? gsMB : gsTM;
+                const unsigned cA = ((unsigned)gf >> (second ? 7 : 4)) & 7u, cB = ((unsigned)gf >> 10) & 7u;
+                int oLa, oRa, oLb, oRb;
+                edge_offsets(cA, sA, oLa, oRa);
+                edge_offsets(cB, gsTB, oLb, oRb);
+                const int xa = (unpack_x((uint32_t)pA) << 16) + (y0 - unpack_y((uint32_t)pA)) * sA;
+                const int xb = (unpack_x((uint32_t)gT) << 16) + (y0 - unpack_y((uint32_t)gT)) * gsTB;
+                int la = xa + oLa, ra = xa + oRa, lb = xb + oLb, rb = xb + oRb;
+                uint32_t *rowp = w.planes + (size_t)(__umul24(__umul24((unsigned)(gf & 15), (unsigned)H), (unsigned)wpr) + (unsigned)y0);
 #pragma unroll
                 for (int i = 0; i < CHUNK; ++i) {
-                    const int y = y0 + i;
-                    if (y <= y1) {
-                        const int xx1 = (min(xa, xb) + 32768) >> 16, xx2 = (max(xa, xb) + 32768) >> 16;
-                        // OpenCV draws [xx1, xx2] clamped to the image unless it lies entirely outside
-                        const int s0 = max(max(xx1, 0), X0), s1 = min(min(xx2, W - 1), X0 + TWp - 1);
+                    if (y0 + i <= y1) {
+                        // OpenCV draws the span clamped to the image unless it lies entirely outside; the merged edges lie inside
+                        const int s0 = max(min(la, lb) >> 16, X0), s1 = min(max(ra, rb) >> 16, Xhi);
                         if (s0 <= s1) paint_span_bits(rowp, H, s0 - X0, s1 - X0);
                     }
-                    xa += da; xb += db;
-                    if (y + 1 == aysw) { xa = axs2 << 16; da = adx2; }
-                    if (y + 1 == bysw) { xb = bxs2 << 16; db = bdx2; }
+                    la += sA; ra += sA; lb += gsTB; rb += gsTB;
                     rowp += 1;
                 }
             }
         }
     }
-    // ---- outline edges ----
-    // The edges to draw go through a per-wave ring of EQCAP entries (two packed end points + plane index) that lives across
-    // batches: 64 of them are taken at a time, so that the per-edge set-up and the row items below run on full waves.
+    // ---- outline edges that are walked exactly ----
+    // They go through a per-wave ring of EQCAP entries (two packed end points + plane index) that lives across batches: 64 of them are
+    // taken at a time, so that the per-edge set-up and the row items below run on full waves.
     if (!(TDS_DBG(w.debug) & 8)) {
-        TDS_STAT(w, 5, __popcll(__ballot(lane < n && (em & 1))) + __popcll(__ballot(lane < n && (em & 2))) + __popcll(__ballot(lane < n && (em & 4))));
+        TDS_STAT_LANES(w, 5, __popc(ring));
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
             if (l < 3) {
-                // push edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) of every face that has to draw it
-                bool has = lane < n && ((em >> l) & 1u);
-                const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
-                // A y-major edge that needs no clipping, |dy| < 256, whose exact line never passes midway between two pixel centres, of a face
-                // that is scan-converted here: every pixel of cv::Line except its end points is the end of a scan-converted span already.
-                // Row tau of the line holds the pixel x0 +- floor((2 dx tau + c) / (2 |dy|)), i.e. x0 + dx tau / |dy| rounded to nearest, ties
-                // (2 |dy| dividing 2 dx tau + |dy|) broken by c.  The span ends at the edge's 16.16 chain x0 + tau * slope, slope rounded to
-                // 2^-16, which strays from the exact line by tau * 2^-17 < 1 / (2 |dy|): it rounds to the same pixel in every row that is
-                // no tie, a non-tie being at least 1 / (2 |dy|) away from one.  A tie needs |dy| (2 m - 1) = 2 dx tau, which has a solution
-                // 0 < tau < |dy| exactly when |dy| / gcd(dx, |dy|) is even, i.e. when |dy| holds more factors of two than dx: edges with
-                // ctz(dx) >= ctz(|dy|) (all odd |dy|, all vertical edges) have none.  Only the end points (the bottom vertex row is never
-                // scan-converted) are painted, here.
-                // Likewise an edge between neighbouring pixels (|dx|, |dy| <= 1: the short sides of the lane-marking slivers) IS its two end
-                // points, and a horizontal edge along the top row of a scan-converted face is that row's span (both chains start in its
-                // end points).
-                if (has) {
-                    const int xa = unpack_x(pa), ya = unpack_y(pa), xb = unpack_x(pb), yb = unpack_y(pb);
-                    const int adx = abs(xb - xa), ady = abs(yb - ya);
-                    const bool inside = (unsigned)xa < (unsigned)W && (unsigned)xb < (unsigned)W && (unsigned)ya < (unsigned)H && (unsigned)yb < (unsigned)H;
-                    const bool covered = r.nrows > 0 && ((ady > adx && ady < 256 && (adx == 0 || __ffs(adx) >= __ffs(ady))) || (ady == 0 && ya == r.ymin));
-                    if (inside && (covered || (adx <= 1 && ady <= 1))) {
-                        uint32_t *pl = w.planes + (size_t)__umul24(__umul24(kidx, (unsigned)H), (unsigned)wpr);
-                        const int la = xa - X0, lb = xb - X0;
-                        if ((unsigned)la < (unsigned)TWp) atomicOr(pl + __umul24((unsigned)(la >> 5), (unsigned)H) + ya, 1u << (la & 31));
-                        if ((unsigned)lb < (unsigned)TWp) atomicOr(pl + __umul24((unsigned)(lb >> 5), (unsigned)H) + yb, 1u << (lb & 31));
-                        has = false;
-                    }
-                }
+                // push edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) of every face that has to walk it
+                const bool has = ((ring >> l) & 1u) != 0;
                 const unsigned long long bm = __ballot(has);
+                if (bm == 0) continue;
                 if (has) {
+                    const uint32_t v0 = w.q[QCAP + lane], v1 = w.q[2 * QCAP + lane], v2 = w.q[3 * QCAP + lane];
+                    const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
                     const int slot = (w.eq_head + w.eq_count + rank) & (EQCAP - 1);
                     w.eq[slot] = pack_xyk(unpack_x(pa), unpack_y(pa), kidx & 3u);
