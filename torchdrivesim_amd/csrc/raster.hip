@@ -694,6 +694,8 @@ struct ScanState {
     int cur_i;
     uint4 pu0, pu1;
     MapView map;                                         // the map of this camera's scene (wave-uniform)
+    uint32_t *dyn;                                       // LDS counter that deals the chunks to the waves as they ask (nullptr: round-robin)
+    int done;                                            // chunks of the blocks of grid rows already left behind (the counter numbers them all)
 };
 
 // Lane r prepares grid row `row0 + r` of the scan: the cells of that row under the window polygon (the pixel window plus a 2 px
@@ -757,7 +759,7 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const Comm
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
-    st.have = false; st.cur_i = -1;
+    st.have = false; st.cur_i = -1; st.dyn = nullptr; st.done = 0;
     st.pu0 = st.pu1 = make_uint4(0, 0, 0, 0);
     if (m.nx > 0 && !(TDS_DBG(c.debug) & 1)) {
         // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell rectangle
@@ -809,10 +811,17 @@ __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, cons
                 const uint4 *ep = (const uint4 *)(m.entries + i);
                 st.pu0 = ep[0]; st.pu1 = ep[1];
             }
-            st.chunk += NW;
+            if (st.dyn != nullptr) {
+                // the next chunk goes to whichever wave asks first: the waves of a camera finish together (they meet at a barrier before the
+                // stream-out, and with three waves per SIMD an idle one costs issue slots)
+                unsigned nxt = 0;
+                if (lane == 0) nxt = atomicAdd(st.dyn, 1u);
+                st.chunk = __builtin_amdgcn_readfirstlane((int)nxt) - st.done;
+            } else st.chunk += NW;
             return true;
         }
         st.chunk -= (total + 63) >> 6;
+        st.done += (total + 63) >> 6;
         st.row += 64;
         if (st.row < st.nrows) {                                  // more than 64 grid rows: prepare the next block
             st.prev_rw = __builtin_amdgcn_readlane(st.rw, 63);
@@ -1375,14 +1384,14 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     if (TDS_DBG(w.debug) & 512) return;                       // ablation: no per-face set-up either
     // ---- per-face set-up (lane = face): vertices by row (T, M, B), the three 16.16 slopes, the rows of the vertices painted on the spot,
     //      the rows in between described as two parts (T..M: chains T->M and T->B; M..B: chains M->B and T->B)
-    uint32_t kidx = 0, ring = 0;                  // ring: outline edges (bit l) that have to be walked exactly
-    int pT = 0, pM = 0, sTB = 0, sTM = 0, sMB = 0, ysn1 = 0, ysn2 = 0, nch1 = 0, nch = 0;
-    unsigned cTM = 0, cMB = 0, cTB = 0;
+    // what a lane keeps of its face: the packed top and middle vertices, the three slopes, the row counts of the two parts (n1 | n2 << 16)
+    // and flags = plane index | classes of T->M, M->B, T->B << 4, 7, 10 | outline edges to walk exactly << 13
+    int pT = 0, pM = 0, sTB = 0, sTM = 0, sMB = 0, n12 = 0, flags = 0;
     if (lane < n) {
         const uint32_t q0 = w.q[lane];
         const uint32_t v0 = w.q[QCAP + lane], v1 = w.q[2 * QCAP + lane], v2 = w.q[3 * QCAP + lane];
-        kidx = q0 & 15u;
-        const uint32_t em = (q0 >> 4) & 7u;
+        const uint32_t kidx = q0 & 15u, em = (q0 >> 4) & 7u;
+        flags = (int)kidx;
         // packed vertices (x & 0xffff | y << 16) compare like (y, x): sorted by row with three instructions
         const int i0 = (int)v0, i1 = (int)v1, i2 = (int)v2;
         pT = min(i0, min(i1, i2));
@@ -1392,13 +1401,23 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
         const int xb = unpack_x((uint32_t)pB), yb = unpack_y((uint32_t)pB);
         const int xmin = min(xt, min(xm, xb)), xmax = max(xt, max(xm, xb));
         const bool hit = !(xmax < X0 || xmin > Xhi || yb < 0 || yt >= H);
+        unsigned cTM = 0, cMB = 0, cTB = 0;
         if (hit && !(TDS_DBG(w.debug) & 8)) {
-            // outline edges in OpenCV's order and direction (l = 0: v2-v0, 1: v0-v1, 2: v1-v2): the ones that are not merged
-            const unsigned m0 = edge_class(unpack_x(v2), unpack_y(v2), unpack_x(v0), unpack_y(v0), W, H) & 1u;
-            const unsigned m1 = edge_class(unpack_x(v0), unpack_y(v0), unpack_x(v1), unpack_y(v1), W, H) & 1u;
-            const unsigned m2 = edge_class(unpack_x(v1), unpack_y(v1), unpack_x(v2), unpack_y(v2), W, H) & 1u;
-            ring = em & ~(m0 | (m1 << 1) | (m2 << 2));
             cTM = edge_class(xt, yt, xm, ym, W, H); cMB = edge_class(xm, ym, xb, yb, W, H); cTB = edge_class(xt, yt, xb, yb, W, H);
+            // Outline edges in OpenCV's order (l = 0: v2-v0, 1: v0-v1, 2: v1-v2; cv::clipLine depends on the direction): the ones that are
+            // not merged and not entirely on one outer side of the image are walked exactly.  Edge l lies opposite vertex (l + 1) % 3;
+            // T->M lies opposite B, M->B opposite T, T->B opposite M (vertices that coincide have edges of the same class).
+            unsigned ring = 0;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int po = (int)(l == 0 ? v1 : (l == 1 ? v2 : v0));
+                const unsigned cl = po == pB ? cTM : (po == pT ? cMB : cTB);
+                const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
+                const int ax = unpack_x(pa), ay = unpack_y(pa), bx = unpack_x(pb), by = unpack_y(pb);
+                const bool gone = (ax < 0 && bx < 0) || (ay < 0 && by < 0) || (ax >= W && bx >= W) || (ay >= H && by >= H);    // clipLine: nothing left
+                ring |= (!(cl & 1u) && !gone) ? (1u << l) : 0u;
+            }
+            flags |= (int)((cTM << 4) | (cMB << 7) | (cTB << 10) | ((em & ring) << 13));
         }
         if (hit) {
             uint32_t *pl = w.planes + (size_t)__umul24(__umul24(kidx, (unsigned)H), (unsigned)wpr);
@@ -1447,12 +1466,9 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                         }
                         paint_row(yb, L, R);
                     }
-                    // the rows in between
-                    const int ys1 = max(yt + 1, 0), n1 = max(0, min(ym - 1, H - 1) - ys1 + 1);
-                    const int ys2 = max(ym + 1, 0), n2 = max(0, min(yb - 1, H - 1) - ys2 + 1);
-                    ysn1 = ys1 | (n1 << 16); ysn2 = ys2 | (n2 << 16);
-                    nch1 = (n1 + CHUNK - 1) / CHUNK;
-                    nch = nch1 + (n2 + CHUNK - 1) / CHUNK;
+                    // the rows in between: part 1 = rows yt+1 .. ym-1, part 2 = rows ym+1 .. yb-1, cut to the image
+                    const int n1 = max(0, min(ym - 1, H - 1) - max(yt + 1, 0) + 1), n2 = max(0, min(yb - 1, H - 1) - max(ym + 1, 0) + 1);
+                    n12 = n1 | (n2 << 16);
                 }
             }
         }
@@ -1460,21 +1476,21 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     TDS_STAT(w, 0, 1); TDS_STAT(w, 1, n);
     // ---- the rows between the vertices: items of CHUNK rows of one part ----
     {
+        const int nch = ((n12 & 0xffff) + CHUNK - 1) / CHUNK + ((n12 >> 16) + CHUNK - 1) / CHUNK;
         const int incl = wave_scan_add(nch), excl = incl - nch;
         const int total = __builtin_amdgcn_readlane(incl, 63);
         TDS_STAT(w, 2, total); TDS_STAT(w, 3, (total + 63) / 64);
-        TDS_STAT_LANES(w, 4, (ysn1 >> 16) + (ysn2 >> 16)); TDS_STAT_LANES(w, 15, nch > 0 ? 1 : 0);
-        const int sh_f = (int)(kidx | (cTM << 4) | (cMB << 7) | (cTB << 10)) | (nch1 << 16);
+        TDS_STAT_LANES(w, 4, (n12 & 0xffff) + (n12 >> 16)); TDS_STAT_LANES(w, 15, nch > 0 ? 1 : 0);
         for (int base = 0; base < total; base += 64) {
             const int f = wave_owner(w.slots, w.gen, lane, nch > 0, excl, incl, base);
             const int gT = __shfl(pT, f), gM = __shfl(pM, f), gsTB = __shfl(sTB, f), gsTM = __shfl(sTM, f), gsMB = __shfl(sMB, f);
-            const int g1 = __shfl(ysn1, f), g2 = __shfl(ysn2, f), gf = __shfl(sh_f, f), ex = __shfl(excl, f);
+            const int gn = __shfl(n12, f), gf = __shfl(flags, f), ex = __shfl(excl, f);
             if (base + lane < total) {
-                const int t = base + lane - ex, n1c = gf >> 16;
+                const int t = base + lane - ex, n1c = ((gn & 0xffff) + CHUNK - 1) / CHUNK;
                 const bool second = t >= n1c;
-                const int ysn = second ? g2 : g1, ys = ysn & 0xffff, nr = ysn >> 16;
-                const int y0 = ys + CHUNK * (second ? t - n1c : t), y1 = min(y0 + CHUNK, ys + nr) - 1;
                 const int pA = second ? gM : gT, sA = second ? gsMB : gsTM;
+                const int ys = max(unpack_y((uint32_t)pA) + 1, 0), nr = second ? gn >> 16 : gn & 0xffff;
+                const int y0 = ys + CHUNK * (second ? t - n1c : t), y1 = min(y0 + CHUNK, ys + nr) - 1;
                 const unsigned cA = ((unsigned)gf >> (second ? 7 : 4)) & 7u, cB = ((unsigned)gf >> 10) & 7u;
                 int oLa, oRa, oLb, oRb;
                 edge_offsets(cA, sA, oLa, oRa);
@@ -1500,12 +1516,12 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     // They go through a per-wave ring of EQCAP entries (two packed end points + plane index) that lives across batches: 64 of them are
     // taken at a time, so that the per-edge set-up and the row items below run on full waves.
     if (!(TDS_DBG(w.debug) & 8)) {
-        TDS_STAT_LANES(w, 5, __popc(ring));
+        TDS_STAT_LANES(w, 5, __popc(((unsigned)flags >> 13) & 7u));
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
             if (l < 3) {
                 // push edge l (0: v2-v0, 1: v0-v1, 2: v1-v2) of every face that has to walk it
-                const bool has = ((ring >> l) & 1u) != 0;
+                const bool has = (((unsigned)flags >> (13 + l)) & 1u) != 0;
                 const unsigned long long bm = __ballot(has);
                 if (bm == 0) continue;
                 if (has) {
@@ -1513,8 +1529,8 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
                     const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
                     const int slot = (w.eq_head + w.eq_count + rank) & (EQCAP - 1);
-                    w.eq[slot] = pack_xyk(unpack_x(pa), unpack_y(pa), kidx & 3u);
-                    w.eq[EQCAP + slot] = pack_xyk(unpack_x(pb), unpack_y(pb), kidx >> 2);
+                    w.eq[slot] = pack_xyk(unpack_x(pa), unpack_y(pa), (uint32_t)flags & 3u);
+                    w.eq[EQCAP + slot] = pack_xyk(unpack_x(pb), unpack_y(pb), ((uint32_t)flags >> 2) & 3u);
                 }
                 w.eq_count += __popcll(bm);
                 wave_sync();
@@ -1524,9 +1540,9 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
             const bool valid = lane < take;
             const int slot = (w.eq_head + lane) & (EQCAP - 1);
             const uint32_t pa = valid ? w.eq[slot] : 0u, pb = valid ? w.eq[EQCAP + slot] : 0u;
-            const int ek = (int)((pa & 3u) | ((pb & 3u) << 2));
             w.eq_head = (w.eq_head + take) & (EQCAP - 1);
             w.eq_count -= take;
+            const int ek = (int)((pa & 3u) | ((pb & 3u) << 2));
             TDS_STAT(w, 6, 1);
             int x1 = unpack_xk(pa), y1 = unpack_yk(pa), x2 = unpack_xk(pb), y2 = unpack_yk(pb);
             bool ok = valid;
@@ -1811,7 +1827,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
         uint32_t kv = 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < 16; ++i) kv = (tid == i) ? kt.key[i] : kv;     // kt lives in SGPRs: no dynamic indexing
-        lkeys[tid] = kv;
+        lkeys[tid] = tid == 15 ? (uint32_t)BWAVES : kv;                    // entry 15 is no key (K <= 15): the next chunk of the grid scan
     }
     __syncthreads();
     for (int e = tid; e < 3 * P; e += BBLOCK) {
@@ -1841,6 +1857,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
     __syncthreads();
     ScanState st;
     scan_init(st, a, c, cam, img, lane, wave, X0, TWp);
+    st.dyn = lkeys + 15;
     for (;;) {
         bool acc;
         uint32_t key;
