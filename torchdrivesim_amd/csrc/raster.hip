@@ -1358,11 +1358,14 @@ __device__ __forceinline__ unsigned edge_class(int ax, int ay, int bx, int by, i
 }
 // row ends of a chain that follows an edge of class `cls` with 16.16 slope s: left = (x + offL) >> 16, right = (x + offR) >> 16
 __device__ __forceinline__ void edge_offsets(unsigned cls, int s, int &offL, int &offR) {
+    // selects, no branches: neighbouring lanes hold edges of every class
     const int bias = (cls & 4u) ? MERGE_BIAS : 0;
     const int h = abs(s) >> 1;
     const bool mx = (cls & 3u) == 3u;
-    offL = mx ? min(32768, 65536 - h + bias) : ((cls & 1u) ? 32768 - bias : 32768);
-    offR = mx ? max(32768, h + bias) : 32768;
+    const int yl = 32768 - ((cls & 1u) ? bias : 0);
+    const int xl = min(32768, 65536 - h + bias), xr = max(32768, h + bias);
+    offL = mx ? xl : yl;
+    offR = mx ? xr : 32768;
 }
 // the pixels of a merged edge in the row of its end point x0: x0 itself and, x-major, the run from x0 towards x0 + d (d = half a row's
 // advance along the edge, 16.16, signed)
@@ -1838,8 +1841,9 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
         if constexpr (sizeof(OutT) == 4) tab[e] = make_float2((float)vlo, (float)vhi);
         else tab[e] = vlo | (vhi << 8);
     }
-    // waves that rasterise take precedence over the waves of other workgroups that are streaming out (measured: -2 % kernel time)
-    __builtin_amdgcn_s_setprio(1);
+    // uint8 output (the kernel is bound by instruction issue): waves that rasterise take precedence over the waves of other workgroups that
+    // are streaming out (measured: -2 %).  float32 output is bound by the HBM write stream: there the raise costs 2 % (7.41 -> 7.23 ms median)
+    if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(1);
     BitCtx w;
     w.planes = planes;
     w.q = lkeys + 16 + wave * BITS_WAVE_LDS_DW;
@@ -1868,7 +1872,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene
         if (!more) break;
     }
     __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(0);
     if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, EMIT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, c.slices);
 }
 
