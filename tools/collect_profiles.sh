@@ -8,7 +8,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# the same command without the profiler, before and after the traced run: rocprofv3's tracing slows this kernel by 1 % on some boxes and by 7 - 16 % on
+# others, so the committed trace comes with the plain figures of the same box and minute
+python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_plain_before.log 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof.log 2>&1
+python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_plain_after.log 2>/dev/null
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 rm -rf $OUT/kt
 for cfg in config2 config3 config5; do

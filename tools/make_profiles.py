@@ -39,6 +39,15 @@ for name, cmd in commands.items():
     if os.path.exists(log):
         lines = [l for l in open(log).read().splitlines() if l.startswith('{')]
         open(os.path.join(dst, f'{tag}_{name}_under_rocprof.log'), 'w').write('\n'.join(lines) + '\n')
+    if name == 'bench':
+        # the plain runs of the same command on the same box, right before and right after the traced one
+        plain = []
+        for when in ('before', 'after'):
+            q = os.path.join(src, f'bench_plain_{when}.log')
+            if os.path.exists(q):
+                plain += [f'# plain run {when} the traced one: ' + l for l in open(q).read().splitlines() if l.startswith('{')]
+        if plain:
+            open(os.path.join(dst, f'{tag}_bench_plain_same_box.log'), 'w').write('\n'.join(plain) + '\n')
 
 out, traffic = dict(kernel_source_sha=stamp, batch=B, agents=A, res=RES,
                     command='tools/collect_profiles.sh: rocprofv3 --pmc <set> --kernel-include-regex raster -- python3 tools/profile_raster.py '
