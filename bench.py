@@ -73,6 +73,19 @@ def build_simulator(B, A, device, seed, metric='iou', lanelet_map=None):
     return sim, torch.from_numpy(actions).to(device), (state, size, present, actions, verts, faces, vcat, cats)
 
 
+def cpu_quota():
+    """CPU quota of this process's cgroup in CPUs (None: unlimited) -- reported beside the thread count of the CPU baseline"""
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q, p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()), int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            return q / p if q > 0 and p > 0 else None
+        except (OSError, ValueError):
+            return None
+
+
 def cpu_baseline(host, n_scenes, A):
     """The oracle (a C port of the reference's CPU path, oracle/tds_oracle.c) timed on this box's host cores on a bounded
     sample of the same workload: the first `n_scenes` scenes, one step."""
@@ -98,7 +111,7 @@ def cpu_baseline(host, n_scenes, A):
         off = orc.offroad(s1, sz, verts, faces, 0.5, present=pr, sc=sc)
         return img, col, off
 
-    cores = os.cpu_count() or 1
+    cores, quota = orc.usable_cpus(), cpu_quota()         # the GPU boxes of this pool show 256 logical CPUs and grant 16 CPUs' worth of time
     out = {}
     for label, threads, count, chunk in (('all', cores, n_scenes, 64), ('one', 1, max(1, min(16, n_scenes // 16)), 4)):
         orc.set_num_threads(threads)
@@ -110,7 +123,8 @@ def cpu_baseline(host, n_scenes, A):
         out[label] = (count * A / dt, dt, count)
     orc.set_num_threads(cores)
     return dict(value=out['all'][0], unit='agent-steps/s', cores=cores, kind='port',
-                sample=f"{out['all'][2]} scenes x {A} agents, 1 step of the same workload (oracle/tds_oracle.c, OpenMP over images) in "
+                sample=f"{out['all'][2]} scenes x {A} agents, 1 step of the same workload (oracle/tds_oracle.c, OpenMP over images, {cores} threads: "
+                       f"{os.cpu_count()} logical CPUs, CPU quota of the cgroup {'none' if quota is None else f'{quota:g} CPUs'}) in "
                        f"{out['all'][1]:.2f} s; single thread: {out['one'][0]:.1f} agent-steps/s on {out['one'][2]} scenes ({out['one'][1]:.2f} s)",
                 value_single_thread=out['one'][0])
 
@@ -334,7 +348,7 @@ def main():
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help="skip the extra `configs` / `roofline_u8` entries (BASELINE.json's configs 2, 3, 5; N = 1 only)")
-    ap.add_argument('--cpu-scenes', type=int, default=320, help='scenes of the CPU-baseline sample (all cores, about 10 s); the single-thread run uses a sixteenth')
+    ap.add_argument('--cpu-scenes', type=int, default=768, help='scenes of the CPU-baseline sample (all usable cores, about 10 s at 16 of them); the single-thread run uses 16')
     ap.add_argument('--dry-run', action='store_true', help='no GPU, no kernels: exercises launch, barrier, reduction and the JSON line only')
     ap.add_argument('--launch-timeout', type=float, default=1500.0)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)

@@ -34,7 +34,27 @@ def lib():
             build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.orc_render_rgb_mesh_one.restype = ctypes.c_int64
+        if 'OMP_NUM_THREADS' not in os.environ:
+            _lib.orc_set_num_threads(ctypes.c_int(usable_cpus()))
     return _lib
+
+
+def usable_cpus():
+    """The CPUs this process may use: its affinity mask cut to the CPU quota of its cgroup.  OpenMP's default is one thread per logical CPU,
+    and a box that shows 256 of them but grants 16 CPUs' worth of time runs 256 threads four times slower than 32."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q, p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()), int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def _f(a):

@@ -547,6 +547,50 @@ def test_k3_large_resolutions_use_strips(ops, oracle, town, res):
     assert (ref > 0).mean() > 0.05
 
 
+@pytest.mark.parametrize('res,fov', [(64, 30.0), (256, 35.0), (256, 12.0), (512, 25.0)])
+def test_k3_triangle_soups_exercise_the_row_rule(ops, oracle, res, fov):
+    """Random triangle soups instead of a road network: slivers, specks, faces larger than the view, everything overlapping, so that the row rule
+    of the bit-plane kernel (outline edges merged into the rows; tests/fill_rows_model.c) meets y- and x-major edges of every length -- at 512
+    pixels and a 25 m view also edges beyond its 100- and 147-row limits, which are walked exactly -- flat tops and bottoms, ties, faces that
+    leave the image on every side; trimmed and untrimmed."""
+    gen = np.random.default_rng(res * 1000 + int(fov))
+    n = 2500
+    c = gen.uniform(-30, 30, (n, 1, 2))
+    kind = gen.integers(0, 5, n)
+    scale = np.choose(kind, [0.15, 0.6, 3.0, 12.0, 40.0])[:, None, None]
+    tri = c + gen.normal(0, 1, (n, 3, 2)) * scale
+    sl = kind == 1                                                          # slivers: two vertices 0.1 m apart, the third several metres away
+    tri[sl, 1] = tri[sl, 0] + gen.normal(0, 0.1, (sl.sum(), 2))
+    tri[sl, 2] = tri[sl, 0] + gen.normal(0, 4.0, (sl.sum(), 2))
+    ax = gen.integers(0, 4, n) == 0                                         # some axis-parallel edges (they stay so for the unrotated cameras)
+    tri[ax, 1, 1] = tri[ax, 0, 1]
+    verts = tri.reshape(-1, 2).astype(np.float32)
+    faces = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    cats = ['road', 'left_lane', 'right_lane']
+    vc = np.repeat(gen.integers(0, 3, n), 3).astype(np.int64)
+    smap = make_map(ops, verts, faces, vc, cats)
+    static = oracle_static(oracle, verts, faces, vc, cats)
+    B, A = 3, 4
+    state = np.concatenate([gen.uniform(-25, 25, (B, A, 2)), gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
+    state[0, :, 2] = np.array([0.0, np.pi / 2, np.pi, -np.pi / 2])          # unrotated cameras: axis-parallel edges stay horizontal / vertical
+    size = np.concatenate([gen.uniform(3.5, 6, (B, A, 1)), gen.uniform(1.6, 2.4, (B, A, 1))], -1).astype(np.float32)
+    mask = gen.uniform(size=(B, A, A)) < 0.8
+    cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
+    sd = dev(state)
+    args = (smap, sd, ops.heading_sc(sd[..., 2]), dev(oracle.actor_template(size)), actor_keys(smap, B, A), dev(mask), dev(state[..., :2].copy()), dev(cam_sc), fov, res)
+    sv, sa, sf = static
+    for trim in (True, False):
+        img = ops.raster_scene(*args, trim=trim).cpu().numpy()
+        oracle.set_trim_mesh(trim)
+        try:
+            ref = oracle.render_scenes(state, size, mask, state[..., :2].copy(), cam_sc, sv, sa, sf, fov, res, agent_sc=cam_sc)
+        finally:
+            oracle.set_trim_mesh(True)
+        bad = img != ref
+        assert not bad.any(), f'res {res} fov {fov} trim {trim}: {bad.sum()} values differ in {bad.any(axis=(2, 3, 4)).sum()} images'
+        assert (ref > 0).mean() > 0.2
+
+
 def test_k3_faces_far_outside_the_packed_coordinate_range(ops, oracle):
     """a ground quad of 1 km seen at 51 px / m puts its vertices 25 000 pixels away from the image: such faces cannot be packed into
     16-bit coordinates and take the sequential exact path (fill_generic / fill_generic_bits), on every kernel family"""

@@ -1284,20 +1284,16 @@ __device__ inline bool clip_line_small(int W, int H, int &x1, int &y1, int &x2, 
     return (c1 | c2) == 0;
 }
 
-__device__ __forceinline__ int chain_x32(int xs1, int dx1, int ysw, int xs2, int dx2, int ymin, int y) {
-    const bool second = y >= ysw;
-    return ((second ? xs2 : xs1) << 16) + (y - (second ? ysw : ymin)) * (second ? dx2 : dx1);
-}
-
-// Rasterise the first n (<= 64) faces of the wave's queue into the bit planes.  Work is cut into items of CHUNK consecutive rows,
-// numbered by wave prefix sums and mapped back to their owners by wave_owner(); a lane enters its item in closed form and then
-// advances incrementally, one span (one or two ds_or) per row:
-//   1. lane f sets up face f (rows of OpenCV's scan conversion, the two edge chains: one 32-bit division per edge);
-//   2. items of CHUNK scan-converted rows: the two chain positions in 16.16 (32-bit);
-//   3. the outline edges that have to be drawn (OpenCV: Line(v2,v0), Line(v0,v1), Line(v1,v2); edges shared with an earlier
-//      same-key face are skipped) are set up one per lane: clipLine, left-to-right order, then rewritten top-down so that the
-//      pixels of row tau of the walk are a closed form of tau (below);
-//   4. items of CHUNK rows of an edge: the pixels of cv::Line in one row are one run, painted like a span.
+// Rasterise the first n (<= 64) faces of the wave's queue into the bit planes (process_batch_bits, below):
+//   1. lane f sets up face f: vertices by row, the three 16.16 slopes of OpenCV's scan conversion (one short division pair per edge),
+//      which outline edges are merged into the rows and which have to be walked exactly; it paints the rows of the three vertices;
+//   2. the rows between the vertices are cut into items of CHUNK consecutive rows of one part (top..middle, middle..bottom), numbered by
+//      wave prefix sums and mapped back to their owners by wave_owner(); a lane enters its item in closed form and then advances four
+//      running sums, one span (one or two ds_or) per row;
+//   3. the outline edges that are walked exactly (OpenCV: Line(v2,v0), Line(v0,v1), Line(v1,v2); edges shared with an earlier same-key
+//      face are skipped) wait in a per-wave ring and are set up 64 at a time, one per lane: clipLine, left-to-right order, then rewritten
+//      top-down so that the pixels of row tau of the walk are a closed form of tau (below);
+//   4. items of VCHUNK / HCHUNK rows of such an edge: the pixels of cv::Line in one row are one run, painted like a span.
 // Bresenham in closed form.  After the left-to-right swap the walk starts at (px, py), dx >= 0, and after k steps the minor axis has
 // advanced m_k = floor((2 dmin k + dmaj - 1) / (2 dmaj)) (see draw_line).  Seen from the TOP end point (x0, ytop), rows tau = 0..|dy|,
 // x moving by sgn = +1 (walk goes down) or -1 (walk goes up):
