@@ -377,11 +377,23 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')        # one node: gloo must not depend on the host name resolving
             if backend == 'nccl':
-                dist.init_process_group('nccl', device_id=device)
-            else:
+                # The process group only carries the barrier around the timed region and the reduction of the timings (no collective is on
+                # the data path), so if RCCL cannot be brought up the run is still valid over gloo: fall back instead of losing the measurement.
+                try:
+                    dist.init_process_group('nccl', device_id=device)
+                    dist.barrier()
+                except Exception as exc:                                 # noqa: BLE001 -- whatever RCCL raises
+                    sys.stderr.write(f'[bench] rank {rank}: RCCL process group failed ({type(exc).__name__}: {exc}); falling back to gloo\n')
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:                                    # noqa: BLE001
+                        pass
+                    backend = 'gloo'
+            if backend != 'nccl':
                 dist.init_process_group('gloo')
-            dist.barrier()
+                dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)

@@ -46,6 +46,9 @@ for name, cmd in commands.items():
             q = os.path.join(src, f'bench_plain_{when}.log')
             if os.path.exists(q):
                 plain += [f'# plain run {when} the traced one: ' + l for l in open(q).read().splitlines() if l.startswith('{')]
+        q = os.path.join(src, 'bench_traced_runs.txt')
+        if os.path.exists(q):
+            plain = ['# ' + l.strip() for l in open(q)] + plain
         if plain:
             open(os.path.join(dst, f'{tag}_bench_plain_same_box.log'), 'w').write('\n'.join(plain) + '\n')
 
