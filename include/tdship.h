@@ -236,10 +236,13 @@ int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
  *   image, grad_out  B x Nc x 3 x H x W float32: the forward output (TDS_OUT_F32) and the incoming gradient
  *   grad_agent       B x Nc x N x 4   [d/dx, d/dy, d/dsin(psi), d/dcos(psi)] of actor n as seen by camera c (caller sums over c)
  *   grad_cam         B x Nc x 4       [d/dcx, d/dcy, d/dsin, d/dcos] of the camera: every colour boundary of the image moves with it
- * Both outputs are overwritten. */
+ *   grad_tmpl        optional (NULL to skip), B x Nc x N x 7 x 2: d/d(template vertex v) of actor n as seen by camera c -- the actor's
+ *                    outline in its own frame (mesh.py:911-996).  The caller sums over c and chains to the actor's length and width
+ *                    through the construction of the template.
+ * All outputs are overwritten. */
 int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                              const float *cam_sc, const float *image, const float *grad_out, int64_t B, int64_t Nc, int64_t N,
-                             float scale, int res, float *grad_agent, float *grad_cam, void *stream);
+                             float scale, int res, float *grad_agent, float *grad_cam, float *grad_tmpl, void *stream);
 
 /* The same gradient computed from the forward's key-index slices (tds_raster_aux_t) instead of the forward image: the incoming gradient
  * is read only next to colour boundaries.  keys / n_keys: HOST, the key table the forward launch reported.
@@ -251,7 +254,7 @@ int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const fl
 int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                                  const float *cam_sc, const uint32_t *index_slices, const uint32_t *keys, int n_keys, const float *grad_out,
                                  int64_t grad_out_stride, int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent,
-                                 float *grad_cam, float *grad_color, void *stream);
+                                 float *grad_cam, float *grad_color, float *grad_tmpl, void *stream);
 
 /* Generic BirdviewRenderer.render_rgb_mesh (rendering/base.py:206-212) for an arbitrary per-camera RGB mesh:
  *   verts n_img x V x 3 (x, y, z), attrs n_img x V x 3 in [0,1], faces n_img x F x 3 int32,

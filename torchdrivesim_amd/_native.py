@@ -61,8 +61,8 @@ _SIGNATURES = {
     'tds_offroad_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     'tds_raster_scene': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
     'tds_raster_index_slices_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
-    'tds_raster_scene_bwd_idx_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
-    'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp],
+    'tds_raster_scene_bwd_idx_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
+    'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
     'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _i32, _vp],
     'tds_lanelet_centerline_f64': [_vp, _i32, _vp, _i32, _vp, ctypes.POINTER(_i32)],

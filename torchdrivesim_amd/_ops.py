@@ -517,7 +517,7 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
 
 class _RasterScene(torch.autograd.Function):
     """Differentiable wrapper of the fused scene rasteriser.  Forward: tds_raster_scene (CV2 pixel semantics).  Backward: the build-defined
-    edge-sampling gradient with respect to actor position / heading and camera position / heading (DESIGN.md "K3 backward"); the
+    edge-sampling gradient with respect to actor position / heading / template vertices (sizes) and camera position / heading (DESIGN.md "K3 backward"); the
     reference's CV2 backend has none (rendering/cv2.py:27-70).  When the bit-plane kernel serves the forward it also leaves the per-pixel key
     index as bit-slices (3 % of the image), and the backward (tds_raster_scene_bwd_idx_f32) reads those and the incoming gradient next
     to colour boundaries only; otherwise the forward image is kept and tds_raster_scene_bwd_f32 streams image and gradient in full."""
@@ -564,14 +564,16 @@ class _RasterScene(torch.autograd.Function):
             ev[0].record(torch.cuda.current_stream(dev))
         poses = (p(state, f32, 'state'), p(agent_sc, f32, 'agent_sc'), p(tmpl, f32, 'tmpl'), None if N == 0 else nat.dev_ptr(m8, u8, 'mask'),
                  nat.dev_ptr(_c(cam_xy), f32, 'cam_xy'), nat.dev_ptr(_c(cam_sc), f32, 'cam_sc'))
-        tail = (B, Nc, N, float(2.0 / ctx.fov), int(ctx.res), nat.dev_ptr(g_agent, f32, 'grad_agent'), nat.dev_ptr(g_cam, f32, 'grad_cam'), nat.stream_ptr(dev))
+        g_tmpl = torch.empty((B, Nc, N, 7, 2), dtype=f32, device=dev) if (N > 0 and ctx.needs_input_grad[6]) else None      # template vertices: actor sizes
+        tail = (B, Nc, N, float(2.0 / ctx.fov), int(ctx.res), nat.dev_ptr(g_agent, f32, 'grad_agent'), nat.dev_ptr(g_cam, f32, 'grad_cam'),
+                nat.dev_ptr(g_tmpl, f32, 'grad_tmpl'), nat.stream_ptr(dev))
         g_color = None
         if ctx.keys is not None:
             kt = (ctypes.c_uint32 * 16)(*ctx.keys)
             if ctx.color_keys is not None and ctx.needs_input_grad[4]:
                 g_color = torch.empty((B, Nc, 16, 4), dtype=f32, device=dev)
             nat.call('tds_raster_scene_bwd_idx_f32', dev, *poses, nat.dev_ptr(kept, i32, 'index_slices'), ctypes.cast(kt, ctypes.c_void_p), len(ctx.keys),
-                     nat.dev_ptr(gout, f32, 'grad_out'), gstride, *tail[:-1], nat.dev_ptr(g_color, f32, 'grad_color'), tail[-1])
+                     nat.dev_ptr(gout, f32, 'grad_out'), gstride, *tail[:-2], nat.dev_ptr(g_color, f32, 'grad_color'), tail[-2], tail[-1])
         else:
             nat.call('tds_raster_scene_bwd_f32', dev, *poses, nat.dev_ptr(kept, f32, 'image'), nat.dev_ptr(gout, f32, 'grad_out'), *tail)
         if ev is not None:
@@ -591,7 +593,7 @@ class _RasterScene(torch.autograd.Function):
             rows = torch.tensor([pos.get(k, -1) for k in ctx.color_keys], device=dev)
             g_key_colors = torch.where((rows >= 0)[:, None], per_key[rows.clamp(min=0)], torch.zeros((), device=dev))
         return (g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), g_key_colors,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None if g_tmpl is None else g_tmpl.sum(dim=1), None, None, None, None, None, None, None, None, None)
 
 
 def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None, extra_tri=None, extra_key=None,

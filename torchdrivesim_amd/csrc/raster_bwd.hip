@@ -13,8 +13,10 @@
 // case: where another actor covers the edge both sides show the same colour and the term vanishes.
 // Gradients produced: actor position (x, y) and heading (through [sin, cos], the form the forward consumes) per (camera, actor) --
 // the host sums over cameras -- and camera position / heading: a camera move shifts the WHOLE image rigidly, so that gradient is the
-// same integral over every colour boundary of the image (neighbouring pixel pairs), static map included.  NOT produced: gradients
-// with respect to actor sizes (templates) and colours.
+// same integral over every colour boundary of the image (neighbouring pixel pairs), static map included.  Optionally the gradient with
+// respect to the seven TEMPLATE vertices of every actor (its outline in its own frame, mesh.py:911-996): a sample at parameter u of the edge
+// t_a -> t_b moves with (1 - u) dt_a + u dt_b, so the same weights A0, A1 give d/dt_a and d/dt_b; the host chains them to the actor's
+// length and width through the template's construction.
 #include "tds_common.h"
 #include <algorithm>
 
@@ -38,6 +40,7 @@ struct BwdArgs {
     const float *grad_out;      // same shape
     float *grad_agent;          // B x Nc x N x 4   [d/dx, d/dy, d/dsin, d/dcos]
     float *grad_cam;            // B x Nc x 4       [d/dcx, d/dcy, d/dsin, d/dcos]
+    float2 *grad_tmpl;          // B x Nc x N x 7   d/d(template vertex), or nullptr
     int N, Nc, res;
     float scale;
 };
@@ -59,6 +62,7 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
     for (int j0 = 0; j0 < a.N; j0 += BW_BLOCK / LANES_PER_AGENT) {
         const int j = j0 + tid / LANES_PER_AGENT;
         float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float2 gta = make_float2(0.0f, 0.0f), gtb = make_float2(0.0f, 0.0f);          // this edge's share of d/dt_a and d/dt_b
         if (j < a.N && sub < 7 && a.mask[img * a.N + j] != 0) {
             const int64_t ia = b * a.N + j;
             const float4 s = a.state[ia];
@@ -114,8 +118,16 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_kernel(BwdArgs a) {
                     g[1] = At * nM(0.0f, 1.0f);
                     g[2] = nM(-Ty, Tx);                 // d w / d sin_j = (-ty, tx)
                     g[3] = nM(Tx, Ty);                  // d w / d cos_j = ( tx, ty)
+                    const float qx = nM(sc.y, sc.x), qy = nM(-sc.x, sc.y);       // d w / d t.x = (cos_j, sin_j), d w / d t.y = (-sin_j, cos_j)
+                    gta = make_float2(A0 * qx, A0 * qy); gtb = make_float2(A1 * qx, A1 * qy);
                 }
             }
+        }
+        if (a.grad_tmpl != nullptr) {
+            // vertex v = sub starts edge v and ends the edge before it in its polygon (body 0..3, direction triangle 4..6)
+            const int prev = (tid & ~(LANES_PER_AGENT - 1)) + (sub < 4 ? ((sub + 3) & 3) : (sub == 4 ? 6 : sub - 1));
+            const float bx = __shfl(gtb.x, prev & 63), by = __shfl(gtb.y, prev & 63);
+            if (j < a.N && sub < 7) a.grad_tmpl[(img * a.N + j) * 7 + sub] = make_float2(gta.x + bx, gta.y + by);
         }
         // sum the edges of an agent (8 consecutive lanes) and store; agents out of sight store zeros
 #pragma unroll
@@ -284,6 +296,7 @@ struct BwdIdxArgs {
     const uint32_t *slices;
     const float *grad_out;
     float *grad_agent, *grad_cam;
+    float2 *grad_tmpl;          // optional: B x Nc x N x 7, d/d(template vertex)
     float *grad_color;          // optional: B x Nc x 16 x 4: per key index (0 = background) the sum of the incoming gradient per channel
     int N, Nc, res, nb;         // nb: slices in use (index bits)
     int64_t gstride;            // floats between the gradient images of consecutive cameras (3 res^2; 0 = one image shared by all)
@@ -346,7 +359,11 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
                 vis = ddx * ddx + ddy * ddy <= reach * reach;
             }
             if (vis) vis_list[atomicAdd(&vis_count, 1)] = jc;
-            else *(float4 *)(a.grad_agent + (img * a.N + jc) * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // out of sight or masked
+            else {                                                                                             // out of sight or masked
+                *(float4 *)(a.grad_agent + (img * a.N + jc) * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (a.grad_tmpl != nullptr)
+                    for (int v = 0; v < 7; ++v) a.grad_tmpl[(img * a.N + jc) * 7 + v] = make_float2(0.0f, 0.0f);
+            }
         }
         __syncthreads();
         const int nvis = vis_count;
@@ -354,6 +371,7 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
             const int j = vis_list[vi];
             const int e = lane >> 3, sl = lane & 7;                       // edge 0..6 (7 idles), position among the edge's 8 lanes
             float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float2 gta = make_float2(0.0f, 0.0f), gtb = make_float2(0.0f, 0.0f);      // this edge's share of d/dt_a and d/dt_b (all 8 lanes of the edge)
             if (e < 7) {
                 const int64_t ia = b * a.N + j;
                 const float4 s = a.state[ia];
@@ -409,7 +427,15 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
                         g[2] = nM(-Ty, Tx);
                         g[3] = nM(Tx, Ty);
                     }
+                    const float qx = nM(sc.y, sc.x), qy = nM(-sc.x, sc.y);
+                    gta = make_float2(A0 * qx, A0 * qy); gtb = make_float2(A1 * qx, A1 * qy);
                 }
+            }
+            if (a.grad_tmpl != nullptr) {
+                // vertex v = e starts edge e and ends the edge before it in its polygon (see raster_scene_bwd_kernel)
+                const int pe = e < 4 ? ((e + 3) & 3) : (e == 4 ? 6 : e - 1);
+                const float bx = __shfl(gtb.x, (pe & 7) * 8), by = __shfl(gtb.y, (pe & 7) * 8);
+                if (e < 7 && sl == 0) a.grad_tmpl[(img * a.N + j) * 7 + e] = make_float2(gta.x + bx, gta.y + by);
             }
             // sum the seven edges (their first lanes hold the values, every other lane holds zero)
 #pragma unroll
@@ -625,7 +651,7 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
 
 TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                                         const float *cam_sc, const float *image, const float *grad_out, int64_t B, int64_t Nc, int64_t N,
-                                        float scale, int res, float *grad_agent, float *grad_cam, void *stream) {
+                                        float scale, int res, float *grad_agent, float *grad_cam, float *grad_tmpl, void *stream) {
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene_bwd_f32: bad sizes");
     TDS_CHECK_ARG(res > 0 && res <= 4096, "tds_raster_scene_bwd_f32: resolution out of range");
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene_bwd_f32: scale must be positive");
@@ -637,7 +663,7 @@ TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_s
     BwdArgs a;
     a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl; a.mask = mask;
     a.cam_xy = (const float2 *)cam_xy; a.cam_sc = (const float2 *)cam_sc; a.image = image; a.grad_out = grad_out;
-    a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
+    a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.grad_tmpl = (float2 *)grad_tmpl; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
     hipLaunchKernelGGL(raster_scene_bwd_kernel, dim3((unsigned)n_img), dim3(BW_BLOCK), 0, (hipStream_t)stream, a);
     TDS_LAUNCH_CHECK("raster_scene_bwd_kernel");
     return TDS_OK;
@@ -646,7 +672,7 @@ TDS_EXPORT int tds_raster_scene_bwd_f32(const float *state, const float *agent_s
 TDS_EXPORT int tds_raster_scene_bwd_idx_f32(const float *state, const float *agent_sc, const float *tmpl, const uint8_t *mask, const float *cam_xy,
                                             const float *cam_sc, const uint32_t *index_slices, const uint32_t *keys, int n_keys, const float *grad_out,
                                             int64_t grad_out_stride, int64_t B, int64_t Nc, int64_t N, float scale, int res, float *grad_agent,
-                                            float *grad_cam, float *grad_color, void *stream) {
+                                            float *grad_cam, float *grad_color, float *grad_tmpl, void *stream) {
     TDS_CHECK_ARG(B >= 0 && Nc >= 0 && N >= 0 && N < (1 << 20), "tds_raster_scene_bwd_idx_f32: bad sizes");
     TDS_CHECK_ARG(res > 0 && res <= 4096 && (res & 3) == 0, "tds_raster_scene_bwd_idx_f32: the resolution must be a multiple of 4");
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene_bwd_idx_f32: scale must be positive");
@@ -659,7 +685,7 @@ TDS_EXPORT int tds_raster_scene_bwd_idx_f32(const float *state, const float *age
     BwdIdxArgs a;
     a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl; a.mask = mask;
     a.cam_xy = (const float2 *)cam_xy; a.cam_sc = (const float2 *)cam_sc; a.slices = index_slices; a.grad_out = grad_out;
-    a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.grad_color = grad_color; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
+    a.grad_agent = grad_agent; a.grad_cam = grad_cam; a.grad_color = grad_color; a.grad_tmpl = (float2 *)grad_tmpl; a.N = (int)N; a.Nc = (int)Nc; a.res = res; a.scale = scale;
     TDS_CHECK_ARG(grad_out_stride == 0 || grad_out_stride >= 3ll * res * res, "tds_raster_scene_bwd_idx_f32: grad_out_stride must be 0 or at least 3 res^2");
     a.gstride = grad_out_stride;
     a.n_keys = n_keys;

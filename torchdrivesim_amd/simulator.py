@@ -624,7 +624,7 @@ class Simulator:
             all_levels = actor_levels + [float(z) for z in torch.unique(bg.verts[..., 2]).tolist()]
             per_scene = [self.renderer.make_static_map(bg[b:b + 1], all_levels, device=dev) for b in range(B)]
             maps = [(_ops.StaticMapSet(per_scene, torch.arange(B, dtype=torch.int32)), None)]
-        tmpl = actor_template(sizes).contiguous()                   # B x N x 7 x 2
+        tmpl = actor_template(sizes.detach()).contiguous()          # B x N x 7 x 2 (a render that differentiates the sizes builds its own)
         keys, key_tables, wp_keys = [], [], []
         for smap, _ in maps:
             body = torch.tensor([(smap.rank_of(lv[n]) << 24) | int(_ops.quantise_colors(torch.tensor(cm[n], dtype=torch.float32) / 255.0)) for n in names],
@@ -742,11 +742,14 @@ class Simulator:
             scene = self._scene()
             state = self.get_all_agent_state()
             # gradients through the rasteriser (K3 backward, build-defined) only when someone asks for them
-            diff = torch.is_grad_enabled() and (state.requires_grad or camera_xy.requires_grad or camera_sc.requires_grad) and \
+            sizes = self.get_all_agent_size()
+            size_grad = torch.is_grad_enabled() and sizes.requires_grad and self.renderer.out_dtype == torch.float32
+            diff = torch.is_grad_enabled() and (state.requires_grad or camera_xy.requires_grad or camera_sc.requires_grad or size_grad) and \
                 self.renderer.out_dtype == torch.float32
             if not diff:
                 state, camera_xy, camera_sc = state.detach(), camera_xy.detach(), camera_sc.detach()
-            tmpl_all = scene['tmpl']
+            # gradients with respect to the agents' length and width flow through the template vertices (actor_template is plain torch)
+            tmpl_all = actor_template(sizes).contiguous() if size_grad else scene['tmpl']
             ctrl = scene['ctrl']
             if ctrl is not None:                                    # stop lines ride along as extra quads
                 state = torch.cat([state, ctrl['state'].to(state.dtype)], dim=1)
