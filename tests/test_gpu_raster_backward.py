@@ -23,7 +23,7 @@ def numpy_backward(state, sc, tmpl, mask, cam_xy, cam_sc, image, gout, fov, res)
     B, Nc = cam_xy.shape[:2]
     N = state.shape[1]
     k, half = (2.0 / fov) * res * 0.5, res * 0.5
-    g_agent, g_cam = np.zeros((B, Nc, N, 4)), np.zeros((B, Nc, 4))
+    g_agent, g_cam, g_tmpl = np.zeros((B, Nc, N, 4)), np.zeros((B, Nc, 4)), np.zeros((B, Nc, N, 7, 2))
     view_r = 1.05 * 1.41421356 / (2.0 / fov)
     for b in range(B):
         for c in range(Nc):
@@ -69,6 +69,9 @@ def numpy_backward(state, sc, tmpl, mask, cam_xy, cam_sc, image, gout, fov, res)
                     T = A0 * t[ia] + A1 * t[ib]
                     g = np.array([(A0 + A1) * nM(1, 0), (A0 + A1) * nM(0, 1), nM(-T[1], T[0]), nM(T[0], T[1])])
                     g_agent[b, c, j] += g
+                    q = np.array([nM(cj, sj), nM(-sj, cj)])            # a sample at u moves with (1 - u) dt_a + u dt_b, rotated into the world
+                    g_tmpl[b, c, j, ia] += A0 * q
+                    g_tmpl[b, c, j, ib] += A1 * q
             # camera: every colour boundary of the image moves rigidly (neighbouring pixel pairs)
             ii, jj = np.meshgrid(np.arange(res, dtype=np.float64), np.arange(res, dtype=np.float64), indexing='ij')
             Dx = (0.5 * (G[:, :-1] + G[:, 1:]) * (I[:, 1:] - I[:, :-1])).sum(0)           # pairs (i, j) - (i + 1, j)
@@ -79,7 +82,7 @@ def numpy_backward(state, sc, tmpl, mask, cam_xy, cam_sc, image, gout, fov, res)
             Cc = (Dx * (cc * dxx - cs * dyx)).sum() + (Dy * (cs * dxy + cc * dyy)).sum()
             Cs = (Dx * (cs * dxx + cc * dyx)).sum() - (Dy * (cc * dxy - cs * dyy)).sum()
             g_cam[b, c] = [-k * (cc * Sx - cs * Sy), -k * (cs * Sx + cc * Sy), -Cs, -Cc]
-    return g_agent, g_cam
+    return g_agent, g_cam, g_tmpl
 
 
 def scene(gen, B=2, N=5, Nc=3, big=False):
@@ -124,13 +127,13 @@ def test_kernel_matches_numpy_definition(ops, oracle, res):   # of a row in two 
     cpsi = dev(cam_psi)
     csc = torch.cat([torch.sin(cpsi), torch.cos(cpsi)], -1).requires_grad_(True)
     sc = ops.heading_sc(st[..., 2]).detach().requires_grad_(True)
-    tmpl = dev(oracle.actor_template(size))
+    tmpl = dev(oracle.actor_template(size)).requires_grad_(True)
     B, N = state.shape[:2]
     img = ops.raster_scene_diff(smap, st, sc, tmpl, actor_keys(smap, B, N), dev(mask), cxy, csc, fov, res)
     gout = torch.from_numpy(smooth_weight(res, gen)).to(DEV).expand_as(img).contiguous() * torch.linspace(0.5, 1.5, img.shape[0] * img.shape[1],
                                                                                                         device=DEV).view(img.shape[0], img.shape[1], 1, 1, 1)
     img.backward(gout)
-    ga, gc = numpy_backward(state, sc.detach().cpu().numpy(), tmpl.cpu().numpy(), mask, cam_xy, csc.detach().cpu().numpy(), img.detach().cpu().numpy(),
+    ga, gc, gt = numpy_backward(state, sc.detach().cpu().numpy(), tmpl.detach().cpu().numpy(), mask, cam_xy, csc.detach().cpu().numpy(), img.detach().cpu().numpy(),
                             gout.cpu().numpy(), fov, res)
     ga = ga.sum(1)
     scale = np.abs(ga).max() + 1e-9
@@ -140,6 +143,9 @@ def test_kernel_matches_numpy_definition(ops, oracle, res):   # of a row in two 
     np.testing.assert_allclose(sc.grad.cpu().numpy(), ga[..., 2:], atol=2e-4 * max(np.abs(ga[..., 2:]).max(), 1e-9), rtol=2e-3)
     np.testing.assert_allclose(cxy.grad.cpu().numpy(), gc[..., :2], atol=2e-4 * max(np.abs(gc[..., :2]).max(), 1e-9), rtol=2e-3)
     np.testing.assert_allclose(csc.grad.cpu().numpy(), gc[..., 2:], atol=2e-4 * max(np.abs(gc[..., 2:]).max(), 1e-9), rtol=2e-3)
+    gt = gt.sum(1)                                                # template vertices (the actors' sizes), over cameras
+    assert np.abs(gt).max() > 1e-3
+    np.testing.assert_allclose(tmpl.grad.cpu().numpy(), gt, atol=2e-4 * np.abs(gt).max(), rtol=2e-3)
 
 
 @pytest.mark.parametrize('res', [64, 256, 288, 512])      # one word column .. two strips (288) .. more than 64 row quads per column (512)
@@ -160,16 +166,17 @@ def test_index_slice_backward_equals_the_image_backward(ops, oracle, res):
             st, cxy = dev(state).requires_grad_(True), dev(cam_xy).requires_grad_(True)
             csc = torch.cat([torch.sin(cpsi), torch.cos(cpsi)], -1).requires_grad_(True)
             sc = ops.heading_sc(st[..., 2]).detach().requires_grad_(True)
-            img = ops.raster_scene_diff(smap, st, sc, tmpl, actor_keys(smap, B, N), dev(mask), cxy, csc, 35.0, res)
+            tm = tmpl.clone().requires_grad_(True)
+            img = ops.raster_scene_diff(smap, st, sc, tm, actor_keys(smap, B, N), dev(mask), cxy, csc, 35.0, res)
             if gout is None:
                 gout = torch.randn(img.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
             img.backward(gout)
-            grads.append([t.grad.double().cpu().numpy() for t in (st, sc, cxy, csc)])
+            grads.append([t.grad.double().cpu().numpy() for t in (st, sc, cxy, csc, tm)])
         finally:
             ops.use_index_slices = True
     for a, b in zip(*grads):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(np.abs(b).max(), 1e-9))
-    assert np.abs(grads[0][2]).max() > 0 and np.abs(grads[0][0]).max() > 0
+    assert np.abs(grads[0][2]).max() > 0 and np.abs(grads[0][0]).max() > 0 and np.abs(grads[0][4]).max() > 0
     # a gradient that is ONE image broadcast over all cameras (stride 0) is read as such: same result as its dense copy
     one = torch.randn(img.shape[2:], device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     res2 = []
@@ -237,12 +244,15 @@ def fine_weight(res, seed, n=3):
     return torch.from_numpy((w / 255.0).astype(np.float32)).to(DEV)
 
 
-@pytest.mark.parametrize('param', ['x', 'y', 'psi', 'cam_x', 'cam_y', 'cam_psi'])
+@pytest.mark.parametrize('param', ['x', 'y', 'psi', 'cam_x', 'cam_y', 'cam_psi', 'size'])
 def test_gradient_follows_finite_differences(ops, oracle, param):
     """L = sum f I with a smooth f.  The image is piecewise constant, so the reference is a central difference of the hard rasterisation
     rendered at 4x the resolution (same f, weights / 16) over a step of a few pixels.  A single pose compares a once-per-pixel boundary
     sample against an OpenCV-style raster (2 - 15 % apart, the phase of the edges against the pixel grid); both sides are therefore
-    AVERAGED over 12 sub-pixel shifts of the whole scene -- the gradient of the shift-averaged loss -- and must agree within 10 % of the scale."""
+    AVERAGED over 12 sub-pixel shifts of the whole scene -- the gradient of the shift-averaged loss -- and must agree within 10 % of the scale.
+    'size': the agents' length and width (through the template vertices), judged together against their common scale -- the two are sums of
+    the same edge integrals (a length moves the short edges, a width the long ones), and the absolute deviation is the same for both
+    (about 2 units here, 4 % of the largest size gradient; on its own the small length gradient of this scene would be 12 % off)."""
     gen = np.random.default_rng(11)
     verts, faces, state, size, cam_xy, cam_psi, mask = scene(gen, B=1, N=3, Nc=1, big=True)
     mask[:] = True
@@ -253,38 +263,45 @@ def test_gradient_follows_finite_differences(ops, oracle, param):
     smap = make_map(ops, verts, faces, MAP_VC, MAP_CATS)
     fov, res, ss = 35.0, 256, 4
 
-    def loss_of(r, state_np, cam_xy_np, cam_psi_np, diff=False):
+    from torchdrivesim_amd.mesh import actor_template
+
+    def loss_of(r, state_np, cam_xy_np, cam_psi_np, diff=False, size_np=None):
         f = fine_weight(r, 3) / ((r // res) ** 2)
         st = dev(state_np).requires_grad_(diff)
         cxy = dev(cam_xy_np).requires_grad_(diff)
         cpsi = dev(cam_psi_np).requires_grad_(diff)
         csc = torch.cat([torch.sin(cpsi), torch.cos(cpsi)], -1)
-        img = render(ops, smap, oracle, st, size, mask, cxy, csc, fov, r, diff)
-        return (img.double() * f.double()).sum(), st, cxy, cpsi
+        sz = dev(size if size_np is None else size_np).requires_grad_(diff)
+        # sizes reach the image through the template vertices (the product's actor_template; bit-equal to the reference's, G4)
+        fn = ops.raster_scene_diff if diff else ops.raster_scene
+        img = fn(smap, st, ops.heading_sc(st[..., 2]), actor_template(sz).contiguous(), actor_keys(smap, 1, st.shape[1]), dev(mask), cxy, csc, fov, r)
+        return (img.double() * f.double()).sum(), st, cxy, cpsi, sz
 
-    h = 0.05 if 'psi' in param else 0.3
+    cols = ('length', 'width') if param == 'size' else (param,)
+    h = 0.05 if 'psi' in param else (0.6 if param == 'size' else 0.3)          # size: an outline edge moves by 0.3 m either way (half the change)
     n = 1 if param.startswith('cam') else state.shape[1]
     shifts = np.random.default_rng(2).uniform(-0.5, 0.5, (12, 2)) * (fov / res)          # within one pixel
-    g_sum, fd_sum = np.zeros(n), np.zeros(n)
+    g_sum, fd_sum = np.zeros((len(cols), n)), np.zeros((len(cols), n))
     for sh in shifts:
         # actors and camera parameters under test move against the static map and the image grid by a fraction of a pixel
         st0, cx0 = state.copy(), cam_xy.copy()
         st0[0, :, :2] += sh
         if param.startswith('cam'):
             cx0[0, :, :] += sh[::-1] * 0.5
-        L, st, cxy, cpsi = loss_of(res, st0, cx0, cam_psi, True)
+        L, st, cxy, cpsi, sz = loss_of(res, st0, cx0, cam_psi, True)
         L.backward()
         grads = dict(x=st.grad[0, :, 0], y=st.grad[0, :, 1], psi=st.grad[0, :, 2], cam_x=cxy.grad[0, :, 0], cam_y=cxy.grad[0, :, 1],
-                     cam_psi=cpsi.grad[0, :, 0])
-        g_sum += grads[param].cpu().numpy().astype(np.float64)
-        for i in range(n):
-            vals = []
-            for sgn in (+1, -1):
-                s2, c2, p2 = st0.copy(), cx0.copy(), cam_psi.copy()
-                tgt, col = dict(x=(s2, 0), y=(s2, 1), psi=(s2, 2), cam_x=(c2, 0), cam_y=(c2, 1), cam_psi=(p2, 0))[param]
-                tgt[0, i, col] += sgn * h
-                vals.append(loss_of(res * ss, s2, c2, p2)[0].item())
-            fd_sum[i] += (vals[0] - vals[1]) / (2 * h)
+                     cam_psi=cpsi.grad[0, :, 0], length=sz.grad[0, :, 0], width=sz.grad[0, :, 1])
+        for ci, name in enumerate(cols):
+            g_sum[ci] += grads[name].cpu().numpy().astype(np.float64)
+            for i in range(n):
+                vals = []
+                for sgn in (+1, -1):
+                    s2, c2, p2, z2 = st0.copy(), cx0.copy(), cam_psi.copy(), size.copy()
+                    tgt, col = dict(x=(s2, 0), y=(s2, 1), psi=(s2, 2), cam_x=(c2, 0), cam_y=(c2, 1), cam_psi=(p2, 0), length=(z2, 0), width=(z2, 1))[name]
+                    tgt[0, i, col] += sgn * h
+                    vals.append(loss_of(res * ss, s2, c2, p2, size_np=z2)[0].item())
+                fd_sum[ci, i] += (vals[0] - vals[1]) / (2 * h)
     g, fd = g_sum / len(shifts), fd_sum / len(shifts)
     # (a camera move shifts the static map as well: its lane stripes contribute to the camera gradient)
     scale = max(np.abs(fd).max(), np.abs(g).max())
@@ -316,3 +333,26 @@ def test_gradients_reach_simulator_state(ops):
     assert g is not None and torch.isfinite(g).all()
     assert (g[..., 3] == 0).all()                     # speed never enters the image
     assert g[..., :3].abs().sum() > 0
+
+
+def test_gradients_reach_the_agent_sizes(ops):
+    """render_egocentric differentiates the agents' length and width (through the template vertices) when agent_size requires grad"""
+    from test_gpu_simulator import make_sim, town_mesh
+    from torchdrivesim_amd.utils import Resolution
+    gen = np.random.default_rng(4)
+    B, A = 2, 5
+    road, t = town_mesh(B)
+    rv = t['verts'][t['vert_category'] == [str(c) for c in t['categories']].index('road')]
+    anchor = rv[gen.integers(0, len(rv), (B, 1))]
+    state = np.concatenate([anchor + gen.uniform(-8, 8, (B, A, 2)), gen.uniform(-np.pi, np.pi, (B, A, 1)), gen.uniform(0, 5, (B, A, 1))], -1).astype(np.float32)
+    size = np.tile(np.array([4.5, 2.0], np.float32), (B, A, 1))
+    sim = make_sim(state, size, np.ones((B, A), bool), road)
+    plain = sim.render_egocentric(res=Resolution(128, 128), fov=35.0)
+    assert not plain.requires_grad
+    sz = sim.get_agent_size().detach().clone().requires_grad_(True)
+    sim.set_agent_size(sz) if hasattr(sim, 'set_agent_size') else setattr(sim, 'agent_size', sz)
+    img = sim.render_egocentric(res=Resolution(128, 128), fov=35.0)
+    assert img.requires_grad and torch.equal(img.detach(), plain)
+    img.sum().backward()                                          # a larger vehicle covers more (darker or brighter) pixels: a gradient wherever it is visible
+    assert sz.grad is not None and torch.isfinite(sz.grad).all() and sz.grad.abs().sum() > 0
+
