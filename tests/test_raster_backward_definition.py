@@ -33,7 +33,7 @@ def test_edge_sampling_gradient_follows_finite_differences_of_the_oracle(oracle)
         state = np.array([[[pos[0], pos[1], psi_a, 0.0]]], np.float32)
         cam_xy, cam_psi = np.zeros((1, 1, 2), np.float32), np.full((1, 1, 1), psi_c, np.float32)
         img, csc, asc = image(res, state, cam_xy, cam_psi)
-        ga, gc = numpy_backward(state, asc, tmpl, mask, cam_xy, csc, img.reshape(1, 1, 3, res, res), f[None, None], fov, res)
+        ga, gc, _ = numpy_backward(state, asc, tmpl, mask, cam_xy, csc, img.reshape(1, 1, 3, res, res), f[None, None], fov, res)
         (sj, cj), (sc_, cc_) = asc[0, 0], csc[0, 0]
         g = np.array([ga[0, 0, 0, 0], ga[0, 0, 0, 1], ga[0, 0, 0, 2] * cj - ga[0, 0, 0, 3] * sj, gc[0, 0, 2] * cc_ - gc[0, 0, 3] * sc_])
         fd = []
