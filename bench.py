@@ -366,7 +366,8 @@ def main():
     if args.dry_run:
         if os.environ.get('TDS_BENCH_DRY_RUN_FAIL_RANK') == str(rank):      # tests/test_bench_launcher.py: a worker that dies at start-up
             raise SystemExit(3)
-        device, backend = torch.device('cpu'), 'gloo'
+        # (TDS_BENCH_DRY_RUN_TRY_NCCL=1: keep asking for RCCL -- on a CPU it cannot come up, which exercises the fallback to gloo below)
+        device, backend = torch.device('cpu'), ('nccl' if os.environ.get('TDS_BENCH_DRY_RUN_TRY_NCCL') == '1' else 'gloo')
     else:
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
@@ -390,8 +391,15 @@ def main():
                         dist.destroy_process_group()
                     except Exception:                                    # noqa: BLE001
                         pass
-                    backend = 'gloo'
-            if backend != 'nccl':
+                    backend = 'gloo-after-rccl'
+            if backend == 'gloo-after-rccl':
+                # a fresh rendezvous: the store of the failed attempt may still hold MASTER_PORT (a second env:// init against it ends in
+                # "Broken pipe" on the other ranks); every rank derives the same neighbouring port
+                addr, port = os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ.get('MASTER_PORT', '29500'))
+                dist.init_process_group('gloo', init_method=f'tcp://{addr}:{port + 1 if port < 65535 else port - 1}', rank=rank, world_size=world)
+                dist.barrier()
+                backend = 'gloo'
+            elif backend != 'nccl':
                 dist.init_process_group('gloo')
                 dist.barrier()
         finally:

@@ -54,6 +54,29 @@ def test_single_process_dry_run_and_torchrun_shape():
     check_line(line, 1, 2, 1)
 
 
+def test_the_barrier_falls_back_to_gloo_when_rccl_cannot_come_up():
+    """The process group only carries the barrier and the timing reductions.  Under an external launcher the worker asks for RCCL; where that
+    fails (here: no GPU at all) both ranks must fall back to gloo and still deliver the line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TDS_BENCH_DRY_RUN_TRY_NCCL='1')
+        e.pop('TDS_BENCH_BACKEND', None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--dry-run'],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('falling back to gloo' in err for _, err in outs), outs
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1 and not outs[1][0].strip()
+    line = json.loads(lines[0])
+    check_line(line, 2, 2, 1)
+    assert 'gloo' in line['launcher']
+
+
 def test_traffic_figure_is_refused_for_another_build(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
