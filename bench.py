@@ -465,7 +465,8 @@ def main():
                           measured_copy_peak=HBM_COPY_GBS, frac_of_measured_copy=None if achieved is None else achieved / HBM_COPY_GBS))
         if world > 1:
             line['per_rank_agent_steps_per_s'] = [B * A * args.steps / t for t in per_rank]
-            line['launcher'] = 'torch.distributed.run + RCCL barrier' if backend == 'nccl' else 'bench.py self-launch, one child per GPU, gloo barrier on 127.0.0.1'
+            line['launcher'] = ('bench.py self-launch, one child per GPU' if args.worker else 'external launcher (torch.distributed.run)') + \
+                (', RCCL barrier' if backend == 'nccl' else ', gloo barrier on 127.0.0.1')
         if args.dry_run:
             line['dry_run'] = True
             line['data'] = 'none (dry run: no kernels were launched, the value is meaningless)'
