@@ -688,7 +688,9 @@ struct ScanState {
     bool masked_seen;
     int cx0, cx1, cy0, nrows, row, chunk, prev_rw;       // wave-uniform: cell rectangle, grid rows to scan, first row of the current block of 64
                                                          // rows, this wave's next chunk of the block's entry list, cell range of the row before the block
-    int rw, re0, re1, rfe;                               // lane r: grid row (block start + r): cell range lo | hi << 16, entry range, end of its first cell
+    int rw, rex, rbase, rfe;                             // lane r: grid row (block start + r): cell range lo | hi << 16; number of its first entry in the
+                                                         // block's list (prefix sum of the rows' entry counts), first entry - that number; end of its first cell
+    int rtotal;                                          // entries of the block (wave-uniform)
     // the chunk of entries in flight (scan_fetch): this lane's entry index | its grid row within the block << 25 (-1: none) and data
     bool have;
     int cur_i;
@@ -714,7 +716,8 @@ __device__ __forceinline__ void scan_load_rows(ScanState &st, const MapView &m, 
     }
     const float eps = 1e-3f + 1e-6f * (fabsf(cam.cx) + fabsf(cam.cy));
     const int r = row0 + lane;
-    st.rw = SCAN_EMPTY_ROW; st.re0 = 0; st.re1 = 0; st.rfe = 0;
+    st.rw = SCAN_EMPTY_ROW; st.rfe = 0;
+    int re0 = 0, re1 = 0;
     if (r < st.nrows) {
         const int cy = st.cy0 + r;
         const float ya = m.oy + (float)cy * m.cell - eps - 1e-4f * m.cell, yb = m.oy + (float)(cy + 1) * m.cell + eps + 1e-4f * m.cell;
@@ -740,10 +743,15 @@ __device__ __forceinline__ void scan_load_rows(ScanState &st, const MapView &m, 
             if (lo <= hi) {
                 const int32_t *cs = m.cell_start + (size_t)cy * m.nx;
                 st.rw = lo | (hi << 16);
-                st.re0 = cs[lo]; st.re1 = cs[hi + 1]; st.rfe = cs[lo + 1];
+                re0 = cs[lo]; re1 = cs[hi + 1]; st.rfe = cs[lo + 1];
             }
         }
     }
+    // the entry ranges of the block's rows form one list: number the entries once per block (scan_fetch cuts the list into chunks of 64)
+    const int cnt = re1 - re0, incl = wave_scan_add(cnt);
+    st.rex = incl - cnt;
+    st.rbase = re0 - st.rex;
+    st.rtotal = __builtin_amdgcn_readlane(incl, 63);
 }
 
 // window = pixel columns [X0, X0 + TWw) of the image (the whole image when binning)
@@ -758,7 +766,7 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const Comm
     if constexpr (has_extras<SA>::value) { if (st.phase == 2 && a.K > 0) st.phase = 3; }
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
-    st.rw = SCAN_EMPTY_ROW; st.re0 = st.re1 = st.rfe = 0;
+    st.rw = SCAN_EMPTY_ROW; st.rex = st.rbase = st.rfe = 0; st.rtotal = 0;
     st.have = false; st.cur_i = -1; st.dyn = nullptr; st.done = 0;
     st.pu0 = st.pu1 = make_uint4(0, 0, 0, 0);
     if (m.nx > 0 && !(TDS_DBG(c.debug) & 1)) {
@@ -793,19 +801,19 @@ template <int NW>
 __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, const CommonArgs &c, const Camera &cam, int lane, int X0, int TWw) {
     while (st.row < st.nrows) {
         const int nblk = min(64, st.nrows - st.row);
-        const int cnt = lane < nblk ? st.re1 - st.re0 : 0;
-        const int incl = wave_scan_add(cnt), excl = incl - cnt;
-        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int total = st.rtotal;
         if (st.chunk * 64 < total) {
             const int v = st.chunk * 64 + lane;
             int r = 0;                                        // the last row whose first entry number is <= v (rows without entries share the
 #pragma unroll                                                // number of the next one and lose to it)
             for (int step = 32; step >= 1; step >>= 1) {
-                const int cand = r + step;
-                const int ex = __shfl(excl, cand & 63);
-                if (cand < nblk && ex <= v) r = cand;
+                if (step < nblk) {                            // wave-uniform: a view spans a handful of grid rows, the upper steps find nothing
+                    const int cand = r + step;
+                    const int ex = __shfl(st.rex, cand & 63);
+                    if (cand < nblk && ex <= v) r = cand;
+                }
             }
-            const int i = __shfl(st.re0, r) + (v - __shfl(excl, r));
+            const int i = __shfl(st.rbase, r) + v;
             st.cur_i = v < total ? (i | (r << 25)) : -1;
             if (v < total) {
                 const uint4 *ep = (const uint4 *)(m.entries + i);
@@ -1343,14 +1351,23 @@ constexpr int HCHUNK = TDS_HCHUNK;    // rows per item: x-major outline edges (o
 constexpr int MERGE_BIAS = 160, MERGE_DY_BIAS = 100, MERGE_DY_NOBIAS = 147;
 
 // bit 0: the edge is merged into the rows, bit 1: x-major, bit 2: biased
-__device__ __forceinline__ unsigned edge_class(int ax, int ay, int bx, int by, int W, int H) {
-    const bool inside = (unsigned)ax < (unsigned)W && (unsigned)bx < (unsigned)W && (unsigned)ay < (unsigned)H && (unsigned)by < (unsigned)H;
+// oca, ocb: outcodes of the end points (vertex_outcode), 0 = inside the image
+__device__ __forceinline__ unsigned vertex_outcode(int x, int y, int W, int H) {      // cv::clipLine's: 1 left, 2 right, 4 above, 8 below
+    return ((unsigned)x >> 31) | (((unsigned)(W - 1 - x) >> 31) << 1) | (((unsigned)y >> 31) << 2) | (((unsigned)(H - 1 - y) >> 31) << 3);
+}
+__device__ __forceinline__ unsigned edge_class(int ax, int ay, int bx, int by, unsigned oca, unsigned ocb) {
+    const bool inside = (oca | ocb) == 0u;
     const int adx = abs(bx - ax), ady = abs(by - ay);
-    const bool xmaj = adx >= ady;
-    const int fx = __ffs(adx), fy = __ffs(ady);                       // 1 + trailing zeros, 0 for 0
-    const bool tiefree = xmaj ? (fx <= fy) : (adx == 0 || fx >= fy);
-    const bool merge = inside && (ady <= MERGE_DY_BIAS || (ady <= MERGE_DY_NOBIAS && tiefree));
-    return (merge ? 1u : 0u) | (xmaj ? 2u : 0u) | (ady <= MERGE_DY_BIAS ? 4u : 0u);
+    const bool xmaj = adx >= ady, shortish = ady <= MERGE_DY_BIAS;
+    bool merge = inside && shortish;
+    // longer edges (101 .. 147 rows) are merged when they have no ties; hardly any edge is that long, so the test sits behind a wave-uniform branch
+    const bool longer = inside && !shortish && ady <= MERGE_DY_NOBIAS;
+    if (__ballot(longer) != 0) {
+        const int fx = __ffs(adx), fy = __ffs(ady);                   // 1 + trailing zeros, 0 for 0
+        const bool tiefree = xmaj ? (fx <= fy) : (adx == 0 || fx >= fy);
+        merge = merge || (longer && tiefree);
+    }
+    return (merge ? 1u : 0u) | (xmaj ? 2u : 0u) | (shortish ? 4u : 0u);
 }
 // row ends of a chain that follows an edge of class `cls` with 16.16 slope s: left = (x + offL) >> 16, right = (x + offR) >> 16
 __device__ __forceinline__ void edge_offsets(unsigned cls, int s, int &offL, int &offR) {
@@ -1402,19 +1419,18 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
         const bool hit = !(xmax < X0 || xmin > Xhi || yb < 0 || yt >= H);
         unsigned cTM = 0, cMB = 0, cTB = 0;
         if (hit && !(TDS_DBG(w.debug) & 8)) {
-            cTM = edge_class(xt, yt, xm, ym, W, H); cMB = edge_class(xm, ym, xb, yb, W, H); cTB = edge_class(xt, yt, xb, yb, W, H);
-            // Outline edges in OpenCV's order (l = 0: v2-v0, 1: v0-v1, 2: v1-v2; cv::clipLine depends on the direction): the ones that are
-            // not merged and not entirely on one outer side of the image are walked exactly.  Edge l lies opposite vertex (l + 1) % 3;
-            // T->M lies opposite B, M->B opposite T, T->B opposite M (vertices that coincide have edges of the same class).
+            const unsigned ocT = vertex_outcode(xt, yt, W, H), ocM = vertex_outcode(xm, ym, W, H), ocB = vertex_outcode(xb, yb, W, H);
+            cTM = edge_class(xt, yt, xm, ym, ocT, ocM); cMB = edge_class(xm, ym, xb, yb, ocM, ocB); cTB = edge_class(xt, yt, xb, yb, ocT, ocB);
+            // Edges that are not merged and not entirely on one outer side of the image (both outcodes share a bit: cv::clipLine leaves nothing)
+            // are walked exactly, in OpenCV's order and direction (l = 0: v2-v0, 1: v0-v1, 2: v1-v2; clipLine depends on the direction).
+            // Edge l lies opposite vertex (l + 1) % 3; T->M lies opposite B, M->B opposite T, T->B opposite M (vertices that coincide have
+            // edges of the same class).
+            const unsigned wTM = (!(cTM & 1u) && !(ocT & ocM)) ? 1u : 0u, wMB = (!(cMB & 1u) && !(ocM & ocB)) ? 1u : 0u, wTB = (!(cTB & 1u) && !(ocT & ocB)) ? 1u : 0u;
             unsigned ring = 0;
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const int po = (int)(l == 0 ? v1 : (l == 1 ? v2 : v0));
-                const unsigned cl = po == pB ? cTM : (po == pT ? cMB : cTB);
-                const uint32_t pa = l == 0 ? v2 : (l == 1 ? v0 : v1), pb = l == 0 ? v0 : (l == 1 ? v1 : v2);
-                const int ax = unpack_x(pa), ay = unpack_y(pa), bx = unpack_x(pb), by = unpack_y(pb);
-                const bool gone = (ax < 0 && bx < 0) || (ay < 0 && by < 0) || (ax >= W && bx >= W) || (ay >= H && by >= H);    // clipLine: nothing left
-                ring |= (!(cl & 1u) && !gone) ? (1u << l) : 0u;
+                ring |= (po == pB ? wTM : (po == pT ? wMB : wTB)) << l;
             }
             flags |= (int)((cTM << 4) | (cMB << 7) | (cTB << 10) | ((em & ring) << 13));
         }
