@@ -1821,8 +1821,12 @@ constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename 
 
 // one workgroup per (camera, strip); for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
 // EMIT: also store the key-index slices for the backward pass (a separate instantiation: the plain kernel sits exactly at its VGPR limit)
-template <int BWAVES, int NB, typename OutT, typename SA, bool EMIT = false>
-__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? 3 : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp) {
+// MINWG: workgroups per CU the register budget is cut for.  3 (170 VGPRs) is what the LDS of a 256 x 256 camera with five keys allows
+// (51.8 KB each).  Where the planes are small enough for four workgroups per CU (40 KB each: 128 x 128 images, scenes of three keys) the
+// instantiation with 128 VGPRs is used: it spills 160 bytes per lane and is still 13 % faster (128 x 128: 4.47 -> 3.89 ms) -- at three
+// waves per SIMD the kernel waits for its own latencies; five or six workgroups per CU (96 / 80 VGPRs) lose to their spills.
+template <int BWAVES, int NB, typename OutT, typename SA, bool EMIT = false, int MINWG = 3>
+__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -2157,9 +2161,12 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                     hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp);
                 };
                 const int nb = bits_index_bits(kt.n);
+                const bool four_per_cu = lds <= 40 * 1024 && !(TDS_DBG(g_debug) & 2048);      // see MINWG (2048: ablation, the 170-VGPR kernel)
 #define TDS_BITS_DISPATCH(T)                                                                                                   \
     do {                                                                                                                       \
-        if (nwv == 4 && a.K == 0) { if (nb == 2) launch_b(raster_scene_bits_kernel<4, 2, T, SceneArgs>); else if (nb == 3) launch_b(raster_scene_bits_kernel<4, 3, T, SceneArgs>); else launch_b(raster_scene_bits_kernel<4, 4, T, SceneArgs>); } \
+        if (nwv == 4 && four_per_cu && a.K == 0) { if (nb == 2) launch_b(raster_scene_bits_kernel<4, 2, T, SceneArgs, false, 4>); else if (nb == 3) launch_b(raster_scene_bits_kernel<4, 3, T, SceneArgs, false, 4>); else launch_b(raster_scene_bits_kernel<4, 4, T, SceneArgs, false, 4>); } \
+        else if (nwv == 4 && four_per_cu) { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, T, SceneArgsEx, false, 4>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, T, SceneArgsEx, false, 4>); else launch(raster_scene_bits_kernel<4, 4, T, SceneArgsEx, false, 4>); } \
+        else if (nwv == 4 && a.K == 0) { if (nb == 2) launch_b(raster_scene_bits_kernel<4, 2, T, SceneArgs>); else if (nb == 3) launch_b(raster_scene_bits_kernel<4, 3, T, SceneArgs>); else launch_b(raster_scene_bits_kernel<4, 4, T, SceneArgs>); } \
         else if (nwv == 4) { if (nb == 2) launch(raster_scene_bits_kernel<4, 2, T, SceneArgsEx>); else if (nb == 3) launch(raster_scene_bits_kernel<4, 3, T, SceneArgsEx>); else launch(raster_scene_bits_kernel<4, 4, T, SceneArgsEx>); } \
         else { if (nb == 2) launch(raster_scene_bits_kernel<8, 2, T, SceneArgsEx>); else if (nb == 3) launch(raster_scene_bits_kernel<8, 3, T, SceneArgsEx>); else launch(raster_scene_bits_kernel<8, 4, T, SceneArgsEx>); } \
     } while (0)
