@@ -32,7 +32,6 @@ sys.path.insert(0, ROOT)
 RES, FOV = 256, 35.0
 ALGO_BYTES_PER_IMAGE = 3 * RES * RES * 4          # fp32 CHW raster output, the algorithmic bytes of K3
 HBM_PEAK_GBS = 8000.0                             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-HBM_COPY_GBS = 6290.0                             # what a float4 copy reaches on this part (same guide): the practical roof, reported beside the spec
 
 
 def load_town01():
@@ -130,11 +129,15 @@ def cpu_baseline(host, n_scenes, A):
 
 
 def kernel_source_stamp():
-    """sha256 over the sources of the raster kernel: PMC figures committed under profiles/ carry the stamp of the build they were
-    measured on and are refused for any other (the static traffic figure must not go stale silently)."""
+    """sha256 over everything the measured FETCH_SIZE / WRITE_SIZE of the raster kernel depend on: the kernel's sources, the layout of the
+    grid entries it reads (map.hip), the build flags (Makefile) and the host code that chooses the grid cell size (rendering/hip.py).
+    PMC figures committed under profiles/ carry the stamp of the build they were measured on and are refused for any other (VERDICT r1:
+    the static traffic figure must not go stale silently)."""
     h = hashlib.sha256()
-    for name in ('raster.hip', 'tds_common.h'):
-        with open(os.path.join(ROOT, 'torchdrivesim_amd', 'csrc', name), 'rb') as f:
+    pkg = os.path.join(ROOT, 'torchdrivesim_amd')
+    for path in (os.path.join(pkg, 'csrc', 'raster.hip'), os.path.join(pkg, 'csrc', 'tds_common.h'), os.path.join(pkg, 'csrc', 'map.hip'),
+                 os.path.join(pkg, 'csrc', 'Makefile'), os.path.join(pkg, 'rendering', 'hip.py')):
+        with open(path, 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
@@ -162,6 +165,7 @@ class _ImageProbe(torch.autograd.Function):
     probe is the last term of the loss, its upstream gradient is 1), so that no 12.9 GB temporary is produced by the LOSS."""
 
     events = []
+    checked = False          # the shortcut of backward() has been checked against the upstream gradient (once, in the warm-up)
 
     @staticmethod
     def forward(ctx, img, w):
@@ -178,6 +182,12 @@ class _ImageProbe(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if not _ImageProbe.checked:
+            # handing w itself back is right only while the probe enters the loss with coefficient exactly 1: checked, not assumed
+            # (one host synchronisation, in the first warm-up step -- never inside a timed region)
+            if float(g) != 1.0:
+                raise RuntimeError(f'_ImageProbe: the upstream gradient is {float(g)}, not 1 -- the loss scales the image term; return g * w instead')
+            _ImageProbe.checked = True
         return ctx.saved_tensors[0], None
 
 
@@ -251,11 +261,44 @@ def other_configs(device, steps, warmup, only=None):
             # the image term of the LOSS (25.8 GB read by torch.dot) is the benchmark's, not the library's: reported so that it can be told apart
             ent['loss_probe_ms'] = float(np.mean([a.elapsed_time(b) for a, b in _ImageProbe.events[-steps:]]))
             _ImageProbe.events.clear()
+            ent['ms_per_step_without_loss_probe'] = ent['ms_per_step'] - ent['loss_probe_ms']
+            ent['agent_steps_per_s_without_loss_probe'] = B * A / (ent['ms_per_step_without_loss_probe'] * 1e-3)
         out.append(ent)
         del sim
         sink.clear()
         torch.cuda.empty_cache()
     return out
+
+
+def same_run_write_roofs(sim, buf, res, device, reps=5):
+    """What this part, in this run, writes into the very output buffer of the timed region (the reference points the roofline entry carries
+    beside the 8 TB/s of the data sheet):
+      measured_fill_gbs    torch's fill_ over the buffer (a front-to-back stream of the same bytes);
+      measured_stream_gbs  the raster kernel itself with nothing to rasterise -- the same launch geometry and store pattern, the cameras moved
+                           off the map so that no face and no agent is in view: the bare write stream of this kernel, an upper bound of
+                           what the launch with work can reach."""
+    from torchdrivesim_amd import _ops
+    n = buf.numel() * buf.element_size()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    buf.fill_(0.0)
+    for a, b in ev:
+        a.record()
+        buf.fill_(0.0)
+        b.record()
+    torch.cuda.synchronize(device)
+    fill_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    state = sim.get_state()
+    far = state[..., :2] * 0.0 + 1.0e6
+    psi = state[..., 2:3]
+    sim.render(far, psi, res=res, fov=FOV, out=buf)
+    _ops.raster_events = []
+    for _ in range(reps):
+        sim.render(far, psi, res=res, fov=FOV, out=buf)
+    torch.cuda.synchronize(device)
+    stream_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events]))
+    _ops.raster_events = None
+    assert not bool(buf[:2].any()), 'the cameras of the stream-only launch see something'
+    return dict(measured_fill_gbs=n / (fill_ms * 1e-3) / 1e9, measured_stream_gbs=n / (stream_ms * 1e-3) / 1e9, measured_stream_ms=stream_ms)
 
 
 def u8_mode(device, steps, warmup, B, A):
@@ -328,12 +371,16 @@ def launch(args, argv):
         raise SystemExit(f'--gpus {n} but only {len(ids)} devices are visible ({visible})')
     port = _free_port()
     procs = []
+    import tempfile
+    # rank 0's stdout goes to a file, not a pipe: whatever it prints (library warnings, NCCL_DEBUG=INFO ...) can never fill a pipe buffer
+    # and block it in write() while the other ranks wait in a barrier
+    out_file = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=ids[r], TDS_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
         env.pop('CUDA_VISIBLE_DEVICES', None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ['--worker'], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=out_file if r == 0 else subprocess.DEVNULL))
     out0 = b''
     deadline = time.time() + args.launch_timeout
     failed = None
@@ -354,10 +401,14 @@ def launch(args, argv):
         for pr in procs:                        # exact PIDs of the children this process started, nothing else
             if pr.poll() is None:
                 pr.kill()
-        try:
-            out0 = procs[0].communicate(timeout=10)[0] or b''
-        except Exception:
-            out0 = b''
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except Exception:                   # noqa: BLE001
+                pass
+        out_file.seek(0)
+        out0 = out_file.read()
+        out_file.close()
     for ln in out0.decode().splitlines():       # rank 0's JSON line to stdout, anything else it printed to stderr
         (sys.stdout if ln.lstrip().startswith('{') else sys.stderr).write(ln + '\n')
     sys.stdout.flush()
@@ -395,9 +446,19 @@ def main():
         # (TDS_BENCH_DRY_RUN_TRY_NCCL=1: keep asking for RCCL -- on a CPU it cannot come up, which exercises the fallback to gloo below)
         device, backend = torch.device('cpu'), ('nccl' if os.environ.get('TDS_BENCH_DRY_RUN_TRY_NCCL') == '1' else 'gloo')
     else:
+        n_dev = torch.cuda.device_count()
+        if n_dev == 0:
+            raise SystemExit('bench.py needs an MI355X (use --dry-run for the launch path alone)')
+        if local_rank >= n_dev:
+            # fewer devices than local ranks: only when the multi-process path is exercised on a smaller box (tests/test_gpu_bench_workers.py
+            # runs two ranks on the one GPU it has); on the 8-GPU node every rank has its own device
+            sys.stderr.write(f'[bench] rank {rank}: local rank {local_rank} but {n_dev} visible device(s): sharing device {local_rank % n_dev}\n')
+        local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
+    rccl_group = None
     if distributed:
+        import datetime
         import torch.distributed as dist
         # the transports announce themselves on fd 1 ("[Gloo] Rank 0 is connected to ..."): stdout carries the ONE JSON line and nothing else
         sys.stdout.flush()
@@ -405,34 +466,33 @@ def main():
         os.dup2(2, 1)
         try:
             os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')        # one node: gloo must not depend on the host name resolving
+            # No collective is on the data path: the process group carries the barrier around the timed region and the reductions of the
+            # timings.  Those reductions ALWAYS run over a gloo group created first (host tensors).  Under an external launcher the barrier is
+            # then moved to RCCL -- if and only if RCCL came up on EVERY rank, which the ranks agree on over gloo: a rank on which RCCL fails
+            # fast can no longer leave the others inside an RCCL rendezvous, and the attempt is bounded by a short timeout.
+            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=600))
+            dist.barrier()
             if backend == 'nccl':
-                # The process group only carries the barrier around the timed region and the reduction of the timings (no collective is on
-                # the data path), so if RCCL cannot be brought up the run is still valid over gloo: fall back instead of losing the measurement.
+                os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')            # a timeout raises in this thread instead of aborting the process
+                os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
+                ok, why = 1, ''
                 try:
-                    dist.init_process_group('nccl', device_id=device)
-                    dist.barrier()
+                    rccl_group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=float(os.environ.get('TDS_BENCH_RCCL_TIMEOUT', '90'))))
+                    dist.barrier(group=rccl_group, device_ids=[local_rank])
+                    torch.cuda.synchronize(device)
                 except Exception as exc:                                 # noqa: BLE001 -- whatever RCCL raises
-                    sys.stderr.write(f'[bench] rank {rank}: RCCL process group failed ({type(exc).__name__}: {exc}); falling back to gloo\n')
-                    try:
-                        dist.destroy_process_group()
-                    except Exception:                                    # noqa: BLE001
-                        pass
-                    backend = 'gloo-after-rccl'
-            if backend == 'gloo-after-rccl':
-                # a fresh rendezvous: the store of the failed attempt may still hold MASTER_PORT (a second env:// init against it ends in
-                # "Broken pipe" on the other ranks); every rank derives the same neighbouring port
-                addr, port = os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ.get('MASTER_PORT', '29500'))
-                dist.init_process_group('gloo', init_method=f'tcp://{addr}:{port + 1 if port < 65535 else port - 1}', rank=rank, world_size=world)
-                dist.barrier()
-                backend = 'gloo'
-            elif backend != 'nccl':
-                dist.init_process_group('gloo')
-                dist.barrier()
+                    ok, why = 0, f'{type(exc).__name__}: {exc}'
+                vote = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(vote, op=dist.ReduceOp.MIN)              # over gloo
+                if int(vote.item()) == 0:
+                    sys.stderr.write(f'[bench] rank {rank}: RCCL process group ' + (f'failed ({why})' if not ok else 'failed on another rank') +
+                                     '; falling back to gloo for the barrier\n')
+                    rccl_group, backend = None, 'gloo'
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    red_dev = device if backend == 'nccl' else 'cpu'        # where the (timing-only) reductions live
+    red_dev = 'cpu'        # the (timing-only) reductions live on the host, over gloo
 
     B, A = args.batch, args.agents
     from torchdrivesim_amd import parallel
@@ -448,14 +508,26 @@ def main():
         res = Resolution(RES, RES)
         from torchdrivesim_amd import _ops
 
+        # The images go to two caller-owned buffers, allocated once and used in turn (step i renders while the consumer of step i - 1 still
+        # holds the other one): a training loop owns its observation ring, and a fresh 51.5 GB allocation per step made the measured time depend
+        # on which physical memory each allocation happened to get.  The reference allocates per call (rendering/cv2.py:52).
+        bufs = [torch.empty((B, A, 3, RES, RES), dtype=torch.float32, device=device) for _ in range(2)]
+        _ops.raster_events = []
+        for b_ in bufs:                     # first touch of each buffer: the launch that also pays for mapping fresh memory, reported apart
+            sim.render_egocentric(res=res, fov=FOV, out=b_)
+        torch.cuda.synchronize(device)
+        first_touch_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events]))
+        _ops.raster_events = None
+
         def step(i):
             sim.step(actions[i % actions.shape[0]])
-            sink['img'] = sim.render_egocentric(res=res, fov=FOV)
+            sink['img'] = sim.render_egocentric(res=res, fov=FOV, out=bufs[i % 2])
             sink['col'] = sim.compute_collision()
             sink['off'] = sim.compute_offroad()
 
     def barrier():
-        parallel.barrier(device)            # dist.barrier() when there is a process group, then torch.cuda.synchronize()
+        # dist.barrier() when there is a process group (over RCCL where it came up, else gloo), then torch.cuda.synchronize()
+        parallel.barrier(device, group=rccl_group, device_ids=None if rccl_group is None else [local_rank])
 
     for i in range(args.warmup):
         step(i)
@@ -478,6 +550,12 @@ def main():
         value = world * B * A * args.steps / elapsed
         achieved = (B * A * ALGO_BYTES_PER_IMAGE) / (raster_ms * 1e-3) / 1e9 if raster_ms else None
         traffic, traffic_note = stamped_traffic(B, A)
+        same_run = {}
+        if not args.dry_run:
+            same_run = same_run_write_roofs(sim, bufs[0], res, device)
+            same_run['first_touch_ms'] = first_touch_ms
+            if achieved is not None:
+                same_run['frac_of_measured_stream'] = achieved / same_run['measured_stream_gbs']
         line = dict(
             metric='agent-steps/sec (whole node) at B=1024xA=64, 256x256 BEV', value=value, unit='agent-steps/s', n_gpus=world,
             steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / max(args.steps, 1), higher_is_better=True, scaling='weak',
@@ -488,7 +566,7 @@ def main():
             roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=None if achieved is None else achieved / HBM_PEAK_GBS,
                           traffic=traffic, traffic_source=traffic_note,
                           kernel='raster_scene_bits_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE,
-                          measured_copy_peak=HBM_COPY_GBS, frac_of_measured_copy=None if achieved is None else achieved / HBM_COPY_GBS))
+                          **same_run))
         if world > 1:
             line['per_rank_agent_steps_per_s'] = [B * A * args.steps / t for t in per_rank]
             line['launcher'] = ('bench.py self-launch, one child per GPU' if args.worker else 'external launcher (torch.distributed.run)') + \
@@ -500,7 +578,7 @@ def main():
             if not args.no_configs:
                 line['roofline_u8'] = u8_mode(device, args.steps, args.warmup, B, A)
                 line['roofline_128'] = low_res_mode(device, args.steps, args.warmup, B, A)
-                del sim
+                del sim, bufs
                 sink.clear()
                 torch.cuda.empty_cache()
                 line['configs'] = other_configs(device, args.steps, args.warmup)

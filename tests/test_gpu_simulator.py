@@ -435,3 +435,102 @@ def test_config5_full_size_backward(full_size):
     p_state, p_act = grads(part, actions[1][pick], w[pick])
     np.testing.assert_allclose(p_state.cpu().numpy(), g_state[pick].cpu().numpy(), rtol=2e-4, atol=2e-4 * float(g_state[pick].abs().max()))
     np.testing.assert_allclose(p_act.cpu().numpy(), g_act[pick].cpu().numpy(), rtol=2e-4, atol=2e-4 * float(g_act[pick].abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The headline shard -- B = 1024 x A = 64 x 256 x 256 per GPU, which is also BASELINE.json's config 4 (8192 scenes over 8 GPUs) as seen by
+# one GPU (this size had only ever been run by bench.py and the fuzz scripts).  simulator.py:480-511 of the reference is the
+# batch-axis contract: scenes are independent, so any sub-batch must reproduce the full batch bit for bit.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def test_headline_shard_full_size(oracle):
+    import bench
+    from torchdrivesim_amd.rendering import HipRendererConfig, renderer_from_config
+    from torchdrivesim_amd.utils import Resolution
+    B, A = 1024, 64
+    sim, actions, host = bench.build_simulator(B, A, torch.device(DEV), seed=1234 + 3)          # the shard of rank 3 in bench.py
+    state0, size, present, act, verts, faces, vcat, cats = host
+    sim.step(actions[0])
+    res = Resolution(256, 256)
+    img = sim.render_egocentric(res=res, fov=35.0)
+    col, off = sim.compute_collision(), sim.compute_offroad()
+    assert img.shape == (B, A, 3, 256, 256) and img.dtype == torch.float32 and col.shape == off.shape == (B, A)
+    # a caller-owned output buffer receives the same image, and the metrics are the same whether they ran beside the rasteriser or after it
+    buf = torch.empty_like(img)
+    assert sim.render_egocentric(res=res, fov=35.0, out=buf) is buf and torch.equal(buf, img)
+    del buf
+    sim.overlap_infractions = False
+    try:
+        assert torch.equal(sim.compute_collision(), col) and torch.equal(sim.compute_offroad(), off)
+    finally:
+        sim.overlap_infractions = True
+    # sub-batches (first, middle, last scene and a run across the XCD boundaries of the launch) reproduce the full batch bit for bit
+    pick = [0, 127, 128, 511, 512, 640, 1023]
+    sub = sim.select_batch_elements(torch.tensor(pick), in_place=False)
+    assert torch.equal(sub.render_egocentric(res=res, fov=35.0), img[pick])
+    assert torch.equal(sub.compute_collision(), col[pick]) and torch.equal(sub.compute_offroad(), off[pick])
+    # the uint8 mode shows the same values over the whole shard (compared slice by slice: no 51 GB temporary)
+    u8 = sim.copy()
+    u8.renderer = renderer_from_config(HipRendererConfig(out_dtype='uint8'), res=res, fov=35.0)
+    u8._scene_cache = None
+    img8 = u8.render_egocentric(res=res, fov=35.0)
+    assert img8.dtype == torch.uint8
+    for lo in range(0, B, 64):
+        assert torch.equal(img8[lo:lo + 64].float(), img[lo:lo + 64])
+    del img8, u8
+    # the oracle on what it can afford: one scene of images (the last one of the shard), eight scenes of collisions and off-road
+    s1 = sim.get_state().cpu().numpy()
+    sc = torch.stack([torch.sin(sim.get_state()[..., 2]), torch.cos(sim.get_state()[..., 2])], -1).cpu().numpy()
+    sv, sa, sf = oracle.static_mesh_arrays(verts, faces, vcat, cats)
+    b = B - 1
+    mask = np.ascontiguousarray(np.broadcast_to(present[b:b + 1, None, :], (1, A, A)))
+    ref = oracle.render_scenes(s1[b:b + 1], size[b:b + 1], mask, s1[b:b + 1, :, :2].copy(), sc[b:b + 1], sv, sa, sf, 35.0, 256, agent_sc=sc[b:b + 1])
+    np.testing.assert_array_equal(img[b:b + 1].cpu().numpy(), ref)
+    boxes = np.concatenate([s1[..., :2], size, s1[..., 2:3]], -1)
+    sl = slice(B - 8, B)
+    np.testing.assert_array_equal(col[sl].cpu().numpy(), oracle.collision(boxes[sl], present[sl], metric='iou', sc=sc[sl]))
+    np.testing.assert_array_equal(off[sl].cpu().numpy(), oracle.offroad(s1[sl], size[sl], verts, faces, 0.5, present=present[sl], sc=sc[sl]))
+    # size-independent sanity of the whole shard: every image has content, absent agents have no off-road loss
+    assert bool((img.flatten(2).amax(-1) > 0).all()) and not off[~torch.from_numpy(present).to(off.device)].any()
+    assert (col > 0).float().mean() > 0.01
+
+
+def test_infractions_beside_the_rasteriser_equal_the_serial_ones():
+    """compute_collision / compute_offroad / compute_wrong_way asked for after a render run on a second stream beside the raster launch
+    (Simulator._beside_render); whatever invalidates the fork -- a new state, an edited mask, another stream, gradients -- takes them
+    back to the caller's stream.  Either way the bits are the same."""
+    import bench, os
+    from torchdrivesim_amd import lanelet2
+    from torchdrivesim_amd.utils import Resolution
+    osm = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'carla_Town01.osm.gz')
+    lanes = lanelet2.load_lanelet_map(osm, origin=(0.0, 0.0))
+    sim, actions, _ = bench.build_simulator(32, 64, torch.device(DEV), seed=5, lanelet_map=lanes)
+    res = Resolution(256, 256)
+    for metric in ('iou', 'discs', 'nograd'):
+        from torchdrivesim_amd.simulator import CollisionMetric
+        sim.cfg.collision_metric = CollisionMetric(metric)
+        sim.step(actions[1])
+        sim.overlap_infractions = False
+        serial = (sim.compute_collision(), sim.compute_offroad(), sim.compute_wrong_way())
+        sim.overlap_infractions = True
+        img = sim.render_egocentric(res=res, fov=35.0)
+        assert sim._fork is not None
+        beside = (sim.compute_collision(), sim.compute_offroad(), sim.compute_wrong_way())
+        for a, b in zip(serial, beside):
+            assert torch.equal(a, b)
+        # results are usable on the caller's stream right away (joined by an event): consume them there
+        total = sum(float(t.sum()) for t in beside)
+        assert np.isfinite(total)
+        # a mask edited in place after the render invalidates the fork: the metric runs in place and sees the edit
+        sim.present_mask[:, 1] = False
+        col2 = sim.compute_collision()
+        sim.overlap_infractions = False
+        assert torch.equal(col2, sim.compute_collision())
+        sim.overlap_infractions = True
+        sim.present_mask[:, 1] = True
+    # gradients: the differentiable path never forks
+    s0 = sim.get_state().detach().clone().requires_grad_(True)
+    sim.kinematic_model.set_state(s0)
+    sim.cfg.collision_metric = CollisionMetric('iou')
+    img = sim.render_egocentric(res=Resolution(64, 64), fov=35.0)
+    (sim.compute_collision().sum() + sim.compute_offroad().sum() + img.sum() / 255.0).backward()
+    assert torch.isfinite(s0.grad).all()

@@ -85,6 +85,7 @@ struct CommonArgs {
                                 // only; layout in include/tdship.h, tds_raster_aux_t)
     int debug;                  // ablation switches for profiling (tds_raster_set_debug): 1 no static, 2 no actors, 4 no store,
                                 // 8 no outline edges, 16 no scan conversion
+    int xcd_skew;               // bit-plane kernel: XCD j starts its eighth of the images j * xcd_skew images in (and wraps around), see block_to_image
 };
 
 struct Camera {
@@ -596,11 +597,16 @@ __device__ inline void write_out(const uint32_t *tile, OutT *out, int64_t img, i
     }
 }
 
-__device__ inline void block_to_image(int64_t nblk, int strips, int64_t &img, int &strip) {
+__device__ inline void block_to_image(int64_t nblk, int strips, int64_t &img, int &strip, int skew = 0) {
     // blocks are dealt round-robin to the 8 XCDs; give consecutive logical ids to the same XCD so that the strips of
     // one camera (and neighbouring cameras of a scene) share an L2
     int64_t b = blockIdx.x, L = b;
-    if ((nblk & 7) == 0) L = (b & 7) * (nblk >> 3) + (b >> 3);
+    if ((nblk & 7) == 0) {
+        const int64_t per = nblk >> 3;
+        int64_t l = (b >> 3) + (int64_t)(b & 7) * skew * strips;     // skew: the eight write fronts do not advance at equal distances
+        if (skew != 0) l %= per;
+        L = (b & 7) * per + l;
+    }
     img = L / strips;
     strip = (int)(L - img * strips);
 }
@@ -1834,7 +1840,11 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
     const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
     int64_t img;
     int strip;
-    block_to_image(c.n_img * c.strips, c.strips, img, strip);
+    block_to_image(c.n_img * c.strips, c.strips, img, strip, c.xcd_skew);
+#ifdef TDS_TESTING
+    // debug flag 4096: when does each XCD start and finish its share of the launch?  (wall clock, 100 MHz; blocks are dealt round-robin to the XCDs)
+    if ((c.debug & 4096) && tid == 0) atomicMax(&g_stats[8 + (blockIdx.x & 7)], ~(unsigned long long)wall_clock64());
+#endif
     const int X0 = strip * TWp;
     const int plane_dw = K * H * wpr;
     // LDS: everything of fixed size first (addresses known at compile time), the planes (K * H * wpr words) last
@@ -1890,6 +1900,9 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
     __syncthreads();
     if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(0);
     if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, EMIT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, c.slices);
+#ifdef TDS_TESTING
+    if ((c.debug & 4096) && lane == 0) atomicMax(&g_stats[blockIdx.x & 7], (unsigned long long)wall_clock64());
+#endif
 }
 
 inline int bits_index_bits(int K) { return K <= 3 ? 2 : (K <= 7 ? 3 : 4); }
@@ -1953,6 +1966,7 @@ inline int pick_tw(int res) {
 }
 
 int g_force_tw = 0;
+int g_xcd_skew = 0;
 #ifdef TDS_TESTING
 int g_debug = 0;
 #endif
@@ -1987,6 +2001,13 @@ TDS_EXPORT int tds_raster_get_stats(unsigned long long *out16) {
 // ablation switches, see CommonArgs::debug
 TDS_EXPORT int tds_raster_set_debug(int flags) {
     g_debug = flags;
+    return TDS_OK;
+}
+
+// the skew between the write fronts of the eight XCDs, in images (see block_to_image)
+TDS_EXPORT int tds_raster_set_xcd_skew(int images) {
+    TDS_CHECK_ARG(images >= 0, "tds_raster_set_xcd_skew: negative skew");
+    g_xcd_skew = images;
     return TDS_OK;
 }
 #endif  // TDS_TESTING
@@ -2106,7 +2127,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     a.extra_tri = extra_tri; a.extra_key = extra_key; a.K = (int)n_extra;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug); cm.xcd_skew = g_xcd_skew;
     cm.no_trim = (aux && (aux->flags & TDS_RASTER_NO_TRIM)) ? 1 : 0;
     const bool want_slices = aux && aux->index_slices;
     if (want_slices) {
@@ -2239,7 +2260,7 @@ TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int
     for (int i = 1; i < n_levels; ++i) TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_raster_mesh: levels must be strictly descending");
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug); cm.xcd_skew = g_xcd_skew;
     cm.no_trim = (flags & TDS_RASTER_NO_TRIM) ? 1 : 0;
     TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
     TDS_LAUNCH_CHECK("raster_mesh_kernel");

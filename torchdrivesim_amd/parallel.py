@@ -28,11 +28,15 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def barrier(device=None):
-    """dist.barrier() (if a process group exists) followed by a device synchronisation when `device` is a GPU."""
+def barrier(device=None, group=None, device_ids=None):
+    """dist.barrier() (if a process group exists; over `group` when given, e.g. an RCCL group beside a default gloo group) followed by a
+    device synchronisation when `device` is a GPU."""
     d = _dist()
     if d is not None:
-        d.barrier()
+        if group is not None:
+            d.barrier(group=group, device_ids=device_ids)
+        else:
+            d.barrier()
     if device is not None and torch.device(device).type == 'cuda':
         torch.cuda.synchronize(device)
 

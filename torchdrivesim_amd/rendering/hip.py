@@ -88,8 +88,10 @@ class HipRenderer(BirdviewRenderer):
     def render_scene(self, static_map: _ops.StaticMap, state: Tensor, agent_sc: Tensor, tmpl: Tensor, actor_key: Tensor, mask: Tensor,
                      camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None,
                      key_table=None, differentiable: bool = False, extra_tri: Optional[Tensor] = None,
-                     extra_key: Optional[Tensor] = None, key_colors: Optional[Tensor] = None, color_keys=None) -> Tensor:
-        """-> B x Nc x 3 x H x W.  `differentiable`: attach the K3 backward (gradients w.r.t. state[..., :2], agent_sc, camera_xy,
+                     extra_key: Optional[Tensor] = None, key_colors: Optional[Tensor] = None, color_keys=None,
+                     out: Optional[Tensor] = None) -> Tensor:
+        """-> B x Nc x 3 x H x W.  `out`: a caller-owned contiguous B x Nc x 3 x H x W tensor of the renderer's output dtype to render into
+        (the C ABI takes caller buffers, include/tdship.h; the reference allocates per call, rendering/cv2.py:52) -- not for differentiable calls.  `differentiable`: attach the K3 backward (gradients w.r.t. state[..., :2], agent_sc, camera_xy,
         camera_sc; float32 output only).  `extra_tri` (B,Nc,K,3,2) / `extra_key` (B,Nc,K): per-camera world-space triangles.
         `key_colors` (K,3) / `color_keys` (K packed keys): colour-gradient handle, see _ops.raster_scene_diff."""
         res = self.res if res is None else res
@@ -99,7 +101,9 @@ class HipRenderer(BirdviewRenderer):
         if differentiable:
             if self.out_dtype != torch.float32:
                 raise RuntimeError('the differentiable path renders float32 images')
+            if out is not None:
+                raise RuntimeError('`out=` cannot be combined with a differentiable render (autograd owns the image)')
             return _ops.raster_scene_diff(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, key_table=key_table,
                                           extra_tri=extra_tri, extra_key=extra_key, key_colors=key_colors, color_keys=color_keys, trim=self.trim)
         return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype,
-                                 key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim)
+                                 key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)

@@ -278,6 +278,7 @@ class Simulator:
         if self.traffic_controls and getattr(self.birdview_mesh_generator, 'traffic_lights_mesh', None) is None:
             self.birdview_mesh_generator.initialize_traffic_controls_mesh(self.traffic_controls)      # simulator.py:373-374
         self._scene_cache = None        # device-resident static maps + actor templates/keys, rebuilt lazily
+        self._fork = None               # (event, stamp, stream) recorded right before the last raster launch, see _beside_render
 
     # ------------------------------------------------------------------------------------------------- properties
     @property
@@ -582,6 +583,57 @@ class Simulator:
     def fit_action(self, future_state: Tensor, current_state: Optional[Tensor] = None) -> Tensor:
         return self.kinematic_model.fit_action(future_state=future_state, current_state=current_state)
 
+    # ------------------------------------------------------------------------------------------------- infractions beside the rasteriser
+    #: The GymEnv.step body (examples/gym_env.py:83-126 of the reference) is step -> render_egocentric -> compute_collision / compute_offroad /
+    #: compute_wrong_way.  The rasteriser is bound by the HBM write stream and the metrics are compute-light and do not read the image, so the
+    #: metrics that are asked for AFTER a render of the same state are enqueued on a second HIP stream that waits only for what preceded the
+    #: raster launch (an event, no host synchronisation) and is joined to the caller's stream before the result is handed out: they run
+    #: beside the rasteriser instead of behind it.  Same kernels, same inputs, same bits.  False: everything on the caller's stream.
+    overlap_infractions = True
+    _side_streams: Dict[int, Any] = {}
+
+    def _fork_sources(self):
+        return [self.kinematic_model.get_state(), self.present_mask, self.agent_size, self.agent_type]
+
+    def _mark_fork(self) -> None:
+        """called by render() right before the raster launch: everything the metrics read has been enqueued by now"""
+        self._fork = None
+        state = self.kinematic_model.get_state()
+        if not self.overlap_infractions or not state.is_cuda or self.npc_count > 0:
+            return
+        self._heading_sc()                                        # the shared [sin, cos] exists before the fork
+        srcs = self._fork_sources()
+        stream = torch.cuda.current_stream(state.device)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._fork = (ev, [(t, t._version) for t in srcs], stream)
+
+    def _beside_render(self, fn):
+        """fn() -> Tensor, on the side stream when a render of exactly this state is in flight on the current stream, else in place"""
+        fork = self._fork
+        if fork is None or not self.overlap_infractions:
+            return fn()
+        ev, stamp, main = fork
+        srcs = self._fork_sources()
+        state = srcs[0]
+        cached = getattr(self, '_sc_cache', None)
+        if len(srcs) != len(stamp) or any(a is not b or a._version != v for a, (b, v) in zip(srcs, stamp)) or self.npc_count > 0 or \
+                (torch.is_grad_enabled() and any(t.requires_grad for t in srcs)) or torch.cuda.current_stream(state.device) != main or \
+                cached is None or cached[0] is not state or cached[1] != state._version:
+            return fn()
+        idx = state.device.index if state.device.index is not None else torch.cuda.current_device()
+        side = Simulator._side_streams.get(idx)
+        if side is None:
+            side = Simulator._side_streams[idx] = torch.cuda.Stream(device=state.device, priority=-1)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            out = fn()
+        out.record_stream(main)                                  # allocated in the side stream's pool, consumed on the caller's stream
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
+        return out
+
     # ------------------------------------------------------------------------------------------------- device scene data
     def _scene(self):
         """Static maps (one per distinct road mesh in the batch), actor templates and packed actor keys; rebuilt after
@@ -715,8 +767,11 @@ class Simulator:
 
     def render(self, camera_xy: Tensor, camera_psi: Tensor, res: Optional[Resolution] = None, rendering_mask: Optional[Tensor] = None,
                fov: Optional[float] = None, waypoints: Optional[Tensor] = None, waypoints_rendering_mask: Optional[Tensor] = None,
-               custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None) -> Tensor:
-        """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992)."""
+               custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None,
+               out: Optional[Tensor] = None) -> Tensor:
+        """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992).
+        `out` (not in the reference, which allocates per call, rendering/cv2.py:52): a caller-owned contiguous BxNx3xHxW tensor of the
+        renderer's output dtype to render into; returned.  HipRenderer only, one static map per batch, not for differentiable calls."""
         if noisy_perception:
             # what the policy is shown instead of the truth (simulator.py:951-978): the observation model's background, its lane markers
             # drawn as triangles, its traffic controls.  The scene of the ordinary path is swapped for the duration of the call; its
@@ -727,7 +782,7 @@ class Simulator:
             try:
                 return self.render(camera_xy, camera_psi, res=res, rendering_mask=rendering_mask, fov=fov, waypoints=waypoints,
                                    waypoints_rendering_mask=waypoints_rendering_mask, custom_agent_colors=custom_agent_colors,
-                                   noisy_perception=False, _camera_sc=_camera_sc)
+                                   noisy_perception=False, _camera_sc=_camera_sc, out=out)
             finally:
                 self.birdview_mesh_generator, self.traffic_controls, self._scene_cache = saved
         camera_sc = _camera_sc if _camera_sc is not None else torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
@@ -759,7 +814,11 @@ class Simulator:
             wp_tri = wp_on = None
             if waypoints is not None and waypoints.shape[2] > 0:
                 wp_tri, wp_on = self._waypoint_triangles(waypoints.to(state.dtype), waypoints_rendering_mask)
-            out = []
+            if out is not None and len(scene['maps']) != 1:
+                raise RuntimeError('`out=` needs a batch that is served by one launch')
+            out_arg, out = ({} if out is None else dict(out=out)), []
+            if not diff:
+                self._mark_fork()
             for i_map, ((smap, b), keys, ktab) in enumerate(zip(scene['maps'], scene['keys'], scene['key_tables'])):
                 sl = slice(None) if b is None else slice(b, b + 1)
                 k = keys[sl]
@@ -780,8 +839,11 @@ class Simulator:
                     extra = dict(extra_tri=wp_tri[sl], extra_key=torch.full(wp_tri[sl].shape[:3], wk, dtype=torch.int32, device=state.device))
                     ktab = None if ktab is None else sorted(set(ktab) | {wk})
                 out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], tmpl_all[sl], k, mask[sl].contiguous(),
-                                                      camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff, **extra))
+                                                      camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff, **extra,
+                                                      **out_arg))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
+        if out is not None:
+            raise RuntimeError(f'`out=` is served by HipRenderer only, not by {type(self.renderer).__name__}')
         # any other BirdviewRenderer: the reference's generic dataflow (explicit per-camera mesh)
         rgb_mesh = self.birdview_mesh_generator.generate(n_cam, agent_state=self.get_all_agent_state()[:, None].expand(-1, n_cam, -1, -1),
                                                          present_mask=mask, custom_agent_colors=custom_agent_colors,
@@ -793,8 +855,8 @@ class Simulator:
 
     def render_egocentric(self, ego_rotate: bool = True, res: Optional[Resolution] = None, fov: Optional[float] = None,
                           visibility_matrix: Optional[Tensor] = None, custom_agent_colors: Optional[Tensor] = None,
-                          n_subsequent_waypoints: int = 1, noisy_perception: bool = False) -> Tensor:
-        """One camera per exposed agent -> BxAx3xHxW (simulator.py:994-1033)."""
+                          n_subsequent_waypoints: int = 1, noisy_perception: bool = False, out: Optional[Tensor] = None) -> Tensor:
+        """One camera per exposed agent -> BxAx3xHxW (simulator.py:994-1033).  `out`: see `render`."""
         state = self.get_state()
         camera_xy, camera_psi = state[..., :2], state[..., 2:3]
         if not ego_rotate:
@@ -810,12 +872,16 @@ class Simulator:
         waypoints = self.get_waypoints(count=n_subsequent_waypoints)                  # simulator.py:1013-1017
         waypoints_mask = self.get_waypoints_mask(count=n_subsequent_waypoints) if waypoints is not None else None
         return self.render(camera_xy, camera_psi, rendering_mask=rendering_mask, res=res, fov=fov, custom_agent_colors=custom_agent_colors,
-                           waypoints=waypoints, waypoints_rendering_mask=waypoints_mask, noisy_perception=noisy_perception, _camera_sc=cam_sc)
+                           waypoints=waypoints, waypoints_rendering_mask=waypoints_mask, noisy_perception=noisy_perception, _camera_sc=cam_sc,
+                           out=out)
 
     # ------------------------------------------------------------------------------------------------- infractions
     def compute_offroad(self) -> Tensor:
         """BxA off-road loss = thresholded squared corner-to-mesh distance x present (simulator.py:1035-1044).
         The whole road_mesh is the driving surface, lane markings included."""
+        return self._beside_render(self._compute_offroad)
+
+    def _compute_offroad(self) -> Tensor:
         state = self.get_state()
         if self.agent_count == 0 or self.road_mesh.faces_count == 0:
             return torch.zeros_like(state[..., 0])
@@ -834,6 +900,9 @@ class Simulator:
         """Wrong-way metric per agent, -cos of the angle between the agent and the lane it is on where that angle exceeds
         `cfg.wrong_way_angle_threshold` (simulator.py:607-630 -> infractions.lanelet_orientation_loss), times the present mask.
         Zeros without a lanelet map, as the reference.  `lanelet_map`: a list of B `lanelet2.LaneletMap` or None."""
+        return self._beside_render(self._compute_wrong_way)
+
+    def _compute_wrong_way(self) -> Tensor:
         state = self.get_state()
         if self.lanelet_map is None or all(m is None for m in self.lanelet_map):
             return torch.zeros(state.shape[0], state.shape[1], device=state.device)
@@ -866,6 +935,9 @@ class Simulator:
     def compute_collision(self, agent_types: Optional[List[str]] = None) -> Tensor:
         """BxA collision metric of the exposed agents against ALL agents (simulator.py:1161-1194).  For `iou` / `discs`:
         collision_i = sum_j o_ij present_j - max_j o_ij present_j, self overlap assumed to be the max."""
+        return self._beside_render(lambda: self._compute_collision(agent_types))
+
+    def _compute_collision(self, agent_types: Optional[List[str]] = None) -> Tensor:
         metric = self.cfg.collision_metric
         A = self.agent_count
         if A == 0:
