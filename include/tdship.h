@@ -321,9 +321,6 @@ int tds_raster_set_bits_waves(int n);
  * 64 no bit planes, 128 work counters on, 512 no per-face set-up (nothing is painted), 1024 walk the grid but project nothing,
  * 2048 the 170-VGPR instantiation everywhere, 4096 the work counters hold per-XCD finish [0..7] and ~start [8..15] wall clocks (100 MHz) */
 int tds_raster_set_debug(int flags);
-/* bit-plane kernel: XCD j starts its eighth of the images j * `images` images in and wraps around (0: all eight fronts start at the
- * beginning of their eighth) */
-int tds_raster_set_xcd_skew(int images);
 /* read and reset the 16 work counters of the bit-plane kernel */
 int tds_raster_get_stats(unsigned long long *out16);
 /* 0: maps created from now on carry no nearest-face candidate lists (K2b then walks grid rings) */

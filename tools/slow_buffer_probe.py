@@ -28,18 +28,16 @@ def main():
     ap.add_argument('--filler-gb', type=float, default=0.0, help='an allocation of this size made BEFORE the output tensors')
     ap.add_argument('--stream-only', action='store_true', help='testing build, no rasterisation: the store pattern alone')
     ap.add_argument('--reps', type=int, default=3)
-    ap.add_argument('--skews', type=int, nargs='*', default=[], help='testing build: whole launches with these skews (in images) between the write fronts of the XCDs')
     ap.add_argument('--no-chunks', action='store_true')
     args = ap.parse_args()
     from torchdrivesim_amd import _native, _ops
     from torchdrivesim_amd.utils import Resolution
     dev = torch.device('cuda', 0)
     L = None
-    if args.stream_only or args.skews:
+    if args.stream_only:
         L = _native.testing_lib()
         _native._lib = L
-        if args.stream_only:
-            L.tds_raster_set_debug(1 | 2)
+        L.tds_raster_set_debug(1 | 2)
     B, A = 1024, 64
     sim, actions, _ = bench.build_simulator(B, A, dev, seed=1234)
     for i in range(5):
@@ -75,19 +73,6 @@ def main():
         whole = min(a.elapsed_time(b) for a, b in _ops.raster_events)
         _ops.raster_events = None
         fill = timed(lambda: buf.fill_(2.0))
-        by_skew = []
-        for sk in args.skews:
-            L.tds_raster_set_xcd_skew(sk)
-            sim.render_egocentric(res=res, fov=bench.FOV, out=buf)
-            _ops.raster_events = []
-            for _ in range(args.reps):
-                sim.render_egocentric(res=res, fov=bench.FOV, out=buf)
-            torch.cuda.synchronize()
-            by_skew.append(f'skew {sk}: {min(a.elapsed_time(b) for a, b in _ops.raster_events):.2f}')
-            _ops.raster_events = None
-            L.tds_raster_set_xcd_skew(0)
-        if by_skew:
-            print(f'buffer {bi} ptr {buf.data_ptr():x}: whole launch {whole:.2f} ms, fill_ {fill:.2f} ms | ' + ', '.join(by_skew), flush=True)
         chunks = []
         for ci, sub in enumerate(subs if not args.no_chunks else []):
             lo = ci * args.chunk

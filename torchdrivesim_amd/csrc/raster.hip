@@ -18,6 +18,8 @@
 //     explicit per-camera RGB mesh.
 // Roofline: HBM write, 3*H*W*4 B per camera (fp32) -- DESIGN.md.
 #include "tds_common.h"
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 using tds::GridEntry;
@@ -85,7 +87,6 @@ struct CommonArgs {
                                 // only; layout in include/tdship.h, tds_raster_aux_t)
     int debug;                  // ablation switches for profiling (tds_raster_set_debug): 1 no static, 2 no actors, 4 no store,
                                 // 8 no outline edges, 16 no scan conversion
-    int xcd_skew;               // bit-plane kernel: XCD j starts its eighth of the images j * xcd_skew images in (and wraps around), see block_to_image
 };
 
 struct Camera {
@@ -597,16 +598,11 @@ __device__ inline void write_out(const uint32_t *tile, OutT *out, int64_t img, i
     }
 }
 
-__device__ inline void block_to_image(int64_t nblk, int strips, int64_t &img, int &strip, int skew = 0) {
+__device__ inline void block_to_image(int64_t nblk, int strips, int64_t &img, int &strip) {
     // blocks are dealt round-robin to the 8 XCDs; give consecutive logical ids to the same XCD so that the strips of
     // one camera (and neighbouring cameras of a scene) share an L2
     int64_t b = blockIdx.x, L = b;
-    if ((nblk & 7) == 0) {
-        const int64_t per = nblk >> 3;
-        int64_t l = (b >> 3) + (int64_t)(b & 7) * skew * strips;     // skew: the eight write fronts do not advance at equal distances
-        if (skew != 0) l %= per;
-        L = (b & 7) * per + l;
-    }
+    if ((nblk & 7) == 0) L = (b & 7) * (nblk >> 3) + (b >> 3);
     img = L / strips;
     strip = (int)(L - img * strips);
 }
@@ -1825,38 +1821,67 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
 template <int NB, typename OutT>
 constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename PairTab<NB, OutT>::E) / 4; }
 
-// one workgroup per (camera, strip); for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
+// Work distribution of the bit-plane kernel.  The launch is PERSISTENT: a fixed number of workgroups (a few per CU), each of which takes
+// one (camera, strip) after the other from a queue until none is left.  There is one queue per XCD -- a contiguous eighth of the launch, so
+// that neighbouring cameras share an L2 for grid cells and every XCD streams into its own region of the output (scenes dealt round-robin to
+// the XCDs cost 15 %) -- and a workgroup whose own queue has run dry STEALS from the queues of the other XCDs.  Why: the write path is not
+// symmetric.  With equal shares the even XCDs of this part finish their eighth 9 % (float32: 6.5 against 7.1 ms; on a "slow" output
+// allocation 7.2 against 8.3 ms) before the odd ones, which then write the tail at half the aggregate bandwidth (tools/xcd_finish_times.py;
+// the imbalance is in the store stream: a launch that rasterises nothing shows it, a launch that stores nothing does not).
+// `queue`: 8 counters, zero at launch (the host clears a slot of a small pool in stream order).  Workgroups find their XCD by
+// blockIdx.x & 7 (workgroups are dealt round-robin to the XCDs).
+constexpr int BITS_FIXED_DW = 20;             // [0..14] ascending key table, [15] next chunk of the grid scan, [16] the work item taken next,
+                                              // [17] queues this workgroup has found empty
+// one thread: take the next item -- own queue first, then the others in cyclic order -- and leave it in state[0] (-1: nothing left);
+// state[1] = queues of that order already found empty by this workgroup.  Everything a workgroup carries from item to item lives in
+// LDS: the kernel has no register to spare
+__device__ __noinline__ void claim_work(uint32_t *queue, int nblk, uint32_t *state) {
+    const int nq = (nblk & 7) == 0 ? 8 : 1, per = nq == 8 ? nblk >> 3 : nblk, xcd = (int)(blockIdx.x & (unsigned)(nq - 1));
+    int tried = (int)state[1], item = -1;
+    for (; tried < nq; ++tried) {
+        const int v = (xcd + tried) & (nq - 1);
+        const uint32_t i = atomicAdd(&queue[v], 1u);
+        if (i < (uint32_t)per) { item = v * per + (int)i; break; }
+    }
+    state[1] = (uint32_t)tried;
+    state[0] = (uint32_t)item;
+}
+
+// one workgroup per (camera, strip) at a time; for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
 // EMIT: also store the key-index slices for the backward pass (a separate instantiation: the plain kernel sits exactly at its VGPR limit)
 // MINWG: workgroups per CU the register budget is cut for.  3 (170 VGPRs) is what the LDS of a 256 x 256 camera with five keys allows
 // (51.8 KB each).  Where the planes are small enough for four workgroups per CU (40 KB each: 128 x 128 images, scenes of three keys) the
 // instantiation with 128 VGPRs is used: it spills 160 bytes per lane and is still 13 % faster (128 x 128: 4.47 -> 3.89 ms) -- at three
 // waves per SIMD the kernel waits for its own latencies; five or six workgroups per CU (96 / 80 VGPRs) lose to their spills.
+// The instantiations that run three workgroups per CU are persistent (work queues above; also 4 % on the uint8 mode: no gap between
+// the end of one workgroup and the start of the next on its slot).  The 128-VGPR instantiations are not: the loop over the items costs
+// them another 64 bytes of spills per lane, which outweighs it (128 x 128: 3.95 -> 4.17 ms); they take ONE item, by blockIdx.
 template <int BWAVES, int NB, typename OutT, typename SA, bool EMIT = false, int MINWG = 3>
-__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp) {
+__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp, uint32_t *queue) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
+    constexpr bool PERSIST = BWAVES == 4 && MINWG == 3;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
-    int64_t img;
-    int strip;
-    block_to_image(c.n_img * c.strips, c.strips, img, strip, c.xcd_skew);
+    const int plane_dw = K * H * wpr;
+    // LDS: everything of fixed size first (addresses known at compile time), the planes (K * H * wpr words) last
+    E *tab = (E *)smem;                                                  // [3][P] output values of an index pair
+    uint32_t *lkeys = smem + pair_tab_dw<NB, OutT>();                     // [16] ascending key table, [16] the work item taken next
+    uint32_t *planes = lkeys + BITS_FIXED_DW + BWAVES * BITS_WAVE_LDS_DW;
+    // the launch's work items: (camera, strip) pairs, as eight queues of consecutive items when they divide evenly, else as one
+    if constexpr (PERSIST) {
+        if (tid == 0) { lkeys[17] = 0; claim_work(queue, (int)(c.n_img * c.strips), lkeys + 16); }
+    }
 #ifdef TDS_TESTING
     // debug flag 4096: when does each XCD start and finish its share of the launch?  (wall clock, 100 MHz; blocks are dealt round-robin to the XCDs)
     if ((c.debug & 4096) && tid == 0) atomicMax(&g_stats[8 + (blockIdx.x & 7)], ~(unsigned long long)wall_clock64());
 #endif
-    const int X0 = strip * TWp;
-    const int plane_dw = K * H * wpr;
-    // LDS: everything of fixed size first (addresses known at compile time), the planes (K * H * wpr words) last
-    E *tab = (E *)smem;                                                  // [3][P] output values of an index pair
-    uint32_t *lkeys = smem + pair_tab_dw<NB, OutT>();                     // [16] ascending key table
-    uint32_t *planes = lkeys + 16 + BWAVES * BITS_WAVE_LDS_DW;
-    for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
     if (tid < 16) {
         uint32_t kv = 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < 16; ++i) kv = (tid == i) ? kt.key[i] : kv;     // kt lives in SGPRs: no dynamic indexing
-        lkeys[tid] = tid == 15 ? (uint32_t)BWAVES : kv;                    // entry 15 is no key (K <= 15): the next chunk of the grid scan
+        lkeys[tid] = kv;                                                   // entry 15 is no key (K <= 15): the next chunk of the grid scan, set per item
     }
     __syncthreads();
     for (int e = tid; e < 3 * P; e += BBLOCK) {
@@ -1867,39 +1892,71 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
         if constexpr (sizeof(OutT) == 4) tab[e] = make_float2((float)vlo, (float)vhi);
         else tab[e] = vlo | (vhi << 8);
     }
-    // uint8 output (the kernel is bound by instruction issue): waves that rasterise take precedence over the waves of other workgroups that
-    // are streaming out (measured: -2 %).  float32 output is bound by the HBM write stream: there the raise costs 2 % (7.41 -> 7.23 ms median)
-    if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(1);
     BitCtx w;
     w.planes = planes;
-    w.q = lkeys + 16 + wave * BITS_WAVE_LDS_DW;
+    w.q = lkeys + BITS_FIXED_DW + wave * BITS_WAVE_LDS_DW;
     w.slots = w.q + Q_DW;
     w.eq = w.slots + 64;
-    w.eq_head = 0; w.eq_count = 0;
-    w.slots[lane] = 0;
-    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug; w.gen = 0;
-    Camera cam;
-    {
-        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
-        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
-        make_polygon(cam, c.scale, res);
-    }
-    __syncthreads();
-    ScanState st;
-    scan_init(st, a, c, cam, img, lane, wave, X0, TWp);
-    st.dyn = lkeys + 15;
+    w.lane = lane; w.H = H; w.W = W; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug;
+#pragma unroll 1
     for (;;) {
-        bool acc;
-        uint32_t key;
-        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-        unsigned edges;
-        const bool more = scan_step<BWAVES, SA>(st, a, c, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
-        drain_bits(w, lkeys, K, acc, key, edges, px, py, more);
-        if (!more) break;
+        int64_t img;
+        int X0;
+        if constexpr (PERSIST) {
+            __syncthreads();                                                 // the next item is known; every wave has left the planes of the previous one
+            const int item = __builtin_amdgcn_readfirstlane((int)lkeys[16]);
+            if (item < 0) break;
+            img = item / c.strips;
+            X0 = (item - (int)img * c.strips) * TWp;
+        } else {
+            int strip;
+            block_to_image(c.n_img * c.strips, c.strips, img, strip);
+            X0 = strip * TWp;
+        }
+        for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
+        if (tid == 15) lkeys[15] = (uint32_t)BWAVES;
+        // uint8 output (the kernel is bound by instruction issue): waves that rasterise take precedence over the waves of other workgroups that
+        // are streaming out (measured: -2 %).  float32 output is bound by the HBM write stream: there the raise costs 2 % (7.41 -> 7.23 ms median)
+        if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(1);
+        w.eq_head = 0; w.eq_count = 0;
+        w.slots[lane] = 0;
+        w.qlen = 0; w.X0 = X0; w.gen = 0;
+        // Scale and resolution are the same for every item, and the compiler would compute what the item prologue derives from them (the
+        // corners of the trim polygon, the window of the grid scan: a dozen divisions) once, before the loop over the items -- and then
+        // hold the results in registers through the rasterisation of every item, where the kernel has none to spare.  The empty asm makes
+        // them per-item values.
+        CommonArgs ci = c;
+        if constexpr (PERSIST) {
+            int sb = __float_as_int(c.scale), rb = c.res;
+            asm volatile("" : "+s"(sb), "+s"(rb));
+            ci.scale = __int_as_float(sb); ci.res = rb;
+        }
+        Camera cam;
+        {
+            float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
+            cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
+            make_polygon(cam, ci.scale, ci.res);
+        }
+        __syncthreads();
+        ScanState st;
+        scan_init(st, a, ci, cam, img, lane, wave, X0, TWp);
+        st.dyn = lkeys + 15;
+        for (;;) {
+            bool acc;
+            uint32_t key;
+            int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+            unsigned edges;
+            const bool more = scan_step<BWAVES, SA>(st, a, ci, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
+            drain_bits(w, lkeys, K, acc, key, edges, px, py, more);
+            if (!more) break;
+        }
+        // the next item is taken now (every wave read the current one two barriers ago): the round trip of the atomic hides behind the stream-out
+        if constexpr (PERSIST) { if (tid == 0) claim_work(queue, (int)(c.n_img * c.strips), lkeys + 16); }
+        __syncthreads();
+        if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(0);
+        if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, EMIT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, c.slices);
+        if constexpr (!PERSIST) break;
     }
-    __syncthreads();
-    if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(0);
-    if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, EMIT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, c.slices);
 #ifdef TDS_TESTING
     if ((c.debug & 4096) && lane == 0) atomicMax(&g_stats[blockIdx.x & 7], (unsigned long long)wall_clock64());
 #endif
@@ -1910,9 +1967,47 @@ inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) 
     size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
     size_t P = (size_t)1 << (2 * bits_index_bits(K));
     size_t tab_dw = 3 * P * (out_mode == TDS_OUT_F32 ? 2 : 1);
-    return (plane_dw + tab_dw + 16 + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
+    return (plane_dw + tab_dw + BITS_FIXED_DW + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
 }
 int g_bits_waves = 4;
+
+// The work queues of a persistent bit-plane launch: 8 counters (64 bytes) that must be zero when the kernel starts.  A launch takes the
+// next slot of a small per-device pool and clears it in stream order right before the kernel; SLOTS launches can be in flight before a
+// slot comes round again (a launch is milliseconds of work on a device that runs a handful of streams).
+constexpr int QUEUE_SLOTS = 1024, QUEUE_DEVICES = 64;
+uint32_t *g_queue_pool[QUEUE_DEVICES] = {nullptr};
+std::atomic<unsigned> g_queue_next{0};
+std::mutex g_queue_mu;
+int work_queue(hipStream_t stream, uint32_t **out) {
+    int dev = 0;
+    TDS_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= QUEUE_DEVICES) { tds::set_error("tds_raster_scene: device index %d out of range", dev); return TDS_ELIMIT; }
+    {
+        std::lock_guard<std::mutex> lock(g_queue_mu);
+        if (g_queue_pool[dev] == nullptr) {
+            void *p = nullptr;
+            TDS_HIP(hipMalloc(&p, (size_t)QUEUE_SLOTS * 64));
+            g_queue_pool[dev] = (uint32_t *)p;
+        }
+    }
+    uint32_t *slot = g_queue_pool[dev] + (size_t)(g_queue_next.fetch_add(1u) % QUEUE_SLOTS) * 16;
+    TDS_HIP(hipMemsetAsync(slot, 0, 64, stream));
+    *out = slot;
+    return TDS_OK;
+}
+// workgroups of a persistent launch: enough to fill every CU at the kernel's occupancy twice over (a workgroup that finds the queues empty
+// leaves at once; the surplus takes the place of workgroups that could not start with the others because another stream's kernel held
+// their slots)
+int persistent_grid(int64_t items) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    const int64_t cap = (int64_t)cus * 8;
+    return (int)(items < cap ? items : cap);
+}
 
 // Generic path: arbitrary per-camera RGB mesh, every face is a candidate (no grid).
 template <int TW, typename OutT>
@@ -1966,7 +2061,6 @@ inline int pick_tw(int res) {
 }
 
 int g_force_tw = 0;
-int g_xcd_skew = 0;
 #ifdef TDS_TESTING
 int g_debug = 0;
 #endif
@@ -2004,12 +2098,6 @@ TDS_EXPORT int tds_raster_set_debug(int flags) {
     return TDS_OK;
 }
 
-// the skew between the write fronts of the eight XCDs, in images (see block_to_image)
-TDS_EXPORT int tds_raster_set_xcd_skew(int images) {
-    TDS_CHECK_ARG(images >= 0, "tds_raster_set_xcd_skew: negative skew");
-    g_xcd_skew = images;
-    return TDS_OK;
-}
 #endif  // TDS_TESTING
 
 #define TDS_LAUNCH_RASTER(KERNEL, ARGS)                                                                                        \
@@ -2127,7 +2215,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     a.extra_tri = extra_tri; a.extra_key = extra_key; a.K = (int)n_extra;
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug); cm.xcd_skew = g_xcd_skew;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
     cm.no_trim = (aux && (aux->flags & TDS_RASTER_NO_TRIM)) ? 1 : 0;
     const bool want_slices = aux && aux->index_slices;
     if (want_slices) {
@@ -2171,18 +2259,26 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                 cb.strips = (res + twp - 1) / twp;
                 cb.slices = want_slices ? aux->index_slices : nullptr;
                 if (aux) { aux->n_keys = kt.n; aux->index_bits = bits_index_bits(kt.n); for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
-                dim3 grid((unsigned)(n_img * cb.strips));
+                const int nb = bits_index_bits(kt.n);
+                const bool four_per_cu = lds <= 40 * 1024 && !(TDS_DBG(g_debug) & 2048);      // see MINWG (2048: ablation, the 170-VGPR kernel)
+                // the instantiations for three workgroups per CU are persistent launches: their workgroups take (camera, strip) items from per-XCD
+                // queues (see claim_work); the others get one workgroup per item
+                const bool persist = nwv == 4 && (!four_per_cu || cb.slices != nullptr);
+                uint32_t *queue = nullptr;
+                if (persist) {
+                    rc = work_queue((hipStream_t)stream, &queue);
+                    if (rc != TDS_OK) return rc;
+                }
+                dim3 grid((unsigned)(persist ? persistent_grid(n_img * cb.strips) : n_img * cb.strips));
                 const SceneArgs base = a;
                 auto launch_b = [&](auto kern) {            // scenes without per-camera triangles
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, base, cb, kt, twp);
+                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, base, cb, kt, twp, queue);
                 };
                 auto launch = [&](auto kern) {
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp);
+                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp, queue);
                 };
-                const int nb = bits_index_bits(kt.n);
-                const bool four_per_cu = lds <= 40 * 1024 && !(TDS_DBG(g_debug) & 2048);      // see MINWG (2048: ablation, the 170-VGPR kernel)
 #define TDS_BITS_DISPATCH(T)                                                                                                   \
     do {                                                                                                                       \
         if (nwv == 4 && four_per_cu && a.K == 0) { if (nb == 2) launch_b(raster_scene_bits_kernel<4, 2, T, SceneArgs, false, 4>); else if (nb == 3) launch_b(raster_scene_bits_kernel<4, 3, T, SceneArgs, false, 4>); else launch_b(raster_scene_bits_kernel<4, 4, T, SceneArgs, false, 4>); } \
@@ -2260,7 +2356,7 @@ TDS_EXPORT int tds_raster_mesh(const float *verts, const float *attrs, const int
     for (int i = 1; i < n_levels; ++i) TDS_CHECK_ARG(levels[i] < levels[i - 1], "tds_raster_mesh: levels must be strictly descending");
     CommonArgs cm;
     cm.cam_xy = (const float2 *)cam_xy; cm.cam_sc = (const float2 *)cam_sc; cm.scale = scale; cm.res = res;
-    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug); cm.xcd_skew = g_xcd_skew;
+    cm.strips = (res + tw - 1) / tw; cm.n_img = n_img; cm.out = out; cm.slices = nullptr; cm.debug = TDS_DBG(g_debug);
     cm.no_trim = (flags & TDS_RASTER_NO_TRIM) ? 1 : 0;
     TDS_LAUNCH_RASTER(raster_mesh_kernel, a);
     TDS_LAUNCH_CHECK("raster_mesh_kernel");
