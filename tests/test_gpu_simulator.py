@@ -451,6 +451,7 @@ def test_headline_shard_full_size(oracle):
     state0, size, present, act, verts, faces, vcat, cats = host
     sim.step(actions[0])
     res = Resolution(256, 256)
+    sim.overlap_infractions = True                    # the metrics of this test run beside the raster launch (second stream) ...
     img = sim.render_egocentric(res=res, fov=35.0)
     col, off = sim.compute_collision(), sim.compute_offroad()
     assert img.shape == (B, A, 3, 256, 256) and img.dtype == torch.float32 and col.shape == off.shape == (B, A)
@@ -458,11 +459,8 @@ def test_headline_shard_full_size(oracle):
     buf = torch.empty_like(img)
     assert sim.render_egocentric(res=res, fov=35.0, out=buf) is buf and torch.equal(buf, img)
     del buf
-    sim.overlap_infractions = False
-    try:
-        assert torch.equal(sim.compute_collision(), col) and torch.equal(sim.compute_offroad(), off)
-    finally:
-        sim.overlap_infractions = True
+    sim.overlap_infractions = False                   # ... and behind it (the default)
+    assert torch.equal(sim.compute_collision(), col) and torch.equal(sim.compute_offroad(), off)
     # sub-batches (first, middle, last scene and a run across the XCD boundaries of the launch) reproduce the full batch bit for bit
     pick = [0, 127, 128, 511, 512, 640, 1023]
     sub = sim.select_batch_elements(torch.tensor(pick), in_place=False)
@@ -527,6 +525,7 @@ def test_infractions_beside_the_rasteriser_equal_the_serial_ones():
         assert torch.equal(col2, sim.compute_collision())
         sim.overlap_infractions = True
         sim.present_mask[:, 1] = True
+    assert type(sim).overlap_infractions is False          # off unless asked for
     # gradients: the differentiable path never forks
     s0 = sim.get_state().detach().clone().requires_grad_(True)
     sim.kinematic_model.set_state(s0)

@@ -1828,15 +1828,18 @@ constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename 
 // symmetric.  With equal shares the even XCDs of this part finish their eighth 9 % (float32: 6.5 against 7.1 ms; on a "slow" output
 // allocation 7.2 against 8.3 ms) before the odd ones, which then write the tail at half the aggregate bandwidth (tools/xcd_finish_times.py;
 // the imbalance is in the store stream: a launch that rasterises nothing shows it, a launch that stores nothing does not).
-// `queue`: 8 counters, zero at launch (the host clears a slot of a small pool in stream order).  Workgroups find their XCD by
-// blockIdx.x & 7 (workgroups are dealt round-robin to the XCDs).
+// `queue`: 8 counters, zero at launch (the host clears a slot of a small pool in stream order).  A workgroup reads the XCD it runs on
+// from the XCC_ID hardware register.
 constexpr int BITS_FIXED_DW = 20;             // [0..14] ascending key table, [15] next chunk of the grid scan, [16] the work item taken next,
                                               // [17] queues this workgroup has found empty
 // one thread: take the next item -- own queue first, then the others in cyclic order -- and leave it in state[0] (-1: nothing left);
 // state[1] = queues of that order already found empty by this workgroup.  Everything a workgroup carries from item to item lives in
 // LDS: the kernel has no register to spare
 __device__ __noinline__ void claim_work(uint32_t *queue, int nblk, uint32_t *state) {
-    const int nq = (nblk & 7) == 0 ? 8 : 1, per = nq == 8 ? nblk >> 3 : nblk, xcd = (int)(blockIdx.x & (unsigned)(nq - 1));
+    // which XCD this workgroup really runs on: the XCC_ID hardware register (id 20, bits 3:0 on gfx950), not blockIdx.x & 7 -- workgroups
+    // are dealt round-robin to the XCDs, but where the round starts is the dispatcher's business once another stream's kernel is in flight
+    const int nq = (nblk & 7) == 0 ? 8 : 1, per = nq == 8 ? nblk >> 3 : nblk;
+    const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (unsigned)(nq - 1));
     int tried = (int)state[1], item = -1;
     for (; tried < nq; ++tried) {
         const int v = (xcd + tried) & (nq - 1);

@@ -6,7 +6,7 @@ OpenCV configuration) selects it too.
 """
 from torchdrivesim_amd.rendering.base import (RendererConfig, DummyRendererConfig, BirdviewRenderer, DummyRenderer, Cameras,
                                               get_default_color_map, get_default_rendering_levels)
-from torchdrivesim_amd.rendering.hip import HipRendererConfig, CV2RendererConfig, HipRenderer
+from torchdrivesim_amd.rendering.hip import HipRendererConfig, CV2RendererConfig, HipRenderer, allocate_image_ring
 
 
 def renderer_from_config(cfg: RendererConfig, *args, **kwargs) -> BirdviewRenderer:

@@ -107,3 +107,38 @@ class HipRenderer(BirdviewRenderer):
                                           extra_tri=extra_tri, extra_key=extra_key, key_colors=key_colors, color_keys=color_keys, trim=self.trim)
         return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype,
                                  key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)
+
+
+def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 4, reps: int = 2):
+    """`count` caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), chosen as
+    the fastest of up to `candidates` allocations of `shape`.
+
+    Why choose: the rasteriser is bound by the write stream, and on MI355X what the write stream of its launch reaches depends on the
+    ALLOCATION it writes to -- a 51.5 GB tensor is either "fast" (7.1 ms per launch) or "slow" (8.3 ms: every XCD's stores are 13 - 16 %
+    slower), for as long as it lives, whichever kernel touches it first and wherever it lies; about every second allocation of a fresh
+    process is slow (tools/slow_buffer_probe.py, tools/xcd_finish_times.py).  A loop that owns its observation ring can
+    pay for that once, at start-up: allocate a few candidates, time one launch into each, keep the fast ones, free the rest.
+    Returns (buffers, report) with report = dict(first_touch_ms=[...], launch_ms=[...], kept=[indices]) over the candidates.
+    The candidates that are not kept go back to the driver (torch.cuda.empty_cache) so that a later allocation does not get them again."""
+    device = torch.device(device)
+    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    free, _ = torch.cuda.mem_get_info(device)
+    n = max(count, min(candidates, int((free - (4 << 30)) // max(nbytes, 1))))
+    cands = [torch.empty(shape, dtype=dtype, device=device) for _ in range(n)]
+    first, best = [], []
+    for buf in cands:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 2)]
+        ev[0].record()
+        render(buf)                                    # first touch: maps the memory
+        ev[1].record()
+        for r in range(reps):
+            render(buf)
+            ev[2 + r].record()
+        torch.cuda.synchronize(device)
+        first.append(ev[0].elapsed_time(ev[1]))
+        best.append(min(ev[1 + r].elapsed_time(ev[2 + r]) for r in range(reps)))
+    kept = sorted(sorted(range(n), key=lambda i: best[i])[:count])
+    out = [cands[i] for i in kept]
+    del cands, buf
+    torch.cuda.empty_cache()
+    return out, dict(first_touch_ms=first, launch_ms=best, kept=kept)

@@ -586,10 +586,14 @@ class Simulator:
     # ------------------------------------------------------------------------------------------------- infractions beside the rasteriser
     #: The GymEnv.step body (examples/gym_env.py:83-126 of the reference) is step -> render_egocentric -> compute_collision / compute_offroad /
     #: compute_wrong_way.  The rasteriser is bound by the HBM write stream and the metrics are compute-light and do not read the image, so the
-    #: metrics that are asked for AFTER a render of the same state are enqueued on a second HIP stream that waits only for what preceded the
-    #: raster launch (an event, no host synchronisation) and is joined to the caller's stream before the result is handed out: they run
-    #: beside the rasteriser instead of behind it.  Same kernels, same inputs, same bits.  False: everything on the caller's stream.
-    overlap_infractions = True
+    #: metrics that are asked for AFTER a render of the same state can be enqueued on a second HIP stream that waits only for what preceded the
+    #: raster launch (an event, no host synchronisation) and is joined to the caller's stream before the result is handed out: they then run
+    #: beside the rasteriser instead of behind it.  Same kernels, same inputs, same bits.
+    #: OFF by default: the headline raster launch is persistent (its workgroups stay on their CUs until the last image is out), so the metric
+    #: kernels only get the slots they grab in the first microseconds, crawl there (off-road: 0.62 instead of 0.15 ms) and cost the launch more
+    #: than they save (B = 1024: 7.51 ms per step beside, 7.30 behind).  It pays where the metrics are expensive next to
+    #: the image -- small or low-resolution renders, agents that have strayed far from the map (the off-road query then walks grid rings).
+    overlap_infractions = False
     _side_streams: Dict[int, Any] = {}
 
     def _fork_sources(self):
