@@ -401,13 +401,27 @@ __device__ __forceinline__ float tri_d2(float px, float py, const GridEntry &e) 
     return inside ? 0.0f : dist;
 }
 
+// A point is served by a GROUP of OL consecutive lanes (all of them hold the same point); `sub` is the lane's place in its group.
+#ifndef TDS_OL
+#define TDS_OL 8
+#endif
+constexpr int OL = TDS_OL;        // lanes per corner (a power of two, <= 16: a wavefront holds whole agents)
+__device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+    for (int d = 1; d < OL; d <<= 1) v = fminf(v, __shfl_xor(v, d));
+    return v;
+}
+
 // min over all faces of tri_d2, found by walking grid rings outwards from the point's cell.  A face is listed in every
 // cell its bounding box touches, so its closest point lies in a listed cell whose box is at least as close as the face:
 // cells whose box is not closer than the best distance so far can be skipped, and the walk stops once a whole ring is.
+// The lanes of the group share the entries of a cell (entry i + sub of every round) and agree on the minimum after every cell; the minimum
+// over faces does not depend on the order in which they are looked at, so the result is that of a sequential walk, bit for bit.
 // `stop`: the caller only needs the exact minimum if it exceeds `stop` (F.threshold zeroes everything else), so the walk ends as soon
 // as the running minimum is <= stop.
-__device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, float py, float stop) {
-    float best = __builtin_inff();
+__device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, float py, float stop, int sub) {
+    const float inf = __builtin_inff();
+    float best = inf;                                        // the group's minimum so far: the same in all its lanes
     if (m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return best;
     // unclamped cell of the point (float -> int conversion saturates, keep it in a sane range first)
     float fx = fminf(fmaxf((px - m.ox) * m.inv_cell, -1.0e6f), 1.0e6f), fy = fminf(fmaxf((py - m.oy) * m.inv_cell, -1.0e6f), 1.0e6f);
@@ -417,24 +431,20 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
         float bx0 = m.ox + (float)x * m.cell, by0 = m.oy + (float)y * m.cell;
         float ddx = fmaxf(fmaxf(bx0 - px, px - (bx0 + m.cell)), 0.0f), ddy = fmaxf(fmaxf(by0 - py, py - (by0 + m.cell)), 0.0f);
         float cd = (ddx * ddx + ddy * ddy) * 0.998f - 1e-3f;
-        if (cd >= best) return;
-        int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
-        auto consider = [&](const GridEntry &ge) {
-            // the face cannot beat `best` if even its bounding box is farther (same safety shrink as for the cell)
+        if (cd >= best || best <= stop) return;
+        const int s = m.cell_start[y * m.nx + x], e = m.cell_start[y * m.nx + x + 1];
+        float mine = best;
+        for (int i = s + sub; i < e; i += OL) {
+            const GridEntry ge = m.entries[i];
+            // the face cannot beat the minimum if even its bounding box is farther (same safety shrink as for the cell)
             float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
             float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
             float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
-            if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) return;
+            if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= mine) continue;
             float d = tri_d2(px, py, ge);
-            best = (d < best) ? d : best;
-        };
-        // four entries in flight at a time: the walk is a chain of dependent loads otherwise
-        int i = s;
-        for (; i + 4 <= e && best > stop; i += 4) {
-            const GridEntry g0 = m.entries[i], g1 = m.entries[i + 1], g2 = m.entries[i + 2], g3 = m.entries[i + 3];
-            consider(g0); consider(g1); consider(g2); consider(g3);
+            mine = (d < mine) ? d : mine;                    // a NaN distance never becomes the minimum
         }
-        for (; i < e && best > stop; ++i) consider(m.entries[i]);
+        best = group_min(mine);
     };
     int k = max(max(0, max(-cx, cx - (m.nx - 1))), max(-cy, cy - (m.ny - 1)));
     for (;; ++k) {
@@ -457,48 +467,58 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
     return best;
 }
 
-// The same minimum from the candidate list of the point's cell (tds::NearView): one linear walk, four faces in flight, ended by the
-// first candidate whose lower bound is not below the running minimum.  Points outside the grid take the ring walk.
-__device__ __forceinline__ float nearest_face_d2_lists(const MapView &m, const tds::NearView &nv, float px, float py, float stop) {
-    if (nv.cand == nullptr || m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py)) return nearest_face_d2(m, px, py, stop);
-    const float fx = (px - nv.ox) * m.inv_cell, fy = (py - nv.oy) * m.inv_cell;
-    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny)) return nearest_face_d2(m, px, py, stop);
-    const int cx = tds::cell_coord(px, nv.ox, m.inv_cell), cy = tds::cell_coord(py, nv.oy, m.inv_cell);
-    if (cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny) return nearest_face_d2(m, px, py, stop);
-    const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
-    float best = __builtin_inff();
-    auto consider = [&](const tds::NearCand &c, const GridEntry &ge) {
-        if (c.lb >= best) return;
-        float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
-        float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
-        float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
-        if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) return;
-        float d = tri_d2(px, py, ge);
-        best = (d < best) ? d : best;
-    };
-    int i = s;
-    for (; i + 4 <= e && best > stop; i += 4) {
-        const tds::NearCand c0 = nv.cand[i], c1 = nv.cand[i + 1], c2 = nv.cand[i + 2], c3 = nv.cand[i + 3];
-        if (c0.lb >= best) return best;                         // sorted by lb: nothing further can be nearer
-        const GridEntry g0 = nv.faces[c0.face], g1 = nv.faces[c1.face], g2 = nv.faces[c2.face], g3 = nv.faces[c3.face];
-        consider(c0, g0); consider(c1, g1); consider(c2, g2); consider(c3, g3);
+// The same minimum from the candidate list of the point's cell (tds::NearView), walked by OL lanes together: candidate i + lane of every
+// round, the group's running minimum by three xor-shuffles, ended by the first round whose first candidate has a lower bound that is not
+// below it (the list is sorted by lower bound) or as soon as the minimum is <= stop.  The minimum over faces does not depend on the order
+// in which they are looked at, so the result is the sequential walk's, bit for bit.  One lane per point (the first version) was a chain of
+// dependent loads, candidate -> face -> next candidates, a few to a few dozen rounds long: 0.148 ms at B = 1024 x 64 however little
+// arithmetic it is; eight lanes per point: one or two rounds, 0.09 ms.  Points outside the grid take the ring walk.
+__device__ __forceinline__ float nearest_face_d2_lists(const MapView &m, const tds::NearView &nv, float px, float py, float stop, int sub) {
+    const float inf = __builtin_inff();
+    bool ring = nv.cand == nullptr || m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py);
+    int cx = 0, cy = 0;
+    if (!ring) {
+        const float fx = (px - nv.ox) * m.inv_cell, fy = (py - nv.oy) * m.inv_cell;
+        ring = !(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny);
+        if (!ring) {
+            cx = tds::cell_coord(px, nv.ox, m.inv_cell); cy = tds::cell_coord(py, nv.oy, m.inv_cell);
+            ring = cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny;
+        }
     }
-    for (; i < e && best > stop; ++i) {
-        const tds::NearCand c0 = nv.cand[i];
-        if (c0.lb >= best) break;
-        consider(c0, nv.faces[c0.face]);
+    if (ring) return nearest_face_d2(m, px, py, stop, sub);                              // (uniform within the group: all its lanes hold the same point)
+    const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
+    float best = inf;                                                                 // the group's minimum so far, the same in all its lanes
+    for (int i = s; i < e && best > stop; i += OL) {
+        const int j = i + sub;
+        tds::NearCand c;
+        c.face = 0; c.lb = inf;
+        if (j < e) c = nv.cand[j];
+        const float lb0 = __shfl(c.lb, (threadIdx.x & 63 & ~(OL - 1)));                // the round's first candidate
+        if (lb0 >= best) break;                                                       // sorted by lb: nothing further can be nearer
+        float d = inf;
+        if (c.lb < best) {
+            const GridEntry ge = nv.faces[c.face];
+            const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
+            const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
+            const float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
+            if (!((ex * ex + ey * ey) * 0.998f - 1e-3f >= best)) {
+                const float t = tri_d2(px, py, ge);
+                d = (t < inf) ? t : inf;                                              // a NaN distance never becomes the minimum (as `d < best ? d : best`)
+            }
+        }
+        best = fminf(best, group_min(d));
     }
     return best;
 }
 
-// one thread per agent corner (4 consecutive lanes = one agent)
+// OL lanes per agent corner, 4 consecutive groups = one agent
 __global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, tds::NearView nv, const float4 *__restrict__ state, const float2 *__restrict__ lenwid,
                                                          const float2 *__restrict__ sc, const uint8_t *__restrict__ present,
                                                          float *__restrict__ out, int64_t n, float threshold, const MapView *__restrict__ views,
                                                          const tds::NearView *__restrict__ nears, const int32_t *__restrict__ scene_map, int agents_per_scene) {
-    int64_t t = (int64_t)blockIdx.x * OBLOCK + threadIdx.x;
-    int64_t a = t >> 2;
-    int k = (int)(t & 3);
+    const int64_t t = (int64_t)blockIdx.x * OBLOCK + threadIdx.x;
+    const int64_t a = t / (4 * OL);
+    const int k = (int)((t / OL) & 3), sub = (int)(t & (OL - 1));
     float v = 0.0f;
     if (a < n && views != nullptr) {                                                // one map per scene (tds_offroad_multi_f32)
         const int im = scene_map[a / agents_per_scene];
@@ -512,14 +532,14 @@ __global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, tds::NearVie
         float x4 = sx * lw.x, y4 = sy * lw.y;
         float px = (x4 * scv.y + y4 * (-scv.x)) + s.x;
         float py = (x4 * scv.x + y4 * scv.y) + s.y;
-        float d = nearest_face_d2_lists(m, nv, px, py, fmaxf(threshold, 0.0f));
+        float d = nearest_face_d2_lists(m, nv, px, py, fmaxf(threshold, 0.0f), sub);
         d = (d != d) ? 0.0f : d;                                     // nan_to_num :171
         if (__builtin_isinf(d)) d = 3.4028234663852886e38f;
         v = (d > threshold) ? d : 0.0f;                              // F.threshold(d, thr, 0) :172
     }
     // sum of the 4 corners in order (infractions.py:228)
-    float v1 = __shfl_down(v, 1), v2 = __shfl_down(v, 2), v3 = __shfl_down(v, 3);
-    if (a < n && k == 0) {
+    float v1 = __shfl_down(v, OL), v2 = __shfl_down(v, 2 * OL), v3 = __shfl_down(v, 3 * OL);
+    if (a < n && k == 0 && sub == 0) {
         float tot = ((v + v1) + v2) + v3;
         if (present) tot = tot * (present[a] ? 1.0f : 0.0f);         // simulator.py:1044
         out[a] = tot;
@@ -531,10 +551,10 @@ __global__ void __launch_bounds__(OBLOCK) offroad_kernel(MapView m, tds::NearVie
 TDS_EXPORT int tds_offroad_f32(const tds_map_t *map, const float *state, const float *lenwid, const float *sc, const uint8_t *present,
                                float *out, int64_t n_agents, float threshold, void *stream) {
     TDS_CHECK_ARG(map, "tds_offroad_f32: null map");
-    TDS_CHECK_ARG(n_agents >= 0 && n_agents < ((int64_t)1 << 36), "tds_offroad_f32: bad agent count");
+    TDS_CHECK_ARG(n_agents >= 0 && n_agents < ((int64_t)1 << 34), "tds_offroad_f32: bad agent count");
     if (n_agents == 0) return TDS_OK;
     TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_f32: null pointer");
-    int64_t threads = n_agents * 4;
+    int64_t threads = n_agents * 4 * OL;
     hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, map->view, map->near,
                        (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents, threshold,
                        (const MapView *)nullptr, (const tds::NearView *)nullptr, (const int32_t *)nullptr, 1);
@@ -546,10 +566,10 @@ TDS_EXPORT int tds_offroad_multi_f32(const tds_mapset_t *set, const int32_t *sce
                                      const float *sc, const uint8_t *present, float *out, int64_t n_agents, float threshold, void *stream) {
     TDS_CHECK_ARG(set && set->n > 0 && scene_map, "tds_offroad_multi_f32: null map set or scene index array");
     TDS_CHECK_ARG(agents_per_scene > 0 && agents_per_scene < (1 << 30), "tds_offroad_multi_f32: bad number of agents per scene");
-    TDS_CHECK_ARG(n_agents >= 0 && n_agents < ((int64_t)1 << 36), "tds_offroad_multi_f32: bad agent count");
+    TDS_CHECK_ARG(n_agents >= 0 && n_agents < ((int64_t)1 << 34), "tds_offroad_multi_f32: bad agent count");
     if (n_agents == 0) return TDS_OK;
     TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_multi_f32: null pointer");
-    int64_t threads = n_agents * 4;
+    int64_t threads = n_agents * 4 * OL;
     hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, MapView{},
                        tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents,
                        threshold, (const MapView *)set->d_views, (const tds::NearView *)set->d_near, scene_map, (int)agents_per_scene);
