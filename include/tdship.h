@@ -317,9 +317,12 @@ int tds_lanelet_directions_f64(const tds_laneset_t *set, const int32_t *scene_ma
 int tds_raster_set_strip_width(int tw);
 /* waves per workgroup of the bit-plane raster kernel (4 or 8) */
 int tds_raster_set_bits_waves(int n);
+/* K3r, the list rasteriser of the split bit-plane path: LDS budget per workgroup in KiB (sets the strip width) */
+int tds_raster_set_list_lds(int lds_kb);
 /* ablation switches of K3: 1 no static map, 2 no actors, 4 no store, 8 no outline edges, 16 no scan conversion, 32 no binned path,
  * 64 no bit planes, 128 work counters on, 512 no per-face set-up (nothing is painted), 1024 walk the grid but project nothing,
- * 2048 the 170-VGPR instantiation everywhere, 4096 the work counters hold per-XCD finish [0..7] and ~start [8..15] wall clocks (100 MHz) */
+ * 2048 the 170-VGPR instantiation everywhere, 4096 the work counters hold per-XCD finish [0..7] and ~start [8..15] wall clocks (100 MHz),
+ * 8192 never the split form (K3s + K3r), 16384 the split form wherever a workspace allows it */
 int tds_raster_set_debug(int flags);
 /* read and reset the 16 work counters of the bit-plane kernel */
 int tds_raster_get_stats(unsigned long long *out16);

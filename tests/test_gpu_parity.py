@@ -487,6 +487,46 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town, testing_lib):
         assert ref.any()
 
 
+def test_k3_split_form_equals_the_fused_kernel_and_the_oracle(ops, oracle, town, testing_lib):
+    """Below 160 x 160 (float32) / 224 x 224 (uint8) the bit-plane path runs as two kernels -- K3s lists every camera's faces, K3r rasterises
+    the lists -- with a third launch of the fused kernel over the cameras whose list overflowed.  Every form must paint the same pixels:
+    forced either way (debug flags 8192 / 16384 of the testing build), cut into narrow strips (LDS budget), with a workspace so small that
+    most lists overflow."""
+    g = load_golden('g45_mesh_preraster.npz')
+    st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']
+    B, A = st.shape[:2]
+    smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
+    cam_sc = g['g5_town01_128_cam_sc']
+    real_ws = ops._raster_workspace
+    try:
+        for res, fov in ((64, 35.0), (128, 35.0), (192, 60.0), (256, 35.0), (320, 80.0)):
+            ref = None
+            for dtype in (torch.float32, torch.uint8):
+                for flags, lds_kb, small_ws in ((8192, 40, False), (16384, 40, False), (16384, 16, False), (16384, 52, False), (16384, 40, True)):
+                    testing_lib.tds_raster_set_debug(flags)
+                    testing_lib.tds_raster_set_list_lds(lds_kb)
+                    ops._workspaces.clear()
+                    if small_ws:
+                        # room for 300 faces per camera: most Town01 views hold more, their cameras go to the fused kernel
+                        n_img = B * A
+                        nbytes = ((n_img + 1) * 4 + 255) // 256 * 256 + (n_img * 4 + 255) // 256 * 256 + n_img * 300 * 16
+                        ops._raster_workspace = lambda d, n, r: torch.empty(nbytes, dtype=torch.uint8, device=d)
+                    try:
+                        img, r = render_both(ops, oracle, smap, static, st, sz, mask, st[..., :2].copy(), cam_sc, fov, res, dtype)
+                    finally:
+                        ops._raster_workspace = real_ws
+                    ref = r if ref is None else ref
+                    bad = img.astype(np.float32) != ref
+                    assert not bad.any(), f'res {res} {dtype} flags {flags} lds {lds_kb} small workspace {small_ws}: {bad.sum()} values differ'
+            assert ref.any()
+    finally:
+        testing_lib.tds_raster_set_debug(0)
+        testing_lib.tds_raster_set_list_lds(40)
+        ops._workspaces.clear()
+
+
 def test_k3_u8_mode_equals_f32(ops, oracle, town):
     g = load_golden('g45_mesh_preraster.npz')
     st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']

@@ -841,6 +841,51 @@ __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, cons
     return false;
 }
 
+// entry number v of the list that the entry ranges of the current block of grid rows form -> entry index | its grid row within the block << 25
+// (-1: the list is shorter).  A lane finds the row by bisection over the rows' first entry numbers (st.rex), see scan_fetch.
+__device__ __forceinline__ int scan_locate(const ScanState &st, int nblk, int v) {
+    int r = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+        if (step < nblk) {                                // wave-uniform
+            const int cand = r + step;
+            const int ex = __shfl(st.rex, cand & 63);
+            if (cand < nblk && ex <= v) r = cand;
+        }
+    }
+    const int i = __shfl(st.rbase, r) + v;
+    return v < st.rtotal ? (i | (r << 25)) : -1;
+}
+
+// One entry of the static map's grid (ci = entry index | its grid row within the current block of rows << 25, -1: none; u0, u1 = the
+// entry's 32 bytes): the owner rule, then projection and trim.  All lanes take part (shuffles).
+__device__ __forceinline__ void scan_candidate(const ScanState &st, const CommonArgs &c, const Camera &cam, int X0, int TWw, int ci, const uint4 &u0,
+                                               const uint4 &u1, bool &acc, uint32_t &key, int (&px)[3], int (&py)[3], unsigned &edges) {
+    const int i = ci & 0x1ffffff, r = ci >= 0 ? ci >> 25 : 0;
+    // what the owner rule needs to know about the entry's grid row (still the rows of the chunk's block: blocks advance in scan_fetch only)
+    const int first_end = __shfl(st.rfe, r);                                       // end of the row's first scanned cell
+    const int above = __shfl(st.rw, (r + 63) & 63);
+    const int pw = r > 0 ? above : st.prev_rw;                                     // cell range of the row above
+    const int plo = pw & 0xffff, phi = pw >> 16;
+    const bool top = st.row + r == 0;
+    if (ci >= 0) {
+        const unsigned own = u1.w;              // see GridEntry::own
+        // Exactly one of the scanned cells emits the face: in its grid row the first scanned cell of the face's bounding
+        // box; among the rows the first one where the bounding box meets the scanned cells (the row above has none).
+        const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
+        const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
+        const bool none_above = !(own & (1u << 27)) || top || bx1 < plo || bx0 > phi;
+        if (first_in_row && none_above && !(TDS_DBG(c.debug) & 1024)) {      // 1024: ablation, walk the grid but project nothing
+            unsigned ins = 0;
+            float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
+            float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
+            key = u1.z;
+            acc = trim_project(cam, c.scale, c.res, X0, TWw, sxv, syv, px, py, ins, c.no_trim);
+            edges = edge_mask(own >> 29, ins);
+        }
+    }
+}
+
 // one producer step: at most one candidate face per lane; returns false when the producer is exhausted
 template <int NW = RWAVES, typename SA = SceneArgsEx>      // SceneArgsEx: the per-camera triangle phase is compiled in
 __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane,
@@ -929,32 +974,8 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
     // that their latency is hidden behind the rasterisation of the queue.
     if (!st.have) st.have = scan_fetch<NW>(st, m, c, cam, lane, X0, TWw);
     if (!st.have) return false;
-    {
-        const int ci = st.cur_i, i = ci & 0x1ffffff, r = ci >= 0 ? ci >> 25 : 0;
-        const uint4 u0 = st.pu0, u1 = st.pu1;
-        // what the owner rule needs to know about the entry's grid row (still the rows of the chunk's block: blocks advance in scan_fetch only)
-        const int first_end = __shfl(st.rfe, r);                                       // end of the row's first scanned cell
-        const int above = __shfl(st.rw, (r + 63) & 63);
-        const int pw = r > 0 ? above : st.prev_rw;                                     // cell range of the row above
-        const int plo = pw & 0xffff, phi = pw >> 16;
-        const bool top = st.row + r == 0;
-        if (ci >= 0) {
-            const unsigned own = u1.w;              // see GridEntry::own
-            // Exactly one of the scanned cells emits the face: in its grid row the first scanned cell of the face's bounding
-            // box; among the rows the first one where the bounding box meets the scanned cells (the row above has none).
-            const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
-            const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
-            const bool none_above = !(own & (1u << 27)) || top || bx1 < plo || bx0 > phi;
-            if (first_in_row && none_above && !(TDS_DBG(c.debug) & 1024)) {      // 1024: ablation, walk the grid but project nothing
-                float sxv[3] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx)};
-                float syv[3] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy)};
-                key = u1.z;
-                acc = trim_project(cam, c.scale, res, X0, TWw, sxv, syv, px, py, ins, c.no_trim);
-                edges = edge_mask(own >> 29, ins);
-            }
-        }
-        st.have = scan_fetch<NW>(st, m, c, cam, lane, X0, TWw);
-    }
+    scan_candidate(st, c, cam, X0, TWw, st.cur_i, st.pu0, st.pu1, acc, key, px, py, edges);
+    st.have = scan_fetch<NW>(st, m, c, cam, lane, X0, TWw);
     return true;
 }
 
@@ -1666,16 +1687,23 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     wave_sync();
 }
 
-__device__ __forceinline__ void drain_bits(BitCtx &w, const uint32_t *keys, int K, bool acc, uint32_t key, unsigned edges, const int (&px)[3],
-                                           const int (&py)[3], bool more) {
-    // plane of the key = its position in the ascending table
+// plane of a key = its position in the ascending table (in LDS: broadcast reads)
+__device__ __forceinline__ int key_plane(const uint32_t *keys, int K, uint32_t key) {
     int k = 0;
 #pragma unroll 1
-    for (int i = 0; i < K; ++i) k += (keys[i] < key) ? 1 : 0;             // keys: ascending table in LDS (broadcast reads)
-    bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
-    if (__builtin_expect(__ballot(big) != 0, 0)) {
-        if (big) fill_generic_bits(w.planes + (size_t)k * w.H * w.wpr, w.H, w.W, w.X0, w.TWp, w.wpr, px[0], py[0], px[1], py[1], px[2], py[2]);
-        acc = acc && !big;
+    for (int i = 0; i < K; ++i) k += (keys[i] < key) ? 1 : 0;
+    return k;
+}
+
+// BIG: faces outside the packed coordinate range may come along (they take the exact sequential path); the list kernel never sees one
+template <bool BIG = true>
+__device__ __forceinline__ void drain_bits(BitCtx &w, int k, bool acc, unsigned edges, const int (&px)[3], const int (&py)[3], bool more) {
+    if constexpr (BIG) {
+        bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
+        if (__builtin_expect(__ballot(big) != 0, 0)) {
+            if (big) fill_generic_bits(w.planes + (size_t)k * w.H * w.wpr, w.H, w.W, w.X0, w.TWp, w.wpr, px[0], py[0], px[1], py[1], px[2], py[2]);
+            acc = acc && !big;
+        }
     }
     unsigned long long pending = __ballot(acc);
     for (;;) {
@@ -1835,7 +1863,13 @@ constexpr int BITS_FIXED_DW = 20;             // [0..14] ascending key table, [1
 // one thread: take the next item -- own queue first, then the others in cyclic order -- and leave it in state[0] (-1: nothing left);
 // state[1] = queues of that order already found empty by this workgroup.  Everything a workgroup carries from item to item lives in
 // LDS: the kernel has no register to spare
-__device__ __noinline__ void claim_work(uint32_t *queue, int nblk, uint32_t *state) {
+__device__ __noinline__ void claim_work(uint32_t *queue, int nblk, uint32_t *state, const uint32_t *only, int strips) {
+    if (only != nullptr) {
+        // the launch that follows the split form: only the cameras K3s marked (only[0] of them, listed from only[1]), one queue
+        const uint32_t j = atomicAdd(&queue[0], 1u), n = only[0] * (uint32_t)strips;
+        state[0] = j < n ? only[1 + j / (uint32_t)strips] * (uint32_t)strips + j % (uint32_t)strips : 0xffffffffu;
+        return;
+    }
     // which XCD this workgroup really runs on: the XCC_ID hardware register (id 20, bits 3:0 on gfx950), not blockIdx.x & 7 -- workgroups
     // are dealt round-robin to the XCDs, but where the round starts is the dispatcher's business once another stream's kernel is in flight
     const int nq = (nblk & 7) == 0 ? 8 : 1, per = nq == 8 ? nblk >> 3 : nblk;
@@ -1850,17 +1884,11 @@ __device__ __noinline__ void claim_work(uint32_t *queue, int nblk, uint32_t *sta
     state[0] = (uint32_t)item;
 }
 
-// one workgroup per (camera, strip) at a time; for the usual resolutions one strip is the whole image.  NB = bits of a key index (K < 2^NB).
-// EMIT: also store the key-index slices for the backward pass (a separate instantiation: the plain kernel sits exactly at its VGPR limit)
-// MINWG: workgroups per CU the register budget is cut for.  3 (170 VGPRs) is what the LDS of a 256 x 256 camera with five keys allows
-// (51.8 KB each).  Where the planes are small enough for four workgroups per CU (40 KB each: 128 x 128 images, scenes of three keys) the
-// instantiation with 128 VGPRs is used: it spills 160 bytes per lane and is still 13 % faster (128 x 128: 4.47 -> 3.89 ms) -- at three
-// waves per SIMD the kernel waits for its own latencies; five or six workgroups per CU (96 / 80 VGPRs) lose to their spills.
 // The instantiations that run three workgroups per CU are persistent (work queues above; also 4 % on the uint8 mode: no gap between
 // the end of one workgroup and the start of the next on its slot).  The 128-VGPR instantiations are not: the loop over the items costs
 // them another 64 bytes of spills per lane, which outweighs it (128 x 128: 3.95 -> 4.17 ms); they take ONE item, by blockIdx.
 template <int BWAVES, int NB, typename OutT, typename SA, bool EMIT = false, int MINWG = 3>
-__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp, uint32_t *queue) {
+__global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp, uint32_t *queue, const uint32_t *only) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     constexpr bool PERSIST = BWAVES == 4 && MINWG == 3;
@@ -1874,7 +1902,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
     uint32_t *planes = lkeys + BITS_FIXED_DW + BWAVES * BITS_WAVE_LDS_DW;
     // the launch's work items: (camera, strip) pairs, as eight queues of consecutive items when they divide evenly, else as one
     if constexpr (PERSIST) {
-        if (tid == 0) { lkeys[17] = 0; claim_work(queue, (int)(c.n_img * c.strips), lkeys + 16); }
+        if (tid == 0) { lkeys[17] = 0; claim_work(queue, (int)(c.n_img * c.strips), lkeys + 16, only, c.strips); }
     }
 #ifdef TDS_TESTING
     // debug flag 4096: when does each XCD start and finish its share of the launch?  (wall clock, 100 MHz; blocks are dealt round-robin to the XCDs)
@@ -1950,11 +1978,11 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
             int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
             unsigned edges;
             const bool more = scan_step<BWAVES, SA>(st, a, ci, cam, img, lane, wave, X0, TWp, acc, key, px, py, edges);
-            drain_bits(w, lkeys, K, acc, key, edges, px, py, more);
+            drain_bits(w, key_plane(lkeys, K, key), acc, edges, px, py, more);
             if (!more) break;
         }
         // the next item is taken now (every wave read the current one two barriers ago): the round trip of the atomic hides behind the stream-out
-        if constexpr (PERSIST) { if (tid == 0) claim_work(queue, (int)(c.n_img * c.strips), lkeys + 16); }
+        if constexpr (PERSIST) { if (tid == 0) claim_work(queue, (int)(c.n_img * c.strips), lkeys + 16, only, c.strips); }
         __syncthreads();
         if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(0);
         if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, EMIT>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, c.slices);
@@ -1965,6 +1993,182 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
 #endif
 }
 
+// =========================================================================================================
+// The split form of the bit-plane path.  Wherever the launch is bound by instruction issue and latency rather than by the write stream
+// (uint8 output, resolutions below 256 x 256) the fused kernel above pays for carrying the grid scan -- its state, the camera, the trim
+// test, the faces that wait for room in the queue -- through the rasterisation: registers the row loops then spill.  Here
+//   K3s  scan_faces_kernel        one wavefront per camera walks the grid and the actors ONCE and writes the accepted faces of the whole image,
+//                                 projected and classified (plane index | outline edges to draw, three packed vertices: 16 bytes), to a
+//                                 list in the caller's workspace;
+//   K3r  raster_list_bits_kernel  one workgroup per (camera, strip) reads the list and rasterises: no scan state, and strips no longer
+//                                 cost a grid scan each, so the strip width is chosen for occupancy alone.
+// A camera whose list overflowed (more than `caps` faces) or that met a face outside the packed coordinate range is marked in `counts`
+// and rendered by the fused kernel afterwards (a launch over the marked cameras only), so the result never depends on the capacity.
+// =========================================================================================================
+constexpr int SCAN_WAVES = 4;                 // cameras per workgroup of K3s
+constexpr int SCAN_DEPTH = 4;                 // chunks of 64 grid entries whose loads K3s keeps in flight
+constexpr uint32_t LIST_POISON = 0xffffffffu;
+
+// (cut for four waves per SIMD, 128 VGPRs: 0.97 ms at B = 1024 x 64 against 1.18 at three and 2.4 at five)
+template <typename SA>
+__global__ void __launch_bounds__(SCAN_WAVES * 64, 4) scan_faces_kernel(SA a, CommonArgs c, KeyTable kt, uint32_t *__restrict__ counts, uint4 *__restrict__ lists,
+                                                                     int caps, uint32_t *__restrict__ poisoned) {
+    __shared__ uint32_t lkeys[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 16) {
+        uint32_t kv = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kv = ((int)threadIdx.x == i) ? kt.key[i] : kv;
+        lkeys[threadIdx.x] = kv;
+    }
+    __syncthreads();
+    const int64_t img = (int64_t)blockIdx.x * SCAN_WAVES + wv;
+    if (img >= c.n_img) return;                                        // wave-uniform; no further barriers
+    const int res = c.res, K = kt.n;
+    Camera cam;
+    {
+        float2 xy = c.cam_xy[img], sc = c.cam_sc[img];
+        cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
+        make_polygon(cam, c.scale, res);
+    }
+    uint4 *mine = lists + (size_t)img * caps;
+    ScanState st;
+    scan_init(st, a, c, cam, img, lane, 0, 0, res);
+    int count = 0;
+    bool poison = false;
+    auto emit = [&](bool acc, uint32_t key, const int (&px)[3], const int (&py)[3], unsigned edges) {
+        const bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
+        poison = poison || (__ballot(big) != 0);
+        const unsigned long long bm = __ballot(acc);
+        if (bm != 0) {
+            const int k = key_plane(lkeys, K, key);
+            const int slot = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+            if (acc && slot < caps) mine[slot] = make_uint4((uint32_t)k | (edges << 4), pack_xy(px[0], py[0]), pack_xy(px[1], py[1]), pack_xy(px[2], py[2]));
+            count += __popcll(bm);
+        }
+    };
+    // actors, the masked-agent dot, per-camera triangles: the producer steps of the fused kernel, up to the static map
+    while (st.phase != 2) {
+        bool acc;
+        uint32_t key;
+        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+        unsigned edges;
+        (void)scan_step<1, SA>(st, a, c, cam, img, lane, 0, 0, res, acc, key, px, py, edges);
+        emit(acc, key, px, py, edges);
+    }
+    // The static map.  With nothing to rasterise between two chunks of entries the walk would wait for every load (1.2 us each, 28 chunks
+    // per camera): the entries are taken SCAN_DEPTH chunks at a time, all their loads in flight together.
+    if (!(TDS_DBG(c.debug) & 1)) {
+        const MapView &m = st.map;
+        while (st.row < st.nrows) {
+            const int nblk = min(64, st.nrows - st.row);
+            for (int base = 0; base < st.rtotal; base += 64 * SCAN_DEPTH) {
+                int ci[SCAN_DEPTH];
+                uint4 u0[SCAN_DEPTH], u1[SCAN_DEPTH];
+#pragma unroll
+                for (int u = 0; u < SCAN_DEPTH; ++u) {
+                    ci[u] = (base + 64 * u < st.rtotal) ? scan_locate(st, nblk, base + 64 * u + lane) : -1;
+                    u0[u] = u1[u] = make_uint4(0, 0, 0, 0);
+                    if (ci[u] >= 0) {
+                        const uint4 *ep = (const uint4 *)(m.entries + (ci[u] & 0x1ffffff));
+                        u0[u] = ep[0]; u1[u] = ep[1];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SCAN_DEPTH; ++u) {
+                    if (base + 64 * u >= st.rtotal) break;                   // wave-uniform
+                    bool acc = false;
+                    uint32_t key = 0;
+                    int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+                    unsigned edges = 7u;
+                    scan_candidate(st, c, cam, 0, res, ci[u], u0[u], u1[u], acc, key, px, py, edges);
+                    emit(acc, key, px, py, edges);
+                }
+            }
+            st.row += 64;
+            if (st.row < st.nrows) {                                         // more than 64 grid rows: the next block
+                st.prev_rw = __builtin_amdgcn_readlane(st.rw, 63);
+                scan_load_rows(st, m, c, cam, lane, 0, res, st.row);
+            }
+        }
+    }
+    poison = poison || count > caps;
+    if (lane == 0) {
+        counts[img] = poison ? LIST_POISON : (uint32_t)count;
+        if (poison) poisoned[1 + atomicAdd(poisoned, 1u)] = (uint32_t)img;          // poisoned[0] = how many, then which
+    }
+}
+
+// (60 VGPRs with uint8 output, 72 - 79 with float32: LDS, not registers, sets how many workgroups share a CU)
+template <int NB, typename OutT>
+__global__ void __launch_bounds__(256) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
+                                                                      const uint4 *__restrict__ lists, int caps) {
+    using E = typename PairTab<NB, OutT>::E;
+    constexpr int BWAVES = 4, BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
+    const int plane_dw = K * H * wpr;
+    E *tab = (E *)smem;
+    uint32_t *lkeys = smem + pair_tab_dw<NB, OutT>();
+    uint32_t *planes = lkeys + BITS_FIXED_DW + BWAVES * BITS_WAVE_LDS_DW;
+    int64_t img;
+    int strip;
+    block_to_image(c.n_img * c.strips, c.strips, img, strip);
+    const uint32_t n = counts[img];
+    if (n == LIST_POISON) return;                                      // uniform over the workgroup: the fused kernel renders this camera
+    const int X0 = strip * TWp;
+    for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
+    if (tid < 16) {
+        uint32_t kv = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kv = (tid == i) ? kt.key[i] : kv;
+        lkeys[tid] = tid == 15 ? (uint32_t)BWAVES : kv;                    // entry 15: the next chunk of the list
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * P; e += BBLOCK) {
+        const int ch = e / P, pr = e - ch * P, ilo = pr & ((1 << NB) - 1), ihi = pr >> NB;
+        const uint32_t klo = (ilo >= 1 && ilo <= K) ? lkeys[ilo - 1] : 0u, khi = (ihi >= 1 && ihi <= K) ? lkeys[ihi - 1] : 0u;
+        const int sh = 16 - 8 * ch;
+        const uint32_t vlo = (klo >> sh) & 255u, vhi = (khi >> sh) & 255u;
+        if constexpr (sizeof(OutT) == 4) tab[e] = make_float2((float)vlo, (float)vhi);
+        else tab[e] = vlo | (vhi << 8);
+    }
+    BitCtx w;
+    w.planes = planes;
+    w.q = lkeys + BITS_FIXED_DW + wave * BITS_WAVE_LDS_DW;
+    w.slots = w.q + Q_DW;
+    w.eq = w.slots + 64;
+    w.eq_head = 0; w.eq_count = 0;
+    w.slots[lane] = 0;
+    w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug; w.gen = 0;
+    __syncthreads();
+    const uint4 *lst = lists + (size_t)img * caps;
+    const int Xhi = min(W, X0 + TWp) - 1;
+    int chunk = __builtin_amdgcn_readfirstlane(wave);                  // chunks of 64 faces, dealt to the waves as they ask
+    for (;;) {
+        const uint32_t i0 = (uint32_t)chunk * 64u;
+        const bool more = i0 < n;
+        bool acc = more && (i0 + (uint32_t)lane < n);
+        uint4 e = make_uint4(0, 0, 0, 0);
+        if (acc) e = lst[i0 + lane];
+        if (more) {
+            unsigned nxt = 0;
+            if (lane == 0) nxt = atomicAdd(lkeys + 15, 1u);
+            chunk = __builtin_amdgcn_readfirstlane((int)nxt);
+        }
+        const int px[3] = {unpack_x(e.y), unpack_x(e.z), unpack_x(e.w)}, py[3] = {unpack_y(e.y), unpack_y(e.z), unpack_y(e.w)};
+        if (c.strips > 1) {                                            // faces that miss this strip are not queued
+            const int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
+            acc = acc && !(xmax < X0 || xmin > Xhi);
+        }
+        drain_bits<false>(w, (int)(e.x & 15u), acc, (e.x >> 4) & 7u, px, py, more);
+        if (!more) break;
+    }
+    __syncthreads();
+    if (!(TDS_DBG(c.debug) & 4)) write_out_bits<BBLOCK, NB, OutT, false>(planes, tab, K, (OutT *)c.out, img, res, X0, TWp, wpr, tid, nullptr);
+}
+
 inline int bits_index_bits(int K) { return K <= 3 ? 2 : (K <= 7 ? 3 : 4); }
 inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) {
     size_t plane_dw = ((size_t)K * res * (twp / 32) + 3) & ~(size_t)3;
@@ -1973,6 +2177,7 @@ inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) 
     return (plane_dw + tab_dw + BITS_FIXED_DW + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
 }
 int g_bits_waves = 4;
+int g_list_lds_kb = 40;          // K3r picks the widest strip whose workgroup needs at most this much LDS (testing hook)
 
 // The work queues of a persistent bit-plane launch: 8 counters (64 bytes) that must be zero when the kernel starts.  A launch takes the
 // next slot of a small per-device pool and clears it in stream order right before the kernel; SLOTS launches can be in flight before a
@@ -2095,6 +2300,13 @@ TDS_EXPORT int tds_raster_get_stats(unsigned long long *out16) {
     return TDS_OK;
 }
 
+// K3r (the list rasteriser of the split bit-plane path): the LDS a workgroup may take in KiB, which sets the strip width
+TDS_EXPORT int tds_raster_set_list_lds(int lds_kb) {
+    TDS_CHECK_ARG(lds_kb >= 16 && lds_kb <= 150, "tds_raster_set_list_lds: 16..150 KiB");
+    g_list_lds_kb = lds_kb;
+    return TDS_OK;
+}
+
 // ablation switches, see CommonArgs::debug
 TDS_EXPORT int tds_raster_set_debug(int flags) {
     g_debug = flags;
@@ -2133,6 +2345,7 @@ static int common_checks(const char *fn, int64_t n_img, int res, int out_mode, c
 
 namespace {
 constexpr int DEFAULT_CAPS = 512;         // faces per strip list that the recommended workspace provides
+constexpr int LIST_CAPS = 2048;           // faces per camera list of the split bit-plane path that the recommended workspace provides
 inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
     return n_img * strips * ((int64_t)caps * (int64_t)sizeof(uint4) + (int64_t)sizeof(uint32_t));
 }
@@ -2150,8 +2363,10 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
     TDS_CHECK_ARG(res > 0 && res <= 4096 && n_img >= 0, "tds_raster_scene_workspace_bytes: bad arguments");
     int tw = (g_force_tw && g_force_tw <= 64) ? g_force_tw : pick_tw(res);
     *bytes = 0;
-    if (tw == 0 || (res + tw - 1) / tw > MAX_STRIPS) return TDS_OK;
-    *bytes = ws_bytes_for(n_img, (res + tw - 1) / tw, DEFAULT_CAPS);
+    if (tw != 0 && (res + tw - 1) / tw <= MAX_STRIPS) *bytes = ws_bytes_for(n_img, (res + tw - 1) / tw, DEFAULT_CAPS);
+    // the split bit-plane path: a marker list, a count and a list of LIST_CAPS faces (16 bytes each) per camera
+    const int64_t lists = (((n_img + 1) * 4 + 255) & ~(int64_t)255) + ((n_img * 4 + 255) & ~(int64_t)255) + n_img * LIST_CAPS * 16;
+    if (lists > *bytes) *bytes = lists;
     return TDS_OK;
 }
 
@@ -2263,24 +2478,71 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                 cb.slices = want_slices ? aux->index_slices : nullptr;
                 if (aux) { aux->n_keys = kt.n; aux->index_bits = bits_index_bits(kt.n); for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
                 const int nb = bits_index_bits(kt.n);
-                const bool four_per_cu = lds <= 40 * 1024 && !(TDS_DBG(g_debug) & 2048);      // see MINWG (2048: ablation, the 170-VGPR kernel)
+                bool four_per_cu = lds <= 40 * 1024 && !(TDS_DBG(g_debug) & 2048);      // see MINWG (2048: ablation, the 170-VGPR kernel)
+                // ---- the split form (K3s + K3r, above) where the launch is not bound by the write stream: uint8 output, resolutions below 256 ----
+                const uint32_t *only = nullptr;
+                {
+                    const bool f32 = out_mode == TDS_OUT_F32;
+                    // measured at B = 1024 x 64 (fused / split, ms): float32 96 x 96 3.89 / 3.17, 128 3.95 / 3.60, 160 4.33 / 4.79; uint8 128 4.03 / 3.04,
+                    // 192 4.53 / 4.34, 256 5.3 / 5.9 -- from there on the fused launch hides the scan behind its write stream or its row loops
+                    bool split = !want_slices && nwv == 4 && workspace != nullptr && res <= (f32 ? 144 : 208);
+                    if (TDS_DBG(g_debug) & 8192) split = false;                              // testing: the fused kernel everywhere
+                    if (TDS_DBG(g_debug) & 16384) split = !want_slices && nwv == 4 && workspace != nullptr;      // testing: the split form everywhere
+                    const size_t off_counts = (((size_t)n_img + 1) * 4 + 255) & ~(size_t)255;
+                    const size_t off_lists = (off_counts + (size_t)n_img * 4 + 255) & ~(size_t)255;
+                    int64_t caps = split && (size_t)workspace_bytes > off_lists ? ((int64_t)workspace_bytes - (int64_t)off_lists) / (n_img * 16) : 0;
+                    if (caps > 8192) caps = 8192;
+                    if (split && caps >= 256) {
+                        uint32_t *poisoned = (uint32_t *)workspace, *counts = (uint32_t *)((char *)workspace + off_counts);
+                        uint4 *lists = (uint4 *)((char *)workspace + off_lists);
+                        // strip width of K3r: the widest multiple of 32 columns whose workgroup stays within the LDS budget (four workgroups per CU)
+                        int tws = (res + 31) & ~31;
+                        while (tws > 32 && bits_lds_bytes(kt.n, res, tws, 4, out_mode) > (size_t)g_list_lds_kb * 1024) tws -= 32;
+                        const size_t lds_s = bits_lds_bytes(kt.n, res, tws, 4, out_mode);
+                        if (lds_s <= 150 * 1024) {
+                            if (aux) { aux->n_keys = kt.n; aux->index_bits = nb; for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
+                            if (hipMemsetAsync(poisoned, 0, 4, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the workspace failed"); return TDS_EHIP; }
+                            CommonArgs cs = cm;
+                            cs.strips = 1; cs.slices = nullptr;
+                            const dim3 sgrid((unsigned)((n_img + SCAN_WAVES - 1) / SCAN_WAVES));
+                            const SceneArgs sbase = a;
+                            auto launch_s = [&](auto kern, const auto &args) { hipLaunchKernelGGL(kern, sgrid, dim3(SCAN_WAVES * 64), 0, (hipStream_t)stream, args, cs, kt, counts, lists, (int)caps, poisoned); };
+                            if (a.K != 0) launch_s(scan_faces_kernel<SceneArgsEx>, a);
+                            else launch_s(scan_faces_kernel<SceneArgs>, sbase);
+                            TDS_LAUNCH_CHECK("scan_faces_kernel");
+                            CommonArgs cr = cm;
+                            cr.strips = (res + tws - 1) / tws; cr.slices = nullptr;
+                            const dim3 rgrid((unsigned)(n_img * cr.strips));
+                            auto launch_r = [&](auto kern) {
+                                if (lds_s > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+                                hipLaunchKernelGGL(kern, rgrid, dim3(256), lds_s, (hipStream_t)stream, cr, kt, tws, (const uint32_t *)counts, (const uint4 *)lists, (int)caps);
+                            };
+#define TDS_LIST_DISPATCH(T) do { if (nb == 2) launch_r(raster_list_bits_kernel<2, T>); else if (nb == 3) launch_r(raster_list_bits_kernel<3, T>); else launch_r(raster_list_bits_kernel<4, T>); } while (0)
+                            if (f32) TDS_LIST_DISPATCH(float); else TDS_LIST_DISPATCH(uint8_t);
+#undef TDS_LIST_DISPATCH
+                            TDS_LAUNCH_CHECK("raster_list_bits_kernel");
+                            only = poisoned;            // what follows: the fused kernel, over the cameras K3s marked (normally none)
+                        }
+                    }
+                }
                 // the instantiations for three workgroups per CU are persistent launches: their workgroups take (camera, strip) items from per-XCD
                 // queues (see claim_work); the others get one workgroup per item
+                if (only != nullptr) four_per_cu = false;          // the launch over the marked cameras takes its items from a queue: a persistent instantiation
                 const bool persist = nwv == 4 && (!four_per_cu || cb.slices != nullptr);
                 uint32_t *queue = nullptr;
                 if (persist) {
                     rc = work_queue((hipStream_t)stream, &queue);
                     if (rc != TDS_OK) return rc;
                 }
-                dim3 grid((unsigned)(persist ? persistent_grid(n_img * cb.strips) : n_img * cb.strips));
+                dim3 grid((unsigned)(persist ? persistent_grid(only != nullptr ? 512 : n_img * cb.strips) : n_img * cb.strips));
                 const SceneArgs base = a;
                 auto launch_b = [&](auto kern) {            // scenes without per-camera triangles
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, base, cb, kt, twp, queue);
+                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, base, cb, kt, twp, queue, only);
                 };
                 auto launch = [&](auto kern) {
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp, queue);
+                    hipLaunchKernelGGL(kern, grid, dim3(nwv * 64), lds, (hipStream_t)stream, a, cb, kt, twp, queue, only);
                 };
 #define TDS_BITS_DISPATCH(T)                                                                                                   \
     do {                                                                                                                       \
