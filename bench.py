@@ -327,12 +327,14 @@ def u8_mode(device, steps, warmup, B, A):
     del sim, img
     torch.cuda.empty_cache()
     return dict(mode='uint8 output (3*H*W bytes per camera)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                traffic=traffic, traffic_source=note, kernel='raster_scene_bits_kernel<uint8>', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
+                traffic=traffic, traffic_source=note, kernel='raster_scene_bits_kernel<uint8> (persistent launch)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
 
 
 def low_res_mode(device, steps, warmup, B, A, res=128):
-    """The headline render at 128 x 128 float32 (a quarter of the pixels, the same faces per view): bound by instruction issue, not by the write
-    stream -- a SEPARATE roofline entry, never `value` (VERDICT r1 asked for >= 3 TB/s here)."""
+    """The headline render at a lower resolution, float32 (128 x 128: a quarter of the pixels; 64 x 64: the reference's default resolution,
+    rendering/base.py:144-149 -- the same ~1 200 faces per view either way): bound by instruction issue, not by the write stream, and served
+    by the split form of the bit-plane path (K3s lists the faces, K3r rasterises the lists) -- SEPARATE roofline entries, never `value`.
+    `avg_launch_ms` spans everything tds_raster_scene enqueues for the call (HIP events around it)."""
     from torchdrivesim_amd import _ops
     from torchdrivesim_amd.utils import Resolution
     sim, actions, _ = build_simulator(B, A, device, seed=1234)
@@ -353,7 +355,7 @@ def low_res_mode(device, steps, warmup, B, A, res=128):
     del sim, img
     torch.cuda.empty_cache()
     return dict(mode=f'{res}x{res} float32 output', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=None,
-                kernel='raster_scene_bits_kernel (the 128-VGPR instantiation: four workgroups per CU)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
+                kernel='scan_faces_kernel + raster_list_bits_kernel (the split form of the bit-plane path)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
 
 
 def _free_port():
@@ -580,6 +582,7 @@ def main():
             if not args.no_configs:
                 line['roofline_u8'] = u8_mode(device, args.steps, args.warmup, B, A)
                 line['roofline_128'] = low_res_mode(device, args.steps, args.warmup, B, A)
+                line['roofline_64'] = low_res_mode(device, args.steps, args.warmup, B, A, res=64)
                 del sim, bufs
                 sink.clear()
                 torch.cuda.empty_cache()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Large randomised parity run of the K3 scene rasteriser against the oracle (a script, not collected by pytest: minutes of CPU time).
-   python tests/fuzz_raster.py [--seeds 8] [--batch 8] [--agents 24] [--res 256]"""
+   python tests/fuzz_raster.py [--seeds 8] [--batch 8] [--agents 24] [--res 256] [--map town01|town02] [--u8]
+   --res 0: a third family -- every seed draws its own resolution from 4 .. 60 (multiples of 4 or not: the one-pixel-per-thread
+   write-out) and its own field of view from 5 .. 200 m."""
 import argparse, os, sys, time
 import numpy as np
 import torch
@@ -13,8 +15,9 @@ from oracle import oracle                                                       
 ap = argparse.ArgumentParser()
 ap.add_argument('--seeds', type=int, default=8); ap.add_argument('--batch', type=int, default=8); ap.add_argument('--agents', type=int, default=24)
 ap.add_argument('--res', type=int, default=256); ap.add_argument('--fov', type=float, default=35.0)
+ap.add_argument('--map', default='town01'); ap.add_argument('--u8', action='store_true')
 a = ap.parse_args()
-t = np.load(os.path.join(ROOT, 'tests', 'golden', 'town01_mesh.npz'))
+t = np.load(os.path.join(ROOT, 'tests', 'golden', f'{a.map}_mesh.npz'))
 town = dict(verts=t['verts'], faces=t['faces'], vert_category=t['vert_category'], categories=[str(c) for c in t['categories']])
 smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
 static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
@@ -31,10 +34,11 @@ for seed in range(a.seeds):
     present = gen.uniform(size=(B, A)) < 0.85
     mask = np.ascontiguousarray(present[:, None, :] & (gen.uniform(size=(B, A, A)) < 0.95))
     cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
-    img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, a.fov, a.res)
-    bad = (img != ref)
+    res, fov = (a.res, a.fov) if a.res > 0 else (int(gen.integers(4, 61)), float(np.exp(gen.uniform(np.log(5.0), np.log(200.0)))))
+    img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, fov, res, torch.uint8 if a.u8 else torch.float32)
+    bad = (img.astype(np.float32) != ref)
     per_img = bad.reshape(B * A, -1).any(1).sum()
     bad_total += int(bad.sum()); n_img += B * A
-    print(f'seed {seed}: {B * A} images, {int(bad.sum())} differing values in {int(per_img)} images ({time.time() - t0:.0f} s)', flush=True)
+    print(f'seed {seed}: {B * A} images {res} x {res} fov {fov:.1f}, {int(bad.sum())} differing values in {int(per_img)} images ({time.time() - t0:.0f} s)', flush=True)
 print('TOTAL', n_img, 'images,', bad_total, 'differing values')
 sys.exit(1 if bad_total else 0)
