@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--cell', type=float, default=0.0, help='grid cell size of the rendering map in metres (0: the library default)')
     ap.add_argument('--six-keys', action='store_true', help='two agent types: one more distinct key than the bench scene (6 bit planes)')
     ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
+    ap.add_argument('--lib', default='', help='another build of libtdship_testing.so (path) to load instead')
     ap.add_argument('--list-lds', type=int, nargs='*', default=[], help='testing build: LDS budgets (KiB per workgroup) of the list rasteriser of the split path to sweep')
     ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
     ap.add_argument('--no-ws', action='store_true', help='fused per-strip kernel instead of the binned persistent kernel')
@@ -35,7 +36,9 @@ def main():
     from torchdrivesim_amd.utils import Resolution
     dev = torch.device('cuda', 0)
     # ablation switches / tuning knobs exist only in the testing build; a plain timing or counter run measures the PRODUCT library
-    plain = args.tw == [0] and args.debug == [0] and args.bits_waves == [4] and not args.list_lds
+    plain = args.tw == [0] and args.debug == [0] and args.bits_waves == [4] and not args.list_lds and not args.lib
+    if args.lib:
+        _native.TESTING_LIB_PATH = os.path.abspath(args.lib)
     L = None
     if not plain:
         L = _native.testing_lib()

@@ -2006,12 +2006,18 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
 // and rendered by the fused kernel afterwards (a launch over the marked cameras only), so the result never depends on the capacity.
 // =========================================================================================================
 constexpr int SCAN_WAVES = 4;                 // cameras per workgroup of K3s
-constexpr int SCAN_DEPTH = 4;                 // chunks of 64 grid entries whose loads K3s keeps in flight
+#ifndef TDS_SCAN_DEPTH
+#define TDS_SCAN_DEPTH 2
+#endif
+#ifndef TDS_SCAN_OCC
+#define TDS_SCAN_OCC 6
+#endif
+constexpr int SCAN_DEPTH = TDS_SCAN_DEPTH;    // chunks of 64 grid entries whose loads K3s keeps in flight
 constexpr uint32_t LIST_POISON = 0xffffffffu;
 
-// (cut for four waves per SIMD, 128 VGPRs: 0.97 ms at B = 1024 x 64 against 1.18 at three and 2.4 at five)
+// (chunks in flight x waves per SIMD the registers are cut for, ms at B = 1024 x 64: 4 x 3 1.18, 4 x 4 0.98, 3 x 5 0.87, 2 x 6 0.85, 2 x 8 1.00)
 template <typename SA>
-__global__ void __launch_bounds__(SCAN_WAVES * 64, 4) scan_faces_kernel(SA a, CommonArgs c, KeyTable kt, uint32_t *__restrict__ counts, uint4 *__restrict__ lists,
+__global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kernel(SA a, CommonArgs c, KeyTable kt, uint32_t *__restrict__ counts, uint4 *__restrict__ lists,
                                                                      int caps, uint32_t *__restrict__ poisoned) {
     __shared__ uint32_t lkeys[16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2099,7 +2105,8 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, 4) scan_faces_kernel(SA a, Co
     }
 }
 
-// (60 VGPRs with uint8 output, 72 - 79 with float32: LDS, not registers, sets how many workgroups share a CU)
+// (60 VGPRs with uint8 output, 72 - 79 with float32: LDS, not registers, sets how many workgroups share a CU.  NOT a persistent launch:
+// the loop over the items costs 30 VGPRs -- 111 instead of 75 -- and with them a fifth of the waves: 64 x 64 2.8 -> 3.2 ms)
 template <int NB, typename OutT>
 __global__ void __launch_bounds__(256) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
                                                                       const uint4 *__restrict__ lists, int caps) {
