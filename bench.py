@@ -130,15 +130,20 @@ def cpu_baseline(host, n_scenes, A):
 
 def kernel_source_stamp():
     """sha256 over everything the measured FETCH_SIZE / WRITE_SIZE of the raster kernel depend on: the kernel's sources, the layout of the
-    grid entries it reads (map.hip), the build flags (Makefile) and the host code that chooses the grid cell size (rendering/hip.py).
+    grid entries it reads (map.hip), the build flags (Makefile) and the host function that chooses the grid cell size
+    (rendering/hip.py: HipRenderer.make_static_map).
     PMC figures committed under profiles/ carry the stamp of the build they were measured on and are refused for any other (VERDICT r1:
     the static traffic figure must not go stale silently)."""
     h = hashlib.sha256()
     pkg = os.path.join(ROOT, 'torchdrivesim_amd')
     for path in (os.path.join(pkg, 'csrc', 'raster.hip'), os.path.join(pkg, 'csrc', 'tds_common.h'), os.path.join(pkg, 'csrc', 'map.hip'),
-                 os.path.join(pkg, 'csrc', 'Makefile'), os.path.join(pkg, 'rendering', 'hip.py')):
+                 os.path.join(pkg, 'csrc', 'Makefile')):
         with open(path, 'rb') as f:
             h.update(f.read())
+    # of the host side, the function that chooses the cell size of the rendering grid (the rest of rendering/hip.py does not touch the kernel's reads)
+    import inspect
+    from torchdrivesim_amd.rendering.hip import HipRenderer
+    h.update(inspect.getsource(HipRenderer.make_static_map).encode())
     return h.hexdigest()[:16]
 
 
@@ -430,7 +435,7 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help="skip the extra `configs` / `roofline_u8` entries (BASELINE.json's configs 2, 3, 5; N = 1 only)")
     ap.add_argument('--cpu-scenes', type=int, default=768, help='scenes of the CPU-baseline sample (all usable cores, about 10 s at 16 of them); the single-thread run uses 16')
     ap.add_argument('--overlap', action='store_true', help='compute_collision / compute_offroad on a second stream beside the raster launch (Simulator.overlap_infractions = True)')
-    ap.add_argument('--ring-candidates', type=int, default=4, help='output allocations probed for the two-buffer image ring (2: take the first two)')
+    ap.add_argument('--ring-candidates', type=int, default=5, help='output allocations probed for the two-buffer image ring (2: take the first two)')
     ap.add_argument('--dry-run', action='store_true', help='no GPU, no kernels: exercises launch, barrier, reduction and the JSON line only')
     ap.add_argument('--launch-timeout', type=float, default=1500.0)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src, dst = os.path.join(ROOT, 'gpurun_out', 'profiles'), os.path.join(ROOT, 'profiles')
 B, A, RES = 1024, 64, 256
 stamp = bench.kernel_source_stamp()
@@ -68,6 +68,8 @@ for mode, bpp in (('f32', 4), ('u8', 1)):
     ent = dict(kernel=key, counters=c, write_bytes_per_launch=wb, fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch_corrected=2 * fb,
                hbm_bytes_per_launch=wb + 2 * fb, algorithmic_bytes_per_launch=algo, traffic_over_algorithmic=(wb + 2 * fb) / algo,
                valu_instructions_per_wave=c.get('SQ_INSTS_VALU', 0) / waves,
+               # the launch is persistent since round 3 (a wave renders many images): per image and wave of its workgroup, the figure of rounds 1 - 2
+               valu_instructions_per_image_and_wave=c.get('SQ_INSTS_VALU', 0) / (B * A * 4),
                lds_bank_conflict_share=c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1),
                valu_utilisation=c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / max(c.get('SQ_BUSY_CYCLES', 0), 1) if c.get('SQ_BUSY_CYCLES') else None)
     out[mode] = ent

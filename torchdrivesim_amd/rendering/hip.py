@@ -109,7 +109,7 @@ class HipRenderer(BirdviewRenderer):
                                  key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)
 
 
-def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 4, reps: int = 2):
+def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 5, reps: int = 2, spread: float = 1.05):
     """`count` caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), chosen as
     the fastest of up to `candidates` allocations of `shape`.
 
@@ -117,16 +117,20 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
     ALLOCATION it writes to -- a 51.5 GB tensor is either "fast" (7.1 ms per launch) or "slow" (8.3 ms: every XCD's stores are 13 - 16 %
     slower), for as long as it lives, whichever kernel touches it first and wherever it lies; about every second allocation of a fresh
     process is slow (tools/slow_buffer_probe.py, tools/xcd_finish_times.py).  A loop that owns its observation ring can
-    pay for that once, at start-up: allocate a few candidates, time one launch into each, keep the fast ones, free the rest.
-    Returns (buffers, report) with report = dict(first_touch_ms=[...], launch_ms=[...], kept=[indices]) over the candidates.
+    pay for that once, at start-up: allocate candidates one after the other, time a launch into each, stop as soon as the `count` fastest
+    lie within `spread` of each other (the first two, when both are fast), keep those and free the rest.  The candidates are all held until
+    the choice is made -- a slow allocation that is freed early would be handed out again -- so `candidates` x the buffer must fit the
+    device (it is cut to what does).
+    Returns (buffers, report) with report = dict(first_touch_ms=[...], launch_ms=[...], kept=[indices]) over the candidates tried.
     The candidates that are not kept go back to the driver (torch.cuda.empty_cache) so that a later allocation does not get them again."""
     device = torch.device(device)
     nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
     free, _ = torch.cuda.mem_get_info(device)
-    n = max(count, min(candidates, int((free - (4 << 30)) // max(nbytes, 1))))
-    cands = [torch.empty(shape, dtype=dtype, device=device) for _ in range(n)]
-    first, best = [], []
-    for buf in cands:
+    n_max = max(count, min(candidates, int((free - (4 << 30)) // max(nbytes, 1))))
+    cands, first, best = [], [], []
+    while len(cands) < n_max:
+        buf = torch.empty(shape, dtype=dtype, device=device)
+        cands.append(buf)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 2)]
         ev[0].record()
         render(buf)                                    # first touch: maps the memory
@@ -137,7 +141,11 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
         torch.cuda.synchronize(device)
         first.append(ev[0].elapsed_time(ev[1]))
         best.append(min(ev[1 + r].elapsed_time(ev[2 + r]) for r in range(reps)))
-    kept = sorted(sorted(range(n), key=lambda i: best[i])[:count])
+        if len(cands) >= max(count, 2):
+            top = sorted(best)[:count]
+            if top[-1] <= spread * min(best) and (count > 1 or len(cands) > 1):
+                break
+    kept = sorted(sorted(range(len(cands)), key=lambda i: best[i])[:count])
     out = [cands[i] for i in kept]
     del cands, buf
     torch.cuda.empty_cache()
