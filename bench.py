@@ -227,9 +227,15 @@ def other_configs(device, steps, warmup, only=None):
         sim, actions, _ = build_simulator(B, A, device, seed=1234, lanelet_map=lanes)
         state0 = sim.get_state().clone()
 
+        ring = None
+        if not name.startswith('config5'):
+            # the forward-only configurations render into a two-buffer ring like the headline (the differentiable one cannot: autograd owns its image)
+            from torchdrivesim_amd.rendering import allocate_image_ring
+            ring, _ = allocate_image_ring(lambda out: sim.render_egocentric(res=res, fov=FOV, out=out), (B, A, 3, RES, RES), torch.float32, device, count=2)
+
         def fwd(i):
             sim.step(actions[i % actions.shape[0]])
-            sink['img'] = sim.render_egocentric(res=res, fov=FOV)
+            sink['img'] = sim.render_egocentric(res=res, fov=FOV, out=ring[i % 2])
             sink['col'] = sim.compute_collision()
             if name != 'config2':
                 sink['off'] = sim.compute_offroad()
@@ -269,7 +275,7 @@ def other_configs(device, steps, warmup, only=None):
             ent['ms_per_step_without_loss_probe'] = ent['ms_per_step'] - ent['loss_probe_ms']
             ent['agent_steps_per_s_without_loss_probe'] = B * A / (ent['ms_per_step_without_loss_probe'] * 1e-3)
         out.append(ent)
-        del sim
+        del sim, ring
         sink.clear()
         torch.cuda.empty_cache()
     return out

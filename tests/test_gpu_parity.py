@@ -708,3 +708,29 @@ def test_k3_full_size_properties(ops, town):
     pn = (none[:, :, 0].int() << 16) | (none[:, :, 1].int() << 8) | none[:, :, 2].int()
     veh = (pn == pack(COLORS['vehicle'])).flatten(2).sum(-1)
     assert int(veh.max()) <= 1 and not (pn == pack(COLORS['direction'])).any()
+
+
+def test_k3_index_slices_errors_by_code(ops, town):
+    """`_ops.raster_scene` retries without index slices only when the library reports a documented capacity (TDS_ELIMIT); a caller
+    or ABI bug (a buffer that is too small: TDS_EINVAL) must surface.  Straight through the C ABI, then through the wrapper."""
+    import ctypes
+    from torchdrivesim_amd import _native as nat
+    smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    cam_xy = dev(np.array([[[100.0, 200.0]]], np.float32))
+    cam_sc = dev(np.array([[[0.0, 1.0]]], np.float32))
+    out = torch.empty((1, 1, 3, 64, 64), dtype=torch.float32, device=DEV)
+    small = torch.empty(4, dtype=torch.int32, device=DEV)
+    aux = nat.RasterAux(index_slices=small.data_ptr(), index_slices_bytes=16)
+    with pytest.raises(nat.TdsError) as ei:
+        nat.call('tds_raster_scene', out.device, smap.handle, None, None, None, None, None, nat.dev_ptr(cam_xy, torch.float32, 'cam_xy'),
+                 nat.dev_ptr(cam_sc, torch.float32, 'cam_sc'), 1, 1, 0, float(2.0 / 35.0), 64, nat.OUT_F32, nat.dev_ptr(out, torch.float32, 'out'),
+                 None, 0, None, 0, 0, None, None, 0, ctypes.cast(ctypes.pointer(aux), ctypes.c_void_p), nat.stream_ptr(out.device))
+    assert ei.value.code == nat.E_INVAL and 'too small' in str(ei.value)
+    # the wrapper: a resolution that is no multiple of 4 has no slices (decided before the call), 20 distinct actor keys exceed the bit-plane
+    # kernel (TDS_ELIMIT inside the call): both render, without slices
+    st = dev(np.array([[[100.0, 200.0, 0.3, 1.0]] * 20], np.float32))
+    tm = dev(np.tile(np.array([[2, 1], [-2, 1], [-2, -1], [2, -1], [2, 0.5], [2, -0.5], [1, 0]], np.float32), (1, 20, 1, 1)))
+    keys = (torch.arange(1, 21, dtype=torch.int32, device=DEV)[None, :, None] * 0x10101 + (5 << 24)).expand(1, 20, 2).contiguous()
+    img, sl, kt = ops.raster_scene(smap, st, ops.heading_sc(st[..., 2]), tm, keys, torch.ones(1, 1, 20, dtype=torch.bool, device=DEV), cam_xy, cam_sc, 35.0, 64,
+                                   index_slices=True)
+    assert sl is None and kt is None and img.shape == (1, 1, 3, 64, 64) and bool((img > 0).any())

@@ -148,9 +148,21 @@ def last_error():
     return buf.value.decode(errors='replace')
 
 
+E_INVAL, E_HIP, E_LIMIT = -1, -2, -4          # TDS_EINVAL, TDS_EHIP, TDS_ELIMIT of include/tdship.h
+
+
+class TdsError(RuntimeError):
+    """A C-ABI entry point returned a negative code (`.code`; the message is tds_last_error's).  A RuntimeError, the type the reference
+    handles around rendering (rendering/base.py:190-201)."""
+
+    def __init__(self, what, code, message):
+        super().__init__(f'{what} failed (code {code}): {message}')
+        self.code = code
+
+
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError(f'{what} failed (code {rc}): {last_error()}')
+        raise TdsError(what, rc, last_error())
 
 
 def stream_ptr(device):

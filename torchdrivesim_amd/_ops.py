@@ -499,10 +499,12 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
 
     try:
         launch(aux)
-    except RuntimeError as e:
-        if aux is None or 'index slices' not in str(e):
+    except nat.TdsError as e:
+        # only a documented capacity (more than 15 keys, planes too large for the bit-plane kernel: TDS_ELIMIT) sends the call to the kernels
+        # that produce no slices; a bad argument (TDS_EINVAL: wrong byte count, wrong dtype ...) or a HIP failure is the caller's to see
+        if aux is None or slices is None or e.code != nat.E_LIMIT:
             raise
-        slices = None                       # more than 15 keys, or planes too large: another kernel serves the call, without slices
+        slices = None
         aux = None if trim else nat.RasterAux(flags=nat.RASTER_NO_TRIM)
         launch(aux)
     if ev is not None:
