@@ -22,7 +22,10 @@
 
 namespace {
 
-constexpr int BW_BLOCK = 256;
+#ifndef TDS_BW_BLOCK
+#define TDS_BW_BLOCK 256
+#endif
+constexpr int BW_BLOCK = TDS_BW_BLOCK;
 constexpr int LANES_PER_AGENT = 8;          // 4 body edges + 3 direction-triangle edges (+1 idle)
 // Where the colours on the two sides of an edge are read.  The forward draws the polygon through the TRUNCATED vertices with OpenCV's
 // rules (fill + outline): in continuous pixel coordinates that is the polygon through the centres of the vertex pixels, grown by about
@@ -502,15 +505,16 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
                 wl[lane * OWN_DW + NB * 4 + q] = below[q];
             }
             wl[lane * OWN_DW + NB * 4 + NB] = nxt;
-            int cnt = __popc(m), incl = cnt;
+            // The queue is filled COLUMN by column (a ballot per column: which row quads have a boundary there), not lane by lane: neighbouring
+            // entries are then neighbouring row quads of one column, i.e. 16-byte pieces of the SAME 64-byte sector of the gradient (out[ch][x][y]:
+            // four row quads per sector), and the lanes of a gather share their sectors instead of touching up to 64 different ones.
+            int total = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-            const int total = __shfl(incl, 63);
-            int pos = incl - cnt;
-            while (m) {
-                const int x = __ffs((int)m) - 1;
-                m &= m - 1;
-                cells[pos++] = (unsigned short)((lane << 5) | x);
+            for (int x = 0; x < 32; ++x) {
+                const bool mine = (m >> x) & 1u;
+                const unsigned long long bq = __ballot(mine);
+                if (mine) cells[total + __builtin_amdgcn_mbcnt_hi((unsigned)(bq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bq, 0))] = (unsigned short)((lane << 5) | x);
+                total += __popcll(bq);
             }
             wave_sync_bwd();
             for (int base = 0; base < ((TDS_BWD_ABLATE & 2) ? 0 : total); base += 64) {
