@@ -319,6 +319,8 @@ int tds_raster_set_strip_width(int tw);
 int tds_raster_set_bits_waves(int n);
 /* K3r, the list rasteriser of the split bit-plane path: LDS budget per workgroup in KiB (sets the strip width) */
 int tds_raster_set_list_lds(int lds_kb);
+/* K3r: waves per workgroup (2 or 4; 0 = chosen by the size of a strip) */
+int tds_raster_set_list_waves(int waves);
 /* ablation switches of K3: 1 no static map, 2 no actors, 4 no store, 8 no outline edges, 16 no scan conversion, 32 no binned path,
  * 64 no bit planes, 128 work counters on, 512 no per-face set-up (nothing is painted), 1024 walk the grid but project nothing,
  * 2048 the 170-VGPR instantiation everywhere, 4096 the work counters hold per-XCD finish [0..7] and ~start [8..15] wall clocks (100 MHz),

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--cell', type=float, default=0.0, help='grid cell size of the rendering map in metres (0: the library default)')
     ap.add_argument('--six-keys', action='store_true', help='two agent types: one more distinct key than the bench scene (6 bit planes)')
     ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
+    ap.add_argument('--list-waves', type=int, nargs='*', default=[], help='testing build: waves per workgroup of the list rasteriser to sweep (1, 2, 4; 0 = automatic)')
     ap.add_argument('--lib', default='', help='another build of libtdship_testing.so (path) to load instead')
     ap.add_argument('--list-lds', type=int, nargs='*', default=[], help='testing build: LDS budgets (KiB per workgroup) of the list rasteriser of the split path to sweep')
     ap.add_argument('--no-bits', action='store_true', help='packed-key kernels instead of the bit-plane kernel')
@@ -36,7 +37,7 @@ def main():
     from torchdrivesim_amd.utils import Resolution
     dev = torch.device('cuda', 0)
     # ablation switches / tuning knobs exist only in the testing build; a plain timing or counter run measures the PRODUCT library
-    plain = args.tw == [0] and args.debug == [0] and args.bits_waves == [4] and not args.list_lds and not args.lib
+    plain = args.tw == [0] and args.debug == [0] and args.bits_waves == [4] and not args.list_lds and not args.lib and not args.list_waves
     if args.lib:
         _native.TESTING_LIB_PATH = os.path.abspath(args.lib)
     L = None
@@ -65,11 +66,12 @@ def main():
     nbytes = img.numel() * img.element_size()
     print(f'images {img.shape[0] * img.shape[1]}, output {nbytes / 1e9:.2f} GB, nonzero fraction {(img[:8] > 0).float().mean().item():.3f}')
     del img
-    for tw, bw, ll in [(t, b, l) for t in args.tw for b in args.bits_waves for l in (args.list_lds or [0])]:
+    for tw, bw, ll, lwv in [(t, b, l, w) for t in args.tw for b in args.bits_waves for l in (args.list_lds or [0]) for w in (args.list_waves or [0])]:
         if L is not None:
             L.tds_raster_set_bits_waves(bw)
             if ll:
                 L.tds_raster_set_list_lds(ll)
+            L.tds_raster_set_list_waves(lwv)
         for dbg in args.debug:
             if L is not None:
                 L.tds_raster_set_strip_width(tw)
@@ -80,7 +82,7 @@ def main():
             torch.cuda.synchronize()
             ms = np.array([a.elapsed_time(b) for a, b in _ops.raster_events])
             _ops.raster_events = None
-            print(f'tw={tw:3d} waves={bw} list-lds={ll:3d} debug={dbg:5d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
+            print(f'tw={tw:3d} waves={bw} list-lds={ll:3d} list-waves={lwv} debug={dbg:5d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
                   f'({nbytes / np.median(ms) / 1e6 / 80:.1f}% of 8 TB/s)')
     if L is not None:
         L.tds_raster_set_strip_width(0)

@@ -81,6 +81,7 @@ _TESTING_SIGNATURES = {
     'tds_raster_set_strip_width': [_i32],
     'tds_raster_set_bits_waves': [_i32],
     'tds_raster_set_list_lds': [_i32],
+    'tds_raster_set_list_waves': [_i32],
     'tds_raster_set_debug': [_i32],
     'tds_raster_get_stats': [ctypes.POINTER(ctypes.c_ulonglong)],
     'tds_testing_set_near_lists': [_i32],

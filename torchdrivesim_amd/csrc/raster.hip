@@ -2107,11 +2107,13 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
 
 // (60 VGPRs with uint8 output, 72 - 79 with float32: LDS, not registers, sets how many workgroups share a CU.  NOT a persistent launch:
 // the loop over the items costs 30 VGPRs -- 111 instead of 75 -- and with them a fifth of the waves: 64 x 64 2.8 -> 3.2 ms)
-template <int NB, typename OutT>
-__global__ void __launch_bounds__(256) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
+// BWAVES: wavefronts per workgroup.  A 64 x 64 camera holds five chunks of faces per wave of four: too little to keep four waves in step
+// between the barriers of a workgroup (SQ_WAIT_ANY 40 % of the wave cycles) -- small images get fewer waves per workgroup and more workgroups.
+template <int NB, typename OutT, int BWAVES>
+__global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
                                                                       const uint4 *__restrict__ lists, int caps) {
     using E = typename PairTab<NB, OutT>::E;
-    constexpr int BWAVES = 4, BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
+    constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
@@ -2184,6 +2186,7 @@ inline size_t bits_lds_bytes(int K, int res, int twp, int nwaves, int out_mode) 
     return (plane_dw + tab_dw + BITS_FIXED_DW + (size_t)nwaves * BITS_WAVE_LDS_DW) * 4;
 }
 int g_bits_waves = 4;
+int g_list_waves = 0;            // waves per workgroup of K3r (0: by image size; testing hook)
 int g_list_lds_kb = 40;          // K3r picks the widest strip whose workgroup needs at most this much LDS (testing hook)
 
 // The work queues of a persistent bit-plane launch: 8 counters (64 bytes) that must be zero when the kernel starts.  A launch takes the
@@ -2311,6 +2314,13 @@ TDS_EXPORT int tds_raster_get_stats(unsigned long long *out16) {
 TDS_EXPORT int tds_raster_set_list_lds(int lds_kb) {
     TDS_CHECK_ARG(lds_kb >= 16 && lds_kb <= 150, "tds_raster_set_list_lds: 16..150 KiB");
     g_list_lds_kb = lds_kb;
+    return TDS_OK;
+}
+
+// K3r: waves per workgroup (2 or 4; 0 = chosen by the size of a strip)
+TDS_EXPORT int tds_raster_set_list_waves(int waves) {
+    TDS_CHECK_ARG(waves == 0 || waves == 2 || waves == 4, "tds_raster_set_list_waves: 0, 2 or 4");
+    g_list_waves = waves;
     return TDS_OK;
 }
 
@@ -2503,9 +2513,13 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                         uint32_t *poisoned = (uint32_t *)workspace, *counts = (uint32_t *)((char *)workspace + off_counts);
                         uint4 *lists = (uint4 *)((char *)workspace + off_lists);
                         // strip width of K3r: the widest multiple of 32 columns whose workgroup stays within the LDS budget (four workgroups per CU)
+                        // waves per workgroup of K3r: by the pixels of a strip (testing hook: g_list_waves)
+                        int lw = g_list_waves;
                         int tws = (res + 31) & ~31;
-                        while (tws > 32 && bits_lds_bytes(kt.n, res, tws, 4, out_mode) > (size_t)g_list_lds_kb * 1024) tws -= 32;
-                        const size_t lds_s = bits_lds_bytes(kt.n, res, tws, 4, out_mode);
+                        // (ms at B = 1024 x 64 with 1 / 2 / 4 waves: 32 x 32 2.30 / 2.33 / 2.45, 64 x 64 2.53 / 2.45 / 2.59, 96 x 96 3.32 / 2.89 / 3.03, 128 x 128 4.75 / 3.80 / 3.57)
+                        if (lw == 0) lw = (int64_t)res * tws <= 104 * 104 ? 2 : 4;
+                        while (tws > 32 && bits_lds_bytes(kt.n, res, tws, lw, out_mode) > (size_t)g_list_lds_kb * 1024) tws -= 32;
+                        const size_t lds_s = bits_lds_bytes(kt.n, res, tws, lw, out_mode);
                         if (lds_s <= 150 * 1024) {
                             if (aux) { aux->n_keys = kt.n; aux->index_bits = nb; for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
                             if (hipMemsetAsync(poisoned, 0, 4, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the workspace failed"); return TDS_EHIP; }
@@ -2522,11 +2536,13 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                             const dim3 rgrid((unsigned)(n_img * cr.strips));
                             auto launch_r = [&](auto kern) {
                                 if (lds_s > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-                                hipLaunchKernelGGL(kern, rgrid, dim3(256), lds_s, (hipStream_t)stream, cr, kt, tws, (const uint32_t *)counts, (const uint4 *)lists, (int)caps);
+                                hipLaunchKernelGGL(kern, rgrid, dim3(lw * 64), lds_s, (hipStream_t)stream, cr, kt, tws, (const uint32_t *)counts, (const uint4 *)lists, (int)caps);
                             };
-#define TDS_LIST_DISPATCH(T) do { if (nb == 2) launch_r(raster_list_bits_kernel<2, T>); else if (nb == 3) launch_r(raster_list_bits_kernel<3, T>); else launch_r(raster_list_bits_kernel<4, T>); } while (0)
+#define TDS_LIST_DISPATCH_W(T, W) do { if (nb == 2) launch_r(raster_list_bits_kernel<2, T, W>); else if (nb == 3) launch_r(raster_list_bits_kernel<3, T, W>); else launch_r(raster_list_bits_kernel<4, T, W>); } while (0)
+#define TDS_LIST_DISPATCH(T) do { if (lw == 2) TDS_LIST_DISPATCH_W(T, 2); else TDS_LIST_DISPATCH_W(T, 4); } while (0)
                             if (f32) TDS_LIST_DISPATCH(float); else TDS_LIST_DISPATCH(uint8_t);
 #undef TDS_LIST_DISPATCH
+#undef TDS_LIST_DISPATCH_W
                             TDS_LAUNCH_CHECK("raster_list_bits_kernel");
                             only = poisoned;            // what follows: the fused kernel, over the cameras K3s marked (normally none)
                         }

@@ -109,7 +109,8 @@ class HipRenderer(BirdviewRenderer):
                                  key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)
 
 
-def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 5, reps: int = 2, spread: float = 1.05):
+def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 5, reps: int = 2, spread: float = 1.05,
+                        repeat_fast: bool = True):
     """`count` caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), chosen as
     the fastest of up to `candidates` allocations of `shape`.
 
@@ -121,6 +122,7 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
     lie within `spread` of each other (the first two, when both are fast), keep those and free the rest.  The candidates are all held until
     the choice is made -- a slow allocation that is freed early would be handed out again -- so `candidates` x the buffer must fit the
     device (it is cut to what does).
+    `repeat_fast`: when fewer than `count` candidates are fast, the returned list repeats the fast ones (a shorter ring) instead of taking a slow one.
     Returns (buffers, report) with report = dict(first_touch_ms=[...], launch_ms=[...], kept=[indices]) over the candidates tried.
     The candidates that are not kept go back to the driver (torch.cuda.empty_cache) so that a later allocation does not get them again."""
     device = torch.device(device)
@@ -145,7 +147,14 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
             top = sorted(best)[:count]
             if top[-1] <= spread * min(best) and (count > 1 or len(cands) > 1):
                 break
-    kept = sorted(sorted(range(len(cands)), key=lambda i: best[i])[:count])
+    order = sorted(range(len(cands)), key=lambda i: best[i])
+    fast = [i for i in order if best[i] <= spread * best[order[0]]]
+    if len(fast) >= count or not repeat_fast:
+        kept = sorted(order[:count])
+    else:
+        # fewer fast allocations than buffers asked for, and the device holds no more candidates: a shorter ring used in turn (entries
+        # repeat) rather than a slow buffer in it -- the renders of one stream are ordered anyway
+        kept = [fast[i % len(fast)] for i in range(count)]
     out = [cands[i] for i in kept]
     del cands, buf
     torch.cuda.empty_cache()
