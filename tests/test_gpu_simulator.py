@@ -533,3 +533,22 @@ def test_infractions_beside_the_rasteriser_equal_the_serial_ones():
     img = sim.render_egocentric(res=Resolution(64, 64), fov=35.0)
     (sim.compute_collision().sum() + sim.compute_offroad().sum() + img.sum() / 255.0).backward()
     assert torch.isfinite(s0.grad).all()
+
+
+def test_image_ring_is_chosen_among_candidates():
+    """rendering.allocate_image_ring: candidates are probed one after the other (all held until the choice is made), the fastest are kept; when
+    fewer candidates than asked for are fast the ring repeats the fast ones instead of taking a slow one."""
+    import bench
+    from torchdrivesim_amd.rendering import allocate_image_ring
+    from torchdrivesim_amd.utils import Resolution
+    sim, actions, _ = bench.build_simulator(4, 8, torch.device(DEV), seed=3)
+    res = Resolution(64, 64)
+    ref = sim.render_egocentric(res=res, fov=35.0)
+    render = lambda out: sim.render_egocentric(res=res, fov=35.0, out=out)
+    bufs, rep = allocate_image_ring(render, tuple(ref.shape), torch.float32, DEV, count=2, candidates=4, spread=1e9)     # everything counts as fast
+    assert len(bufs) == 2 and bufs[0].data_ptr() != bufs[1].data_ptr() and len(rep['launch_ms']) == len(rep['first_touch_ms']) == 2 and rep['kept'] == [0, 1]
+    assert all(torch.equal(b, ref) for b in bufs)                                      # the probe rendered into them
+    bufs, rep = allocate_image_ring(render, tuple(ref.shape), torch.float32, DEV, count=2, candidates=3, spread=0.5)   # nothing but the fastest is fast
+    assert len(rep['launch_ms']) == 3 and rep['kept'][0] == rep['kept'][1] and bufs[0] is bufs[1] and torch.equal(bufs[0], ref)
+    bufs, rep = allocate_image_ring(render, tuple(ref.shape), torch.float32, DEV, count=2, candidates=3, spread=0.5, repeat_fast=False)
+    assert len(set(rep['kept'])) == 2 and bufs[0] is not bufs[1]

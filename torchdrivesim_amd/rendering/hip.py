@@ -148,7 +148,7 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
             if top[-1] <= spread * min(best) and (count > 1 or len(cands) > 1):
                 break
     order = sorted(range(len(cands)), key=lambda i: best[i])
-    fast = [i for i in order if best[i] <= spread * best[order[0]]]
+    fast = [i for i in order if i == order[0] or best[i] <= spread * best[order[0]]]
     if len(fast) >= count or not repeat_fast:
         kept = sorted(order[:count])
     else:
