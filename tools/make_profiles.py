@@ -31,6 +31,16 @@ for name, cmd in commands.items():
     rows = list(csv.reader(open(path)))
     with open(os.path.join(dst, f'{tag}_{name}_kernel_stats.csv'), 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats -- {cmd}   (MI355X; top 15 kernels by total time; kernel source {stamp})\n')
+        if name == 'bench':
+            # what the raster launches of this trace are: the average below is over ALL of them, the bench's figure over the 20 timed ones
+            try:
+                line = [json.loads(l) for l in open(os.path.join(src, 'bench_under_rocprof.log')) if l.startswith('{')][-1]
+                probe = line['roofline']['ring_probe']
+                f.write(f"# raster_scene_bits_kernel launches of this run: 20 timed + 3 warm-up (HIP events over the 20 timed ones: {line['roofline']['avg_launch_ms']:.3f} ms), "
+                        f"3 per candidate of the image ring incl. its first touch (candidates: {[round(x, 2) for x in probe['launch_ms']]} ms, first touches "
+                        f"{[round(x, 1) for x in probe['first_touch_ms']]} ms, kept {probe['kept']}), 6 of the stream-only reference launch ({line['roofline']['measured_stream_ms']:.2f} ms)\n")
+            except Exception as exc:          # noqa: BLE001
+                f.write(f'# (no bench line beside the trace: {exc})\n')
         w = csv.writer(f)
         for r in rows[:16]:
             r[0] = r[0][:110]
