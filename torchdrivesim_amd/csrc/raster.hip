@@ -1751,14 +1751,13 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
     OutT *o = out + img * 3 * plane_px;
     const int cols = min(TWp, W - X0);
     if constexpr (sizeof(OutT) == 1 && NB <= 3 && !EMIT) {
-        // uint8 output, at most seven keys, strips tall enough to give every thread an item of EIGHT rows x 32 columns: no table in LDS at all.
-        // The colours of the eight key indices are two dwords per channel, and v_perm_b32 looks four pixels up at once: its selector bytes
-        // are the key indices of four rows of a column.  Per four columns: the index bits of a row are gathered into one byte per column
-        // (slice b rotated by b, masked to every 8th column), the 4 x 4 bytes of four rows are transposed with eight more v_perm, and a
-        // lane then stores 8 bytes (eight rows of a column) per channel -- half the store instructions of the 4-row items below, a third
-        // fewer instructions, none of them in LDS (uint8 256 x 256: the stream-out was 0.65 of 5.4 ms).
-        const int octs = H >> 3;
-        if ((H & 7) == 0 && octs * wpr >= BBLOCK) {                // (an item for every thread; with fewer the 4-row items win: uint8 128 x 128 3.05 against 3.3 ms)
+        // uint8 output, at most seven keys: no table in LDS at all.  The colours of the eight key indices are two dwords per channel, and
+        // v_perm_b32 looks four pixels up at once: its selector bytes are the key indices of four rows of a column.  Per four columns: the
+        // index bits of a row are gathered into one byte per column (slice b rotated by b, masked to every 8th column), the 4 x 4 bytes of
+        // four rows are transposed with eight more v_perm, and a lane stores four rows of a column per channel.  Strips tall enough to give
+        // every thread an item of EIGHT rows x 32 columns take those: 8-byte stores, half the store instructions (with fewer items than
+        // threads the 4-row items keep more lanes busy).  uint8 256 x 256: the stream-out was 0.65 of 5.4 ms, now 0.3.
+        if ((H & 3) == 0) {
             uint32_t tlo[3], thi[3];                                 // colour bytes of the key indices 0..3 / 4..7 per channel (index 0 = background)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
@@ -1771,68 +1770,78 @@ __device__ __forceinline__ void write_out_bits(const uint32_t *planes, const typ
                 tlo[ch] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo); thi[ch] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
             }
             const bool full = (cols & 31) == 0;
-            for (int item = tid; item < octs * wpr; item += BBLOCK) {
-                const int ro = item % octs, xw = item / octs, y0 = ro * 8;
-                if (xw * 32 >= cols) continue;
-                uint32_t s[NB][8], cov[8];
+            char *ob[3] = {(char *)o, (char *)(o + plane_px), (char *)(o + 2 * plane_px)};
+            auto run = [&](auto rows_tag) {
+                constexpr int ROWS = decltype(rows_tag)::value, HALVES = ROWS / 4;
+                const int groups = H / ROWS;
+                for (int item = tid; item < groups * wpr; item += BBLOCK) {
+                    const int rg = item % groups, xw = item / groups, y0 = rg * ROWS;
+                    if (xw * 32 >= cols) continue;
+                    uint32_t s[NB][ROWS], cov[ROWS];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { cov[j] = 0; for (int b = 0; b < NB; ++b) s[b][j] = 0; }
-                for (int k = K - 1; k >= 0; --k) {                   // wave-uniform
-                    const int idx = k + 1;
-                    const uint4 *pw = (const uint4 *)(planes + ((size_t)k * wpr + xw) * H + y0);
-                    const uint4 wa = pw[0], wb = pw[1];
-                    const uint32_t wds[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                    for (int j = 0; j < ROWS; ++j) { cov[j] = 0; for (int b = 0; b < NB; ++b) s[b][j] = 0; }
+                    for (int k = K - 1; k >= 0; --k) {               // wave-uniform
+                        const int idx = k + 1;
+                        const uint4 *pw = (const uint4 *)(planes + ((size_t)k * wpr + xw) * H + y0);
+                        uint32_t wds[ROWS];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t sn = wds[j] & ~cov[j];
-                        cov[j] |= wds[j];
+                        for (int h = 0; h < HALVES; ++h) { const uint4 wq = pw[h]; wds[4 * h] = wq.x; wds[4 * h + 1] = wq.y; wds[4 * h + 2] = wq.z; wds[4 * h + 3] = wq.w; }
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) s[b][j] |= ((idx >> b) & 1) ? sn : 0u;
+                        for (int j = 0; j < ROWS; ++j) {
+                            const uint32_t sn = wds[j] & ~cov[j];
+                            cov[j] |= wds[j];
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) s[b][j] |= ((idx >> b) & 1) ? sn : 0u;
+                        }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < ROWS; ++j)
 #pragma unroll
-                    for (int b = 1; b < NB; ++b) s[b][j] = rotl32(s[b][j], b);
-                const int ncol = min(32, cols - xw * 32);
-                const uint32_t off0 = (uint32_t)((X0 + xw * 32) * H + y0), colb = (uint32_t)H;
-                char *ob[3] = {(char *)o, (char *)(o + plane_px), (char *)(o + 2 * plane_px)};
-                auto emit8 = [&](auto check) {
-                    constexpr bool CHECK = decltype(check)::value;
+                        for (int b = 1; b < NB; ++b) s[b][j] = rotl32(s[b][j], b);
+                    const int ncol = min(32, cols - xw * 32);
+                    const uint32_t off0 = (uint32_t)((X0 + xw * 32) * H + y0), colb = (uint32_t)H;
+                    auto emit8 = [&](auto check) {
+                        constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
-                    for (int ph = 0; ph < 8; ++ph) {
-                        uint32_t B[8];                               // B[j]: byte m = key index of (row j, column ph + 8 m)
+                        for (int ph = 0; ph < 8; ++ph) {
+                            uint32_t B[ROWS];                        // B[j]: byte m = key index of (row j, column ph + 8 m)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            uint32_t v = 0;
+                            for (int j = 0; j < ROWS; ++j) {
+                                uint32_t v = 0;
 #pragma unroll
-                            for (int b = 0; b < NB; ++b) v |= s[b][j] & (0x01010101u << ((ph + b) & 7));
-                            B[j] = rotl32(v, 32 - ph);
-                        }
-                        uint32_t C[2][4];                            // C[h][m]: byte r = key index of (row 4 h + r, column ph + 8 m)
+                                for (int b = 0; b < NB; ++b) v |= s[b][j] & (0x01010101u << ((ph + b) & 7));
+                                B[j] = rotl32(v, 32 - ph);
+                            }
+                            uint32_t C[HALVES][4];                   // C[h][m]: byte r = key index of (row 4 h + r, column ph + 8 m)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const uint32_t a_lo = __builtin_amdgcn_perm(B[4 * h + 1], B[4 * h + 0], 0x05010400u), a_hi = __builtin_amdgcn_perm(B[4 * h + 1], B[4 * h + 0], 0x07030602u);
-                            const uint32_t b_lo = __builtin_amdgcn_perm(B[4 * h + 3], B[4 * h + 2], 0x05010400u), b_hi = __builtin_amdgcn_perm(B[4 * h + 3], B[4 * h + 2], 0x07030602u);
-                            C[h][0] = __builtin_amdgcn_perm(b_lo, a_lo, 0x05040100u); C[h][1] = __builtin_amdgcn_perm(b_lo, a_lo, 0x07060302u);
-                            C[h][2] = __builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u); C[h][3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
-                        }
+                            for (int h = 0; h < HALVES; ++h) {
+                                const uint32_t a_lo = __builtin_amdgcn_perm(B[4 * h + 1], B[4 * h + 0], 0x05010400u), a_hi = __builtin_amdgcn_perm(B[4 * h + 1], B[4 * h + 0], 0x07030602u);
+                                const uint32_t b_lo = __builtin_amdgcn_perm(B[4 * h + 3], B[4 * h + 2], 0x05010400u), b_hi = __builtin_amdgcn_perm(B[4 * h + 3], B[4 * h + 2], 0x07030602u);
+                                C[h][0] = __builtin_amdgcn_perm(b_lo, a_lo, 0x05040100u); C[h][1] = __builtin_amdgcn_perm(b_lo, a_lo, 0x07060302u);
+                                C[h][2] = __builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u); C[h][3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
+                            }
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const int pcol = ph + 8 * m;
-                            if (CHECK && pcol >= ncol) continue;
-                            const uint32_t off = off0 + (uint32_t)pcol * colb;
+                            for (int m = 0; m < 4; ++m) {
+                                const int pcol = ph + 8 * m;
+                                if (CHECK && pcol >= ncol) continue;
+                                const uint32_t off = off0 + (uint32_t)pcol * colb;
 #pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) {
-                                typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
-                                const vu2 v = {__builtin_amdgcn_perm(thi[ch], tlo[ch], C[0][m]), __builtin_amdgcn_perm(thi[ch], tlo[ch], C[1][m])};
-                                __builtin_nontemporal_store(v, (vu2 *)(ob[ch] + off));
+                                for (int ch = 0; ch < 3; ++ch) {
+                                    if constexpr (ROWS == 8) {
+                                        typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+                                        const vu2 v = {__builtin_amdgcn_perm(thi[ch], tlo[ch], C[0][m]), __builtin_amdgcn_perm(thi[ch], tlo[ch], C[1][m])};
+                                        __builtin_nontemporal_store(v, (vu2 *)(ob[ch] + off));
+                                    } else {
+                                        __builtin_nontemporal_store(__builtin_amdgcn_perm(thi[ch], tlo[ch], C[0][m]), (uint32_t *)(ob[ch] + off));
+                                    }
+                                }
                             }
                         }
-                    }
-                };
-                if (full) emit8(std::false_type{}); else emit8(std::true_type{});
-            }
+                    };
+                    if (full) emit8(std::false_type{}); else emit8(std::true_type{});
+                }
+            };
+            if ((H & 7) == 0 && (H >> 3) * wpr >= BBLOCK) run(std::integral_constant<int, 8>{}); else run(std::integral_constant<int, 4>{});
             return;
         }
     }
