@@ -109,7 +109,7 @@ class HipRenderer(BirdviewRenderer):
                                  key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)
 
 
-def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 5, reps: int = 2, spread: float = 1.05,
+def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 5, reps: int = 2, spread: float = 1.03,
                         repeat_fast: bool = True):
     """`count` caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), chosen as
     the fastest of up to `candidates` allocations of `shape`.
