@@ -182,9 +182,14 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  *   out       B x Nc x 3 x H x W   float32 or uint8 (out_mode)
  * Equal-level faces of different colour are ordered by packed colour (documented tie-break).
  *
- * workspace: optional DEVICE scratch (tds_raster_scene_workspace_bytes) for the fast path -- a first kernel scans the map grid
- * once per camera and bins the surviving faces into per-strip lists, a second one rasterises the strips from the lists.
- * With workspace == NULL every strip scans the grid itself (same pixels, slower).  The scratch carries no state between calls.
+ * workspace: optional DEVICE scratch (tds_raster_scene_workspace_bytes) for the two-kernel forms -- a first kernel scans the map grid
+ * once per camera and lists the surviving faces, a second one rasterises from the lists: per-strip lists for the packed-key kernels
+ * (more than 15 keys), one list of up to 2 048 faces per camera for the bit-plane kernels below 160 x 160 (float32) / 224 x 224 (uint8),
+ * where that form is faster than the fused kernel.  A list that overflows only sends its camera (or strip) to the kernel that scans for
+ * itself: the pixels never depend on the size of the scratch.  With workspace == NULL every launch scans the grid itself (same pixels,
+ * slower at low resolutions).  The scratch carries no state between calls.
+ * Launch shape of the bit-plane kernels: the fused kernel at three workgroups per CU is a PERSISTENT launch (its workgroups take cameras
+ * from per-XCD queues; the library keeps a small pool of 64-byte queue slots per device and clears one in stream order per launch).
  *
  * actor_keys: optional HOST array of the distinct values occurring in `actor_key` (one per agent type and part).  When it is
  * given and the scene (map + actors) uses at most 16 distinct keys, the bit-plane kernel is used: one bit per pixel and key in

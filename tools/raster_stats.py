@@ -8,6 +8,7 @@ import bench
 from torchdrivesim_amd import _native
 from torchdrivesim_amd.utils import Resolution
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+RES = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device('cuda', 0)
 L = _native.testing_lib()           # the work counters exist only in the testing build
 _native._lib = L
@@ -15,10 +16,10 @@ sim, actions, _ = bench.build_simulator(B, 64, dev, seed=1234)
 for i in range(5):
     sim.step(actions[i % 8])
 buf = (ctypes.c_ulonglong * 16)()
-sim.render_egocentric(res=Resolution(256, 256), fov=35.0); torch.cuda.synchronize()
+sim.render_egocentric(res=Resolution(RES, RES), fov=35.0); torch.cuda.synchronize()
 L.tds_raster_get_stats(buf)
-L.tds_raster_set_debug(128)
-sim.render_egocentric(res=Resolution(256, 256), fov=35.0); torch.cuda.synchronize()
+L.tds_raster_set_debug(128 | 8192)          # the counters are the fused kernel's: force it at every resolution
+sim.render_egocentric(res=Resolution(RES, RES), fov=35.0); torch.cuda.synchronize()
 L.tds_raster_set_debug(0)
 L.tds_raster_get_stats(buf)
 names = ['batches', 'faces', 'fill chunks', 'fill windows', 'fill rows', 'edges', 'edge rounds', 'V chunks', 'V windows', 'V rows', 'H chunks',
