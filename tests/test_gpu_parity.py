@@ -734,3 +734,23 @@ def test_k3_index_slices_errors_by_code(ops, town):
     img, sl, kt = ops.raster_scene(smap, st, ops.heading_sc(st[..., 2]), tm, keys, torch.ones(1, 1, 20, dtype=torch.bool, device=DEV), cam_xy, cam_sc, 35.0, 64,
                                    index_slices=True)
     assert sl is None and kt is None and img.shape == (1, 1, 3, 64, 64) and bool((img > 0).any())
+
+
+@pytest.mark.parametrize('B,A', [(3, 5), (1, 1), (5, 13)])
+def test_k3_camera_counts_that_do_not_divide_by_eight(ops, oracle, town, B, A):
+    """The persistent launch cuts its work items into eight queues only when they divide evenly, else into one; K3s packs four cameras per
+    workgroup.  Camera counts of 15, 1 and 65 at the resolutions of every form (fused persistent, fused one-item, split), both output types."""
+    smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    gen = np.random.default_rng(B * 100 + A)
+    road = town['verts'][town['vert_category'] == town['categories'].index('road')]
+    xy = road[gen.integers(0, len(road), (B, 1))] + gen.uniform(-20, 20, (B, A, 2))
+    state = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), gen.uniform(0, 10, (B, A, 1))], -1).astype(np.float32)
+    size = np.concatenate([gen.uniform(3.5, 6, (B, A, 1)), gen.uniform(1.6, 2.4, (B, A, 1))], -1).astype(np.float32)
+    mask = np.ascontiguousarray(np.broadcast_to((gen.uniform(size=(B, A)) < 0.9)[:, None, :], (B, A, A)))
+    cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
+    for res in (64, 128, 256, 320):
+        for dtype in (torch.float32, torch.uint8):
+            img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 35.0, res, dtype)
+            assert img.shape == (B, A, 3, res, res)
+            np.testing.assert_array_equal(img.astype(np.float32), ref)
