@@ -747,7 +747,7 @@ def test_k3_camera_counts_that_do_not_divide_by_eight(ops, oracle, town, B, A):
     xy = road[gen.integers(0, len(road), (B, 1))] + gen.uniform(-20, 20, (B, A, 2))
     state = np.concatenate([xy, gen.uniform(-np.pi, np.pi, (B, A, 1)), gen.uniform(0, 10, (B, A, 1))], -1).astype(np.float32)
     size = np.concatenate([gen.uniform(3.5, 6, (B, A, 1)), gen.uniform(1.6, 2.4, (B, A, 1))], -1).astype(np.float32)
-    mask = np.ascontiguousarray(np.broadcast_to((gen.uniform(size=(B, A)) < 0.9)[:, None, :], (B, A, A)))
+    mask = np.broadcast_to((gen.uniform(size=(B, A)) < 0.9)[:, None, :], (B, A, A)).copy()
     cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
     for res in (64, 128, 256, 320):
         for dtype in (torch.float32, torch.uint8):
