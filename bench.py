@@ -231,7 +231,7 @@ def other_configs(device, steps, warmup, only=None):
         if not name.startswith('config5'):
             # the forward-only configurations render into a two-buffer ring like the headline (the differentiable one cannot: autograd owns its image)
             from torchdrivesim_amd.rendering import allocate_image_ring
-            ring, _ = allocate_image_ring(lambda out: sim.render_egocentric(res=res, fov=FOV, out=out), (B, A, 3, RES, RES), torch.float32, device, count=2)
+            ring, ring_rep = allocate_image_ring(lambda out: sim.render_egocentric(res=res, fov=FOV, out=out), (B, A, 3, RES, RES), torch.float32, device, count=2)
 
         def fwd(i):
             sim.step(actions[i % actions.shape[0]])
@@ -266,6 +266,11 @@ def other_configs(device, steps, warmup, only=None):
         ent = dict(config=name, what=what, batch=B, agents=A, ms_per_step=1e3 * dt, agent_steps_per_s=B * A / dt,
                    dominant_kernel='raster_scene_bits_kernel', dominant_kernel_ms=k_fwd,
                    dominant_kernel_frac_of_hbm_peak=None if not k_fwd else B * A * ALGO_BYTES_PER_IMAGE / (k_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        if ring is not None:
+            ent['ring_probe'] = dict(launch_ms=ring_rep['launch_ms'], fast=ring_rep['fast'], kept=ring_rep['kept'])
+        else:
+            # autograd owns the image of the differentiable step: a fresh tensor per step from the image pool (spread-out physical pages)
+            ent['image_allocation'] = 'per step, torch memory pool over tds_torch_alloc (csrc/alloc.hip)'
         if k_bwd is not None:
             ent['raster_backward_kernel_ms'] = k_bwd
         if name == 'config5' and _ImageProbe.events:
@@ -440,8 +445,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help="skip the extra `configs` / `roofline_u8` entries (BASELINE.json's configs 2, 3, 5; N = 1 only)")
     ap.add_argument('--cpu-scenes', type=int, default=768, help='scenes of the CPU-baseline sample (all usable cores, about 10 s at 16 of them); the single-thread run uses 16')
-    ap.add_argument('--overlap', action='store_true', help='compute_collision / compute_offroad on a second stream beside the raster launch (Simulator.overlap_infractions = True)')
-    ap.add_argument('--ring-candidates', type=int, default=5, help='output allocations probed for the two-buffer image ring (2: take the first two)')
+    ap.add_argument('--overlap', action='store_true', help='compute_collision / compute_offroad on a second stream, enqueued ahead of the raster launch (Simulator.overlap_infractions = True)')
+    ap.add_argument('--no-default-path', action='store_true', help='skip the `default_path` entry (the loop without out=; N = 1 only)')
+    ap.add_argument('--ring-candidates', type=int, default=4, help='output allocations probed at most for the two-buffer image ring')
     ap.add_argument('--dry-run', action='store_true', help='no GPU, no kernels: exercises launch, barrier, reduction and the JSON line only')
     ap.add_argument('--launch-timeout', type=float, default=1500.0)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
@@ -525,10 +531,12 @@ def main():
         from torchdrivesim_amd import _ops
 
         # The images go to two caller-owned buffers, allocated once and used in turn (step i renders while the consumer of step i - 1 still
-        # holds the other one): a training loop owns its observation ring.  The reference allocates per call (rendering/cv2.py:52); a fresh
-        # 51.5 GB allocation per step made the measured time depend on which allocation each step happened to get -- about every second one
-        # is 16 % slower for the write stream of this launch, for as long as it lives.  allocate_image_ring times one
-        # launch into each of a few candidate allocations and keeps the two fastest; what it saw is reported in `roofline.ring_probe`.
+        # holds the other one): a training loop owns its observation ring.  The reference allocates per call (rendering/cv2.py:52).  What the
+        # write stream of the launch reaches depends on the PHYSICAL pages under the buffer (about one 51.5 GB hipMalloc in three is served
+        # at 7/8 of the rate for as long as it lives): the buffers come from the library's allocator, which spreads the
+        # pages out (csrc/alloc.hip), and allocate_image_ring still measures every candidate against the fill_ rate of the same run; what
+        # it saw is reported per rank (`roofline.ring_probe`, `per_rank`).  The reference-shaped call without `out=` is measured after the
+        # timed region and reported beside (`default_path`).
         from torchdrivesim_amd.rendering import allocate_image_ring
         sim.overlap_infractions = args.overlap
         bufs, ring_probe = allocate_image_ring(lambda out: sim.render_egocentric(res=res, fov=FOV, out=out), (B, A, 3, RES, RES), torch.float32, device,
@@ -548,8 +556,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    first_call = None
     if not args.dry_run:
         _ops.raster_events = []             # HIP events around every raster launch of the timed region
+        first_call = _ops.raster_calls      # which raster launches of this process the timed region is (tools/make_profiles.py cuts a trace to them)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -561,6 +571,11 @@ def main():
     if not args.dry_run:
         raster_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else None
         _ops.raster_events = None
+    # every rank's own figures (a rank on slow memory would otherwise show only as a low rate): reporting only, over gloo
+    mine_report = dict(rank=rank, seconds=mine, agent_steps_per_s=B * A * args.steps / mine, avg_launch_ms=raster_ms,
+                       ring_probe=None if args.dry_run else dict(launch_ms=ring_probe['launch_ms'], fill_ms=ring_probe['fill_ms'], fast=ring_probe['fast'],
+                                                                kept=ring_probe['kept'], aliased=ring_probe['aliased']))
+    all_reports = parallel.gather_objects_over_ranks(mine_report)
 
     if rank == 0:
         value = world * B * A * args.steps / elapsed
@@ -571,6 +586,7 @@ def main():
             same_run = same_run_write_roofs(sim, bufs[0], res, device)
             same_run['first_touch_ms'] = first_touch_ms
             same_run['ring_probe'] = ring_probe
+            same_run['timed_raster_calls'] = [first_call, first_call + args.steps]     # [first, end) among this process's raster launches
         line = dict(
             metric='agent-steps/sec (whole node) at B=1024xA=64, 256x256 BEV', value=value, unit='agent-steps/s', n_gpus=world,
             steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / max(args.steps, 1), higher_is_better=True, scaling='weak',
@@ -582,14 +598,47 @@ def main():
                           traffic=traffic, traffic_source=traffic_note,
                           kernel='raster_scene_bits_kernel', avg_launch_ms=raster_ms, algorithmic_bytes_per_launch=B * A * ALGO_BYTES_PER_IMAGE,
                           **same_run))
+        line['methodology'] = ('images are rendered into a two-buffer ring the loop owns (rendering.allocate_image_ring: buffers from the library\'s '
+                               'allocator, each measured against the fill_ rate of the same run; `roofline.ring_probe`); `default_path` is the same '
+                               'loop with the reference-shaped call render_egocentric() without out= (a fresh tensor per step from the image pool)')
         if world > 1:
             line['per_rank_agent_steps_per_s'] = [B * A * args.steps / t for t in per_rank]
+            line['per_rank'] = all_reports
             line['launcher'] = ('bench.py self-launch, one child per GPU' if args.worker else 'external launcher (torch.distributed.run)') + \
                 (', RCCL barrier' if backend == 'nccl' else ', gloo barrier on 127.0.0.1')
         if args.dry_run:
             line['dry_run'] = True
             line['data'] = 'none (dry run: no kernels were launched, the value is meaningless)'
         if world == 1 and not args.dry_run:
+            if not args.no_default_path:
+                # the reference-shaped call: no `out=`, a fresh image tensor per step (rendering/cv2.py:52 allocates per call); the previous
+                # image is still held when the next one is allocated, as a consumer would
+                del bufs
+                sink.clear()
+                torch.cuda.empty_cache()
+
+                def default_step(i):
+                    sim.step(actions[i % actions.shape[0]])
+                    sink['img'] = sim.render_egocentric(res=res, fov=FOV)
+                    sink['col'] = sim.compute_collision()
+                    sink['off'] = sim.compute_offroad()
+
+                for i in range(args.warmup):
+                    default_step(i)
+                torch.cuda.synchronize(device)
+                _ops.raster_events = []
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    default_step(args.warmup + i)
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - t1) / args.steps
+                ms = [a.elapsed_time(b) for a, b in _ops.raster_events]
+                _ops.raster_events = None
+                line['default_path'] = dict(what='the same loop with render_egocentric() without out=: a fresh image tensor per step',
+                                            ms_per_step=1e3 * dt, agent_steps_per_s=B * A / dt, avg_launch_ms=float(np.mean(ms)),
+                                            min_launch_ms=float(np.min(ms)), max_launch_ms=float(np.max(ms)),
+                                            image_allocation='torch memory pool over tds_torch_alloc (csrc/alloc.hip)' if _ops.use_image_pool else 'torch.empty')
+                bufs = None
             if not args.no_configs:
                 line['roofline_u8'] = u8_mode(device, args.steps, args.warmup, B, A)
                 line['roofline_128'] = low_res_mode(device, args.steps, args.warmup, B, A)

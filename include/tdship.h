@@ -184,12 +184,16 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  *
  * workspace: optional DEVICE scratch (tds_raster_scene_workspace_bytes) for the two-kernel forms -- a first kernel scans the map grid
  * once per camera and lists the surviving faces, a second one rasterises from the lists: per-strip lists for the packed-key kernels
- * (more than 15 keys), one list of up to 2 048 faces per camera for the bit-plane kernels below 160 x 160 (float32) / 224 x 224 (uint8),
- * where that form is faster than the fused kernel.  A list that overflows only sends its camera (or strip) to the kernel that scans for
+ * (more than 15 keys), one list of up to 2 048 faces per camera for the bit-plane kernels up to 144 x 144 (float32) / 208 x 208 (uint8),
+ * where that form is faster than the fused kernel (above, the fused kernel runs and the recommended size holds no lists).  A list that overflows only sends its camera (or strip) to the kernel that scans for
  * itself: the pixels never depend on the size of the scratch.  With workspace == NULL every launch scans the grid itself (same pixels,
  * slower at low resolutions).  The scratch carries no state between calls.
- * Launch shape of the bit-plane kernels: the fused kernel at three workgroups per CU is a PERSISTENT launch (its workgroups take cameras
- * from per-XCD queues; the library keeps a small pool of 64-byte queue slots per device and clears one in stream order per launch).
+ * Launch shape of the bit-plane kernels: the fused kernel at three workgroups per CU is a PERSISTENT launch: its workgroups take cameras
+ * from per-XCD work queues, 64 bytes at the END of the workspace that the call clears in stream order right before the launch (a one-wave
+ * kernel).  The library owns no device memory besides the handles of tds_map_create & co. and allocates nothing in
+ * any per-call entry point, so every call can be captured into a HIP graph.  Two calls that may run at the same time (different
+ * streams) need a workspace each.  With workspace == NULL the same kernel runs one workgroup per camera (about 1 % slower at 256 x 256).
+ * The workspace must be 16-byte aligned.
  *
  * actor_keys: optional HOST array of the distinct values occurring in `actor_key` (one per agent type and part).  When it is
  * given and the scene (map + actors) uses at most 16 distinct keys, the bit-plane kernel is used: one bit per pixel and key in
@@ -233,6 +237,29 @@ int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, co
                            const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream);
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Output buffers with spread-out physical pages (no reference counterpart: rendering/cv2.py:52 allocates a numpy image per call).
+ *
+ * The rasteriser is bound by the HBM write stream, and what a write stream reaches on MI355X depends on the PHYSICAL pages under the
+ * buffer: a large hipMalloc is served at 1, 15/16 or 7/8 of the rate for as long as it lives, whatever its virtual address and whatever
+ * the store pattern (about one 51.5 GB allocation in three is at 7/8); a buffer whose physical pages are spread over twice its size
+ * never was (tools/alloc_probe.hip).  tds_buffer_create builds such a buffer: chunks of 8 MiB created alternately
+ * with spacer chunks that are released once the buffer is mapped (hipMemCreate / hipMemMap; needs twice the size free while it runs,
+ * and falls back to dense chunks when that is not there).  Below 256 MiB, or with TDS_BUFFER_DENSE, it is one hipMalloc.
+ * These are explicit create / destroy calls like tds_map_create: no per-step entry point allocates.
+ * tds_torch_alloc / tds_torch_free have the signatures torch.cuda.memory.CUDAPluggableAllocator binds
+ * (void *(size_t, int device, stream), void(void *, size_t, int device, stream)): a torch memory pool over them hands such buffers to
+ * `torch.empty`, cached and stream-ordered by torch's allocator like any other block (torchdrivesim_amd/rendering/hip.py: image_pool).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define TDS_BUFFER_DENSE 1      /* plain hipMalloc whatever the size */
+typedef struct tds_buffer tds_buffer_t;
+int tds_buffer_create(int64_t bytes, int device, int flags, tds_buffer_t **out);
+void *tds_buffer_ptr(const tds_buffer_t *buf);                         /* device pointer, valid until tds_buffer_destroy */
+int tds_buffer_info(const tds_buffer_t *buf, int64_t *bytes, int64_t *chunks, int *spread);      /* any output may be NULL */
+int tds_buffer_destroy(tds_buffer_t *buf);
+void *tds_torch_alloc(size_t size, int device, void *stream);          /* NULL on failure */
+void tds_torch_free(void *ptr, size_t size, int device, void *stream);
 
 /* Backward of tds_raster_scene with respect to the poses of the actors and cameras.  The CV2 backend of the reference has no
  * gradient (rendering/cv2.py:27-70 runs in numpy); this one is build-defined (edge sampling of the actors' outlines against the

@@ -57,6 +57,21 @@ int main(void) {
         return 1;
     }
 
+    /* an output buffer with spread-out physical pages (512 MiB: 64 chunks of 8 MiB), written and read back, and a small dense one */
+    tds_buffer_t *buf = NULL, *small = NULL;
+    int64_t nbytes = 0, chunks = 0;
+    int spread = 0;
+    rc = tds_buffer_create((int64_t)512 << 20, 0, 0, &buf);
+    if (rc != TDS_OK || tds_buffer_info(buf, &nbytes, &chunks, &spread) != TDS_OK || !spread || chunks != 64 || nbytes != ((int64_t)512 << 20)) {
+        char m[256]; tds_last_error(m, sizeof m); printf("FAIL tds_buffer_create rc=%d spread=%d chunks=%lld %s\n", rc, spread, (long long)chunks, m); return 1;
+    }
+    unsigned char *bp = (unsigned char *)tds_buffer_ptr(buf), back[4] = {0, 0, 0, 0};
+    CHECK_HIP(hipMemset(bp, 0x5a, (size_t)512 << 20));
+    CHECK_HIP(hipMemcpy(back, bp + ((size_t)512 << 20) - 4, 4, hipMemcpyDeviceToHost));
+    if (back[0] != 0x5a || back[3] != 0x5a) { printf("FAIL the buffer does not hold what was written\n"); return 1; }
+    if (tds_buffer_create(4096, 0, 0, &small) != TDS_OK || tds_buffer_info(small, NULL, NULL, &spread) != TDS_OK || spread) { printf("FAIL small buffer\n"); return 1; }
+    if (tds_buffer_destroy(small) != TDS_OK || tds_buffer_destroy(buf) != TDS_OK) { printf("FAIL tds_buffer_destroy\n"); return 1; }
+
     rc = tds_bicycle_step_f32(NULL, d_action, d_lr, d_out, 1, 0.1f, 5.0f, 1.5707963f, 0, 0, NULL);
     char msg[256] = "";
     int len = tds_last_error(msg, sizeof msg);

@@ -18,7 +18,7 @@ def _header(testing):
 
 
 def declared_symbols(testing=False):
-    return sorted(set(re.findall(r'\bint\s+(tds_\w+)\s*\(', _header(testing))))
+    return sorted(set(re.findall(r'\b(?:int|void)\s*\*?\s*(tds_\w+)\s*\(', _header(testing))))
 
 
 def exported_symbols(path):
@@ -105,3 +105,20 @@ def test_a_plain_c_program_runs_through_the_abi(tmp_path):
     import subprocess
     out = subprocess.run([_build_c_caller(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and 'abi smoke ok' in out.stdout, out.stdout + out.stderr
+
+
+def test_no_per_call_entry_point_allocates_or_synchronises():
+    """SURVEY 8(b) "Ownership": the library never allocates per call -- device memory is owned by the explicit create / destroy handles
+    (maps, lane tables, output buffers) -- and never synchronises, so every per-step call can be captured into a HIP graph
+    (tests/test_gpu_graph.py).  The kernel sources must not even mention an allocation or a blocking call (the work
+    queues of the persistent raster launch used to live in a pool the library allocated lazily inside tds_raster_scene)."""
+    csrc = os.path.join(ROOT, 'torchdrivesim_amd', 'csrc')
+    banned = ('hipMalloc', 'hipFree', 'hipMemset', 'hipMemcpy(', 'hipMemcpyAsync', 'hipStreamSynchronize', 'hipDeviceSynchronize', 'hipEventSynchronize', 'hipHostMalloc')
+    for name in ('raster.hip', 'raster_bwd.hip', 'collision.hip', 'backward.hip', 'kinematic.hip'):
+        src = re.sub(r'//.*', '', open(os.path.join(csrc, name)).read())
+        for word in banned:
+            assert word not in src, f'{name} mentions {word}'
+    # where allocations do live: create / destroy functions only
+    for name in ('map.hip', 'lanes.hip', 'alloc.hip'):
+        src = open(os.path.join(csrc, name)).read()
+        assert 'hipMalloc' in src or 'hipMemCreate' in src

@@ -39,6 +39,7 @@ def check(stdout, launcher_words):
     roof = line['roofline']
     assert roof['kernel'] == 'raster_scene_bits_kernel' and roof['avg_launch_ms'] > 0 and 0 < roof['frac'] < 1      # kernels really ran
     assert any(w in line['launcher'] for w in launcher_words), line['launcher']
+    assert [p['rank'] for p in line['per_rank']] == [0, 1] and all(p['avg_launch_ms'] > 0 and not p['ring_probe']['aliased'] for p in line['per_rank'])
     return line
 
 
@@ -59,3 +60,23 @@ def test_two_real_workers_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-3000:]
     line = check(r.stdout, ['external launcher'])
     assert 'RCCL barrier' in line['launcher'] or ('gloo' in line['launcher'] and 'falling back to gloo' in r.stderr)
+
+
+def test_eight_real_workers_on_one_gpu():
+    """The largest world the driver launches (BASELINE.json config 4: 8 GPUs), with eight real workers sharing the one GPU of a test box:
+    rendezvous of eight children, eight image rings probed side by side, eight per-rank reports in the one line."""
+    args = ['--gpus', '8', '--batch', '32', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-configs']
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=1500,
+                       env=clean_env(HIP_VISIBLE_DEVICES='0,0,0,0,0,0,0,0'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['config']['global_batch'] == 256 and 'x8' in line['config']['parallelism']
+    assert len(line['per_rank_agent_steps_per_s']) == 8 and all(v > 0 for v in line['per_rank_agent_steps_per_s'])
+    assert line['value'] <= sum(line['per_rank_agent_steps_per_s']) * 1.0001
+    per_rank = line['per_rank']
+    assert [p['rank'] for p in per_rank] == list(range(8))
+    for p in per_rank:
+        assert p['avg_launch_ms'] > 0 and len(p['ring_probe']['kept']) == 2 and len(set(p['ring_probe']['kept'])) == 2 and not p['ring_probe']['aliased']
+        assert len(p['ring_probe']['launch_ms']) >= 2 and p['ring_probe']['fill_ms'] > 0

@@ -1,0 +1,57 @@
+"""The whole step -- Simulator.step -> render_egocentric(out=) -> compute_collision -> compute_offroad -- captured into a HIP graph and
+replayed: no per-call entry point of the library allocates or synchronises (the work queues of the persistent raster
+launch live in the caller's workspace and are cleared by a memset node), so a captured step equals the eager one bit for bit.
+Loop matched: examples/gym_env.py:83-126 of the reference."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_a_captured_step_replays_bit_for_bit(overlap):
+    import bench
+    from torchdrivesim_amd.utils import Resolution
+    B, A = 24, 64
+    res = Resolution(256, 256)
+    sim, actions, _ = bench.build_simulator(B, A, torch.device(DEV), seed=21)
+    ref, _, _ = bench.build_simulator(B, A, torch.device(DEV), seed=21)
+    sim.overlap_infractions = overlap
+    state = sim.get_state().clone()                       # static tensors of the graph: state in / out, action in, image out
+    action = actions[0].clone()
+    image = torch.empty(B, A, 3, 256, 256, device=DEV)
+    sim.kinematic_model.set_state(state)
+
+    def step():
+        sim.kinematic_model.set_state(state)
+        sim.step(action)
+        img = sim.render_egocentric(res=res, fov=35.0, out=image)
+        col, off = sim.compute_collision(), sim.compute_offroad()
+        new = sim.get_state()
+        return img, col, off, new
+
+    # eager warm-up on a side stream (as torch asks for before capture): builds the device scene, the workspaces, the side stream
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        img, col, off, new = step()
+        state_next = new.clone()
+    for i in range(4):
+        # the eager reference
+        ref.kinematic_model.set_state(state.clone())
+        ref.step(actions[i])
+        want_img = ref.render_egocentric(res=res, fov=35.0)
+        want = (want_img, ref.compute_collision(), ref.compute_offroad(), ref.get_state())
+        action.copy_(actions[i])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(img, want[0]) and torch.equal(col, want[1]) and torch.equal(off, want[2]) and torch.equal(new, want[3])
+        assert bool(img.flatten(2).amax(-1).gt(0).all())
+        state.copy_(state_next)                           # the next replay continues from here

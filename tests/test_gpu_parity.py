@@ -488,7 +488,7 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town, testing_lib):
 
 
 def test_k3_split_form_equals_the_fused_kernel_and_the_oracle(ops, oracle, town, testing_lib):
-    """Below 160 x 160 (float32) / 224 x 224 (uint8) the bit-plane path runs as two kernels -- K3s lists every camera's faces, K3r rasterises
+    """Up to 144 x 144 (float32) / 208 x 208 (uint8) the bit-plane path runs as two kernels -- K3s lists every camera's faces, K3r rasterises
     the lists -- with a third launch of the fused kernel over the cameras whose list overflowed.  Every form must paint the same pixels:
     forced either way (debug flags 8192 / 16384 of the testing build), cut into narrow strips (LDS budget), with a workspace so small that
     most lists overflow."""

@@ -1,0 +1,63 @@
+"""The decision logic of rendering.allocate_image_ring, on the CPU with injected timings: "fast" is absolute
+-- a launch that takes at most 0.98 x the fill_ of the same run -- the search never stops while it has not seen `count` fast candidates,
+the ring is never aliased unless the caller allows it."""
+import torch
+
+from torchdrivesim_amd.rendering import allocate_image_ring
+
+F, M, S, FILL = 7.07, 7.45, 8.3, 7.45          # ms: fast / in-between / slow launches and torch's fill_
+
+
+class FakeTimer:
+    def __init__(self, launches, fill=FILL):
+        self.launches, self.fill_ms, self.i = list(launches), fill, -1
+        self.held = []
+
+    def first_touch(self, buf):
+        self.i += 1
+        self.held.append(buf)
+        return 20.0
+
+    def launch(self, buf):
+        return self.launches[self.i]
+
+    def fill(self, buf):
+        return self.fill_ms
+
+
+def ring(launches, **kw):
+    t = FakeTimer(launches, kw.pop('fill', FILL))
+    bufs, rep = allocate_image_ring(None, (2, 3), torch.float32, 'cpu', count=2, candidates=kw.pop('candidates', 5), timer=t,
+                                    alloc=lambda shape, dtype, device: torch.empty(shape, dtype=dtype), **kw)
+    return bufs, rep, t
+
+
+def test_two_slow_candidates_first_do_not_end_the_search():
+    bufs, rep, t = ring([S, S, F, F, F])
+    assert rep['launch_ms'] == [S, S, F, F] and rep['kept'] == [2, 3] and rep['fast'] == [False, False, True, True]
+    assert bufs[0] is t.held[2] and bufs[1] is t.held[3] and not rep['aliased'] and rep['fill_ms'] == FILL
+
+
+def test_all_slow_takes_the_best_distinct_buffers():
+    bufs, rep, t = ring([S, S + 0.1, S, S + 0.2, S])
+    assert len(rep['launch_ms']) == 5 and rep['fast'] == [False] * 5            # searched to the end
+    assert len(set(rep['kept'])) == 2 and bufs[0] is not bufs[1] and not rep['aliased']
+    assert sorted(rep['launch_ms'][i] for i in rep['kept']) == [S, S]
+
+
+def test_an_in_between_buffer_is_not_fast():
+    bufs, rep, t = ring([M, S, F], candidates=3)
+    assert rep['fast'] == [False, False, True]
+    assert rep['kept'] == [0, 2] and not rep['aliased']                          # the fast one and the best of the rest, distinct
+    bufs, rep, t = ring([M, S, F], candidates=3, allow_aliasing=True)
+    assert rep['kept'] == [2, 2] and rep['aliased'] and bufs[0] is bufs[1]       # only on request
+
+
+def test_fast_candidates_end_the_search_at_once():
+    bufs, rep, t = ring([F, F, S, S])
+    assert rep['launch_ms'] == [F, F] and rep['kept'] == [0, 1]
+
+
+def test_a_launch_that_is_not_write_bound_takes_the_first_buffers():
+    bufs, rep, t = ring([5.1, 5.1, 5.1], fill=1.9)                              # the uint8 mode: 5.1 ms against a 1.9 ms fill
+    assert rep['write_bound'] is False and rep['kept'] == [0, 1] and len(rep['launch_ms']) == 2 and rep['fast'] is None

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Randomised raster parity runs of round 3 (on the GPU box, via gpurun): the persistent fused kernel (256 x 256 and above), the split form
-# K3s + K3r (below 160 x 160 float32 / 224 x 224 uint8), both output types, and the third family of VERDICT r2: resolutions 4 .. 60,
+# K3s + K3r (up to 144 x 144 float32 / 208 x 208 uint8), both output types, and the third family of VERDICT r2: resolutions 4 .. 60,
 # fields of view 5 .. 200 m, on Town02.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/r03_fuzz_raster.log

@@ -65,6 +65,12 @@ _SIGNATURES = {
     'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
     'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _i32, _vp],
+    'tds_buffer_create': [_i64, _i32, _i32, ctypes.POINTER(_vp)],
+    'tds_buffer_ptr': [_vp],
+    'tds_buffer_info': [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i32)],
+    'tds_buffer_destroy': [_vp],
+    'tds_torch_alloc': [ctypes.c_size_t, _i32, _vp],
+    'tds_torch_free': [_vp, ctypes.c_size_t, _i32, _vp],
     'tds_lanelet_centerline_f64': [_vp, _i32, _vp, _i32, _vp, ctypes.POINTER(_i32)],
     'tds_lanes_create': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, ctypes.POINTER(_vp)],
     'tds_lanes_destroy': [_vp],
@@ -75,6 +81,9 @@ _SIGNATURES = {
     'tds_lanelet_directions_f64': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _vp],
 }
 
+
+#: entry points that do not return an error code
+_RESTYPES = {'tds_buffer_ptr': _vp, 'tds_torch_alloc': _vp, 'tds_torch_free': None}
 
 #: entry points that only libtdship_testing.so exports (include/tdship.h, "testing hooks")
 _TESTING_SIGNATURES = {
@@ -109,7 +118,7 @@ def _load(path, signatures):
     for name, argtypes in signatures.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
     return L
 
 
@@ -149,7 +158,8 @@ def last_error():
     return buf.value.decode(errors='replace')
 
 
-E_INVAL, E_HIP, E_LIMIT = -1, -2, -4          # TDS_EINVAL, TDS_EHIP, TDS_ELIMIT of include/tdship.h
+E_INVAL, E_HIP, E_NOMEM, E_LIMIT = -1, -2, -3, -4          # TDS_EINVAL, TDS_EHIP, TDS_ENOMEM, TDS_ELIMIT of include/tdship.h
+BUFFER_DENSE = 1
 
 
 class TdsError(RuntimeError):

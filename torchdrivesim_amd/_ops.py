@@ -3,8 +3,10 @@ Tensor-level entry points of the HIP kernels (device tensors in, device tensors 
 stream through the C ABI of include/tdship.h).  The reference-shaped classes in kinematic.py, infractions.py,
 rendering/ and simulator.py are thin layers over these.
 """
+import atexit
 import collections
 import ctypes
+import sys
 import threading
 
 import numpy as np
@@ -424,10 +426,98 @@ def _raster_workspace(dev, n_img, res):
     return ws if ws is not False else None
 
 
+# ---- where the images live --------------------------------------------------------------------------------------------------------
+#: The raster launch is bound by the HBM write stream, and what that stream reaches depends on the PHYSICAL pages under the image: about one
+#: large hipMalloc in three is served at 7/8 of the rate for as long as it lives, a buffer whose pages are spread out never was (csrc/alloc.hip,
+#: DESIGN.md section 4).  So images of SPREAD_MIN bytes and more are not taken from torch's default pool but from a torch memory pool whose
+#: blocks the library builds (tds_torch_alloc / tds_torch_free behind torch.cuda.memory.CUDAPluggableAllocator): the reference-shaped call
+#: `render_egocentric()` -- a fresh tensor per call, rendering/cv2.py:52 -- gets such a block, cached and stream-ordered by torch's
+#: allocator like any other.  False: plain torch.empty (tests, tools/alloc experiments).
+use_image_pool = True
+SPREAD_MIN = 256 << 20
+_image_pools = {}            # device index -> torch.cuda.MemPool
+_pool_allocators = []        # the pluggable allocators behind them: they must outlive every pool, so they live as long as the process
+
+
+def image_pool(device):
+    """The torch memory pool of `device` whose blocks have spread-out physical pages (one per device, created on first use)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _image_pools.get(idx)
+    if pool is None:
+        nat.lib()                                         # fails loudly when the library is missing
+        if not _pool_allocators:
+            _pool_allocators.append(torch.cuda.memory.CUDAPluggableAllocator(nat.LIB_PATH, 'tds_torch_alloc', 'tds_torch_free'))
+            atexit.register(release_image_pool)           # the pools go before the interpreter takes the allocator apart
+        pool = _image_pools[idx] = torch.cuda.MemPool(_pool_allocators[0].allocator())
+    return pool
+
+
+def release_image_pool(device=None) -> None:
+    """Drop the image pool(s): their cached blocks go back to the driver once the tensors in them are gone."""
+    for idx in list(_image_pools) if device is None else [torch.device(device).index or 0]:
+        pool = _image_pools.pop(idx, None)
+        del pool                                          # the pool dies here, while its allocator is alive
+
+
+def empty_image(shape, dtype, device) -> torch.Tensor:
+    """torch.empty for a rendered image: from the image pool when it is large enough for the placement to matter"""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    device = torch.device(device)
+    if not use_image_pool or nbytes < SPREAD_MIN or device.type != 'cuda' or torch.cuda.is_current_stream_capturing():
+        return torch.empty(shape, dtype=dtype, device=device)
+    with torch.cuda.use_mem_pool(image_pool(device), device=device):
+        return torch.empty(shape, dtype=dtype, device=device)
+
+
+class _OwnedBuffer:
+    """a tds_buffer (csrc/alloc.hip) exposed through __cuda_array_interface__: torch.as_tensor(...) keeps it alive, the buffer goes back
+    to the driver when the last tensor over it is gone"""
+
+    def __init__(self, shape, dtype, device, dense=False):
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        n = 1
+        for d in shape:
+            n *= int(d)
+        self.handle = ctypes.c_void_p()
+        nat.check(nat.lib().tds_buffer_create(max(n * torch.empty((), dtype=dtype).element_size(), 1), idx, nat.BUFFER_DENSE if dense else 0,
+                                              ctypes.byref(self.handle)), 'tds_buffer_create')
+        self._lib = nat.lib()
+        typestr = {torch.float32: '<f4', torch.uint8: '|u1', torch.int32: '<i4'}[dtype]
+        self.__cuda_array_interface__ = dict(shape=tuple(int(d) for d in shape), typestr=typestr, data=(int(self._lib.tds_buffer_ptr(self.handle)), False),
+                                             version=2, strides=None)
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h and not sys.is_finalizing():                  # at interpreter shutdown the driver takes the memory back itself
+
+            try:
+                torch.cuda.synchronize(self.device)            # nothing in flight may still write to pages that are about to be unmapped
+            except Exception:                                  # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._lib.tds_buffer_destroy(h)
+
+
+def owned_image(shape, dtype=torch.float32, device="cuda", dense=False) -> torch.Tensor:
+    """A caller-owned image buffer with spread-out physical pages that does NOT go through torch's caching allocator (long-lived output
+    rings: rendering.allocate_image_ring); freed when the tensor and all its views are gone."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    return torch.as_tensor(_OwnedBuffer(shape, dtype, device, dense=dense), device=device)
+
+
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
 raster_events = None
 #: the same for the launches of the raster backward kernel
 raster_bwd_events = None
+#: calls of raster_scene so far in this process (bench.py reports which of them its timed region was, so that a kernel trace of the run can
+#: be cut to exactly those launches: tools/make_profiles.py)
+raster_calls = 0
 
 
 def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, out_dtype=torch.float32, out=None, key_table=None,
@@ -450,9 +540,16 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
         mask = mask.contiguous().view(u8) if mask.dtype == torch.bool else _c(mask, u8)
     assert out_dtype in (torch.float32, torch.uint8)
     if out is None:
-        out = torch.empty((B, Nc, 3, res, res), dtype=out_dtype, device=dev)
+        out = empty_image((B, Nc, 3, res, res), out_dtype, dev)
     else:
-        assert out.shape == (B, Nc, 3, res, res) and out.dtype == out_dtype and out.is_contiguous()
+        # a real error, not an assert (python -O strips those), on anything the kernel's 16-byte non-temporal stores cannot take
+        if tuple(out.shape) != (B, Nc, 3, res, res) or out.dtype != out_dtype or not out.is_contiguous():
+            raise RuntimeError(f'`out` must be a contiguous {out_dtype} tensor of shape {(B, Nc, 3, res, res)}, got {out.dtype} {tuple(out.shape)}'
+                               f'{"" if out.is_contiguous() else " (not contiguous)"}')
+        if out.device != dev:
+            raise RuntimeError(f'`out` is on {out.device}, the cameras on {dev}')
+        if out.data_ptr() % 16 != 0:
+            raise RuntimeError('`out` must be 16-byte aligned (a view with an odd storage offset is not)')
     p = lambda t, d, nme: nat.dev_ptr(t, d, nme) if N > 0 else None
     mode = nat.OUT_F32 if out_dtype == torch.float32 else nat.OUT_U8
     # distinct actor keys (host side): enables the bit-plane kernel.  Callers that know them (Simulator) pass `key_table`;
@@ -497,6 +594,8 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
              nat.dev_ptr(extra_tri, f32, 'extra_tri') if K > 0 else None, nat.dev_ptr(extra_key, i32, 'extra_key') if K > 0 else None, K,
              None if aux is None else ctypes.cast(ctypes.pointer(aux), ctypes.c_void_p), nat.stream_ptr(dev))
 
+    global raster_calls
+    raster_calls += 1
     try:
         launch(aux)
     except nat.TdsError as e:

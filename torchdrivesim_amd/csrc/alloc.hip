@@ -1,0 +1,186 @@
+// Output buffers whose PHYSICAL pages are spread out (include/tdship.h: tds_buffer_*, tds_torch_alloc / tds_torch_free).
+//
+// Why the library has an allocator at all.  The rasteriser is bound by the HBM write stream (51.5 GB per launch at B = 1024 x A = 64 x 256 x 256),
+// and on MI355X what a write stream reaches depends on the PHYSICAL pages under the buffer: a 51.5 GB hipMalloc is served at one of three
+// rates for as long as it lives -- 7.03 ms per launch, x 16/15 (7.45 ms) or x 8/7 (8.05 ms) -- whatever the virtual address (one
+// hipMemCreate handle mapped at thirteen alignments between 2 MiB and 64 GiB: the same time everywhere, so it is neither the address nor
+// the PTE fragment size), whatever the store pattern (contiguous eighths per XCD, eighths interleaved in chunks of 6 MB .. 3 GB, a rotated
+// column order, a plain front-to-back fill: a slow buffer stays at its 8/7), about one allocation in three.  The ratios read like a load
+// imbalance over 16 units of the memory system that a physically contiguous range of this size can fall into and a scattered one cannot:
+// 1 GiB contiguous chunks all fill at 5.8 TB/s while the driver's scattered leftovers reach 7.0, and buffers assembled from chunks whose
+// physical addresses are spread over TWICE the range were fast in 18 of 18 cases (tools/alloc_probe.hip, profiles/r04_alloc_probe.log;
+// DESIGN.md section 4).  So a buffer is built from chunks of 8 MiB created alternately with spacer chunks that are released once the buffer is
+// mapped (hipMemCreate / hipMemMap): the chunks end up about 16 MiB apart in physical memory and the holes go back to the driver.
+//
+// The reference allocates its image per call (rendering/cv2.py:52: np.zeros); here the Python host routes the image allocations of HipRenderer
+// through a torch memory pool that is served by tds_torch_alloc / tds_torch_free, so that `render_egocentric()` without `out=` gets such a
+// buffer too, cached by torch's allocator like any other block.
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "tds_common.h"
+
+struct tds_buffer {
+    void *ptr = nullptr;
+    size_t bytes = 0, reserved = 0, mapped = 0;
+    int device = 0;
+    int spread = 0;                                 // 1: chunks with spacers, 0: plain hipMalloc
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+
+namespace {
+constexpr size_t CHUNK = (size_t)8 << 20;           // 8 MiB (8 / 64 MiB / 1 GiB chunks were all fast; 8 MiB was the fastest: 7.00 - 7.02 ms)
+constexpr size_t SPREAD_MIN = (size_t)256 << 20;    // below this a buffer is one hipMalloc (a launch into it is too short to tell)
+
+void release(tds_buffer *b) {
+    if (b->spread) {
+        if (b->ptr && b->mapped) (void)hipMemUnmap(b->ptr, b->mapped);
+        for (auto h : b->handles) (void)hipMemRelease(h);
+        if (b->ptr) (void)hipMemAddressFree(b->ptr, b->reserved);
+    } else if (b->ptr) {
+        (void)hipFree(b->ptr);
+    }
+    b->ptr = nullptr;
+    b->handles.clear();
+}
+
+// -> TDS_OK and a mapped buffer, or an error code with nothing held
+int create_spread(tds_buffer *b, size_t bytes, int device) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    const size_t n = (bytes + CHUNK - 1) / CHUNK, total = n * CHUNK;
+    b->spread = 1;
+    b->reserved = total;
+    b->bytes = bytes;
+    b->device = device;
+    hipError_t e = hipMemAddressReserve(&b->ptr, total, (size_t)2 << 20, nullptr, 0);
+    if (e != hipSuccess) { b->ptr = nullptr; tds::set_error("tds_buffer_create: reserving %zu bytes of address space failed: %s", total, hipGetErrorString(e)); return TDS_EHIP; }
+    std::vector<hipMemGenericAllocationHandle_t> spacers;
+    spacers.reserve(n);
+    b->handles.reserve(n);
+    bool spacing = true;
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, CHUNK, &prop, 0);
+        if (e != hipSuccess && !spacers.empty()) {
+            // out of memory with the spacers held: give them back and go on without (the rest of the buffer is then as dense as a hipMalloc)
+            for (auto sp : spacers) (void)hipMemRelease(sp);
+            spacers.clear();
+            spacing = false;
+            (void)hipGetLastError();
+            e = hipMemCreate(&h, CHUNK, &prop, 0);
+        }
+        if (e != hipSuccess) break;
+        b->handles.push_back(h);
+        if (spacing) {
+            hipMemGenericAllocationHandle_t sp;
+            if (hipMemCreate(&sp, CHUNK, &prop, 0) == hipSuccess) spacers.push_back(sp);
+            else { spacing = false; (void)hipGetLastError(); }
+        }
+    }
+    for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+        e = hipMemMap((char *)b->ptr + i * CHUNK, CHUNK, 0, b->handles[i], 0);
+        if (e == hipSuccess) b->mapped = (i + 1) * CHUNK;
+    }
+    for (auto sp : spacers) (void)hipMemRelease(sp);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(b->ptr, total, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        tds::set_error("tds_buffer_create: %zu bytes in chunks of %zu failed: %s", bytes, CHUNK, hipGetErrorString(e));
+        (void)hipGetLastError();
+        release(b);
+        return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
+    }
+    return TDS_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
+TDS_EXPORT int tds_buffer_create(int64_t bytes, int device, int flags, tds_buffer_t **out) {
+    TDS_CHECK_ARG(out, "tds_buffer_create: null output");
+    *out = nullptr;
+    TDS_CHECK_ARG(bytes > 0, "tds_buffer_create: %lld bytes", (long long)bytes);
+    TDS_CHECK_ARG((flags & ~TDS_BUFFER_DENSE) == 0, "tds_buffer_create: unknown flags %#x", flags);
+    DeviceGuard guard(device);
+    if (!guard.ok) { tds::set_error("tds_buffer_create: no device %d", device); return TDS_EINVAL; }
+    tds_buffer *b = new tds_buffer();
+    int rc = TDS_OK;
+    if ((flags & TDS_BUFFER_DENSE) || (size_t)bytes < SPREAD_MIN) {
+        b->bytes = (size_t)bytes;
+        b->device = device;
+        hipError_t e = hipMalloc(&b->ptr, (size_t)bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            tds::set_error("tds_buffer_create: hipMalloc of %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e));
+            rc = e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
+        }
+    } else {
+        rc = create_spread(b, (size_t)bytes, device);
+    }
+    if (rc != TDS_OK) { delete b; return rc; }
+    *out = b;
+    return TDS_OK;
+}
+
+TDS_EXPORT void *tds_buffer_ptr(const tds_buffer_t *buf) { return buf ? buf->ptr : nullptr; }
+
+TDS_EXPORT int tds_buffer_info(const tds_buffer_t *buf, int64_t *bytes, int64_t *chunks, int *spread) {
+    TDS_CHECK_ARG(buf, "tds_buffer_info: null buffer");
+    if (bytes) *bytes = (int64_t)buf->bytes;
+    if (chunks) *chunks = (int64_t)buf->handles.size();
+    if (spread) *spread = buf->spread;
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_buffer_destroy(tds_buffer_t *buf) {
+    if (!buf) return TDS_OK;
+    DeviceGuard guard(buf->device);
+    release(buf);
+    delete buf;
+    return TDS_OK;
+}
+
+// ---- the two entry points a torch.cuda.memory.CUDAPluggableAllocator binds (signatures fixed by torch: plain C types) ---------------------
+namespace {
+std::mutex g_mu;
+std::unordered_map<void *, tds_buffer *> g_live;
+}  // namespace
+
+TDS_EXPORT void *tds_torch_alloc(size_t size, int device, void *stream) {
+    (void)stream;
+    tds_buffer_t *b = nullptr;
+    if (tds_buffer_create((int64_t)(size ? size : 1), device, 0, &b) != TDS_OK) return nullptr;      // torch reports the failure (out of memory)
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_live[b->ptr] = b;
+    return b->ptr;
+}
+
+TDS_EXPORT void tds_torch_free(void *ptr, size_t size, int device, void *stream) {
+    (void)size; (void)device; (void)stream;
+    tds_buffer *b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto it = g_live.find(ptr);
+        if (it == g_live.end()) return;
+        b = it->second;
+        g_live.erase(it);
+    }
+    (void)tds_buffer_destroy(b);
+}

@@ -471,8 +471,8 @@ TDS_EXPORT int tds_collision_bwd_f32(const float *boxes, const float *sc, const 
     TDS_CHECK_ARG(metric == TDS_METRIC_IOU || metric == TDS_METRIC_DISCS, "tds_collision_bwd_f32: unknown metric %d", metric);
     TDS_CHECK_ARG(grad_boxes && grad_sc, "tds_collision_bwd_f32: null gradient outputs");
     if (B == 0 || N == 0) return TDS_OK;
-    TDS_HIP(hipMemsetAsync(grad_boxes, 0, (size_t)B * N * 5 * sizeof(float), (hipStream_t)stream));
-    TDS_HIP(hipMemsetAsync(grad_sc, 0, (size_t)B * N * 2 * sizeof(float), (hipStream_t)stream));
+    TDS_HIP(tds::zero_async(grad_boxes, (size_t)B * N * 5 * sizeof(float), (hipStream_t)stream));
+    TDS_HIP(tds::zero_async(grad_sc, (size_t)B * N * 2 * sizeof(float), (hipStream_t)stream));
     if (A == 0) return TDS_OK;
     TDS_CHECK_ARG(boxes && sc && present && grad_out, "tds_collision_bwd_f32: null pointer");
     dim3 grid((unsigned)((B * A * 64 + GBLOCK - 1) / GBLOCK));              // one wavefront per (scene, agent)

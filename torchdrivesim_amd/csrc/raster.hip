@@ -1951,14 +1951,25 @@ constexpr int pair_tab_dw() { return 3 * (1 << (2 * NB)) * (int)sizeof(typename 
 // symmetric.  With equal shares the even XCDs of this part finish their eighth 9 % (float32: 6.5 against 7.1 ms; on a "slow" output
 // allocation 7.2 against 8.3 ms) before the odd ones, which then write the tail at half the aggregate bandwidth (tools/xcd_finish_times.py;
 // the imbalance is in the store stream: a launch that rasterises nothing shows it, a launch that stores nothing does not).
-// `queue`: 8 counters, zero at launch (the host clears a slot of a small pool in stream order).  A workgroup reads the XCD it runs on
-// from the XCC_ID hardware register.
+// `queue`: 8 counters, zero at launch: the last 64 bytes of the CALLER's workspace, cleared in stream order right before the launch (the
+// library owns no device memory besides the map handles).  A workgroup reads the XCD it runs on from the XCC_ID hardware register.
+// Without a workspace there is no queue and the same kernel runs one workgroup per item (claim_work).
 constexpr int BITS_FIXED_DW = 20;             // [0..14] ascending key table, [15] next chunk of the grid scan, [16] the work item taken next,
                                               // [17] queues this workgroup has found empty
 // one thread: take the next item -- own queue first, then the others in cyclic order -- and leave it in state[0] (-1: nothing left);
 // state[1] = queues of that order already found empty by this workgroup.  Everything a workgroup carries from item to item lives in
 // LDS: the kernel has no register to spare
 __device__ __noinline__ void claim_work(uint32_t *queue, int nblk, uint32_t *state, const uint32_t *only, int strips) {
+    if (queue == nullptr) {
+        // no queue (the caller gave no workspace): ONE item per workgroup, by blockIdx -- the launch then has one workgroup per item.
+        // state[1] doubles as "this workgroup has had its item"
+        int64_t img;
+        int strip;
+        block_to_image(nblk, strips, img, strip);
+        state[0] = state[1] == 0 ? (uint32_t)(img * strips + strip) : 0xffffffffu;
+        state[1] = 1;
+        return;
+    }
     if (only != nullptr) {
         // the launch that follows the split form: only the cameras K3s marked (only[0] of them, listed from only[1]), one queue
         const uint32_t j = atomicAdd(&queue[0], 1u), n = only[0] * (uint32_t)strips;
@@ -2284,39 +2295,32 @@ int g_bits_waves = 4;
 int g_list_waves = 0;            // waves per workgroup of K3r (0: by image size; testing hook)
 int g_list_lds_kb = 40;          // K3r picks the widest strip whose workgroup needs at most this much LDS (testing hook)
 
-// The work queues of a persistent bit-plane launch: 8 counters (64 bytes) that must be zero when the kernel starts.  A launch takes the
-// next slot of a small per-device pool and clears it in stream order right before the kernel; SLOTS launches can be in flight before a
-// slot comes round again (a launch is milliseconds of work on a device that runs a handful of streams).
-constexpr int QUEUE_SLOTS = 1024, QUEUE_DEVICES = 64;
-uint32_t *g_queue_pool[QUEUE_DEVICES] = {nullptr};
-std::atomic<unsigned> g_queue_next{0};
-std::mutex g_queue_mu;
-int work_queue(hipStream_t stream, uint32_t **out) {
-    int dev = 0;
-    TDS_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= QUEUE_DEVICES) { tds::set_error("tds_raster_scene: device index %d out of range", dev); return TDS_ELIMIT; }
-    {
-        std::lock_guard<std::mutex> lock(g_queue_mu);
-        if (g_queue_pool[dev] == nullptr) {
-            void *p = nullptr;
-            TDS_HIP(hipMalloc(&p, (size_t)QUEUE_SLOTS * 64));
-            g_queue_pool[dev] = (uint32_t *)p;
-        }
-    }
-    uint32_t *slot = g_queue_pool[dev] + (size_t)(g_queue_next.fetch_add(1u) % QUEUE_SLOTS) * 16;
-    TDS_HIP(hipMemsetAsync(slot, 0, 64, stream));
-    *out = slot;
-    return TDS_OK;
+// The work queues of a persistent bit-plane launch: 8 counters (64 bytes) that must be zero when the kernel starts.  They live at the
+// END of the caller's workspace (tds_raster_scene_workspace_bytes provides for them) and are cleared in stream order right before the
+// launch.  Two launches that may overlap in time must not share a
+// workspace; that already holds for the face lists.  The library allocates nothing per call.
+constexpr int64_t QUEUE_BYTES = 64;
+// (cleared by tds::zero_async, a kernel: see there why not hipMemsetAsync)
+// splits the caller's workspace: -> queue (nullptr when there is no room for one), `bytes` is cut to what is left for the lists
+inline uint32_t *workspace_queue(void *workspace, int64_t &bytes) {
+    if (workspace == nullptr || bytes < QUEUE_BYTES + 64) return nullptr;
+    const int64_t off = (bytes - QUEUE_BYTES) & ~(int64_t)63;
+    bytes = off;
+    return (uint32_t *)((char *)workspace + off);
 }
 // workgroups of a persistent launch: enough to fill every CU at the kernel's occupancy twice over (a workgroup that finds the queues empty
 // leaves at once; the surplus takes the place of workgroups that could not start with the others because another stream's kernel held
 // their slots)
 int persistent_grid(int64_t items) {
-    static int cus = 0;
+    constexpr int MAX_DEVICES = 64;
+    static std::atomic<int> cus_of[MAX_DEVICES];          // per device: a process may drive several (zero-initialised: not looked up yet)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = -1;
+    if (dev >= 0) cus = cus_of[dev].load(std::memory_order_relaxed);
     if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
+        int n = 0;
+        cus = (dev >= 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        if (dev >= 0) cus_of[dev].store(cus, std::memory_order_relaxed);
     }
     const int64_t cap = (int64_t)cus * 8;
     return (int)(items < cap ? items : cap);
@@ -2458,6 +2462,8 @@ static int common_checks(const char *fn, int64_t n_img, int res, int out_mode, c
 namespace {
 constexpr int DEFAULT_CAPS = 512;         // faces per strip list that the recommended workspace provides
 constexpr int LIST_CAPS = 2048;           // faces per camera list of the split bit-plane path that the recommended workspace provides
+// the split form (K3s + K3r) serves resolutions up to these; above, the fused launch hides the scan behind its write stream or its row loops
+constexpr int SPLIT_MAX_RES_F32 = 144, SPLIT_MAX_RES_U8 = 208;
 inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
     return n_img * strips * ((int64_t)caps * (int64_t)sizeof(uint4) + (int64_t)sizeof(uint32_t));
 }
@@ -2477,8 +2483,13 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
     *bytes = 0;
     if (tw != 0 && (res + tw - 1) / tw <= MAX_STRIPS) *bytes = ws_bytes_for(n_img, (res + tw - 1) / tw, DEFAULT_CAPS);
     // the split bit-plane path: a marker list, a count and a list of LIST_CAPS faces (16 bytes each) per camera
+    // (only where the split form can be chosen for either output type; the testing build can force it anywhere)
     const int64_t lists = (((n_img + 1) * 4 + 255) & ~(int64_t)255) + ((n_img * 4 + 255) & ~(int64_t)255) + n_img * LIST_CAPS * 16;
+#ifndef TDS_TESTING
+    if (res <= (SPLIT_MAX_RES_F32 > SPLIT_MAX_RES_U8 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8))
+#endif
     if (lists > *bytes) *bytes = lists;
+    *bytes = ((*bytes + 63) & ~(int64_t)63) + QUEUE_BYTES + 64;          // + the work queues of a persistent launch, at the end (workspace_queue)
     return TDS_OK;
 }
 
@@ -2538,6 +2549,8 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
     TDS_CHECK_ARG(N == 0 || (state && agent_sc && tmpl && actor_key && mask), "tds_raster_scene: null agent arrays");
     TDS_CHECK_ARG(scale > 0.0f, "tds_raster_scene: scale must be positive");
     TDS_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "tds_raster_scene: bad workspace");
+    TDS_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "tds_raster_scene: the workspace must be 16-byte aligned");
+    uint32_t *const ws_queue = workspace_queue(workspace, workspace_bytes);          // the tail of the workspace: work queues of a persistent launch
     SceneArgsEx a;
     a.map = ms.one; a.views = ms.views; a.scene_map = ms.scene_map; a.state = (const float4 *)state; a.agent_sc = (const float2 *)agent_sc; a.tmpl = (const float2 *)tmpl;
     a.actor_key = actor_key; a.mask = mask; a.N = (int)N; a.Nc = (int)Nc; a.key_per_cam = actor_key_per_camera ? 1 : 0;
@@ -2597,7 +2610,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                     const bool f32 = out_mode == TDS_OUT_F32;
                     // measured at B = 1024 x 64 (fused / split, ms): float32 96 x 96 3.89 / 3.17, 128 3.95 / 3.60, 160 4.33 / 4.79; uint8 128 4.03 / 3.04,
                     // 192 4.53 / 4.34, 256 5.3 / 5.9 -- from there on the fused launch hides the scan behind its write stream or its row loops
-                    bool split = !want_slices && nwv == 4 && workspace != nullptr && res <= (f32 ? 144 : 208);
+                    bool split = !want_slices && nwv == 4 && workspace != nullptr && res <= (f32 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8);
                     if (TDS_DBG(g_debug) & 8192) split = false;                              // testing: the fused kernel everywhere
                     if (TDS_DBG(g_debug) & 16384) split = !want_slices && nwv == 4 && workspace != nullptr;      // testing: the split form everywhere
                     const size_t off_counts = (((size_t)n_img + 1) * 4 + 255) & ~(size_t)255;
@@ -2617,7 +2630,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                         const size_t lds_s = bits_lds_bytes(kt.n, res, tws, lw, out_mode);
                         if (lds_s <= 150 * 1024) {
                             if (aux) { aux->n_keys = kt.n; aux->index_bits = nb; for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
-                            if (hipMemsetAsync(poisoned, 0, 4, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the workspace failed"); return TDS_EHIP; }
+                            if (tds::zero_async(poisoned, 4, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the workspace failed"); return TDS_EHIP; }
                             CommonArgs cs = cm;
                             cs.strips = 1; cs.slices = nullptr;
                             const dim3 sgrid((unsigned)((n_img + SCAN_WAVES - 1) / SCAN_WAVES));
@@ -2646,11 +2659,12 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                 // the instantiations for three workgroups per CU are persistent launches: their workgroups take (camera, strip) items from per-XCD
                 // queues (see claim_work); the others get one workgroup per item
                 if (only != nullptr) four_per_cu = false;          // the launch over the marked cameras takes its items from a queue: a persistent instantiation
-                const bool persist = nwv == 4 && (!four_per_cu || cb.slices != nullptr);
+                // (without a workspace there is no queue: the same kernels then run one workgroup per item)
+                const bool persist = nwv == 4 && (!four_per_cu || cb.slices != nullptr) && ws_queue != nullptr;
                 uint32_t *queue = nullptr;
                 if (persist) {
-                    rc = work_queue((hipStream_t)stream, &queue);
-                    if (rc != TDS_OK) return rc;
+                    queue = ws_queue;
+                    if (tds::zero_async(queue, (size_t)QUEUE_BYTES, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the work queues failed"); return TDS_EHIP; }
                 }
                 dim3 grid((unsigned)(persist ? persistent_grid(only != nullptr ? 512 : n_img * cb.strips) : n_img * cb.strips));
                 const SceneArgs base = a;

@@ -42,6 +42,20 @@ void set_error(const char *fmt, ...);
 
 constexpr int WAVE = 64;
 
+// Zeroing device words in stream order with a KERNEL, never with hipMemsetAsync: on ROCm 7.0 a memset node of a captured graph is not
+// ordered before the kernel node that follows it (a replayed raster launch found its work queues uncleared: tests/test_gpu_graph.py),
+// kernel nodes are.  `words` 4-byte words at a 4-byte aligned address.
+static __global__ void zero_words_kernel(uint32_t *p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+inline hipError_t zero_async(void *p, size_t bytes, hipStream_t stream) {
+    const size_t words = bytes / 4;
+    if (words == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)(words < 256 ? 1 : (words / 256 < 2048 ? words / 256 : 2048));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(words < 256 ? 64 : 256), 0, stream, (uint32_t *)p, words);
+    return hipGetLastError();
+}
+
 // ---- static map handle (device side view is MapView) -------------------------------------------------------
 struct GridEntry {          // 32 bytes, one per (cell, face whose bounding box touches the cell)
     float x0, y0, x1, y1, x2, y2;   // world coordinates of the three vertices

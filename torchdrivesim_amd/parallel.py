@@ -70,6 +70,16 @@ def gather_over_ranks(value: float, device='cpu'):
     return [float(t.item()) for t in out]
 
 
+def gather_objects_over_ranks(obj):
+    """list of every rank's (picklable) object, in rank order (one element without a process group) -- reporting only, never data"""
+    d = _dist()
+    if d is None:
+        return [obj]
+    out = [None] * d.get_world_size()
+    d.all_gather_object(out, obj)
+    return out
+
+
 def aggregate_throughput(units_this_rank: float, elapsed_this_rank: float, device='cpu') -> float:
     """whole-job rate = units processed by all ranks / slowest rank's time"""
     return sum_over_ranks(units_this_rank, device) / max_over_ranks(elapsed_this_rank, device)

@@ -109,53 +109,92 @@ class HipRenderer(BirdviewRenderer):
                                  key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)
 
 
-def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 5, reps: int = 2, spread: float = 1.03,
-                        repeat_fast: bool = True):
-    """`count` caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), chosen as
-    the fastest of up to `candidates` allocations of `shape`.
+class _DeviceTimer:
+    """what allocate_image_ring measures, on the device (tests inject their own timer with the same three methods)"""
 
-    Why choose: the rasteriser is bound by the write stream, and on MI355X what the write stream of its launch reaches depends on the
-    ALLOCATION it writes to -- a 51.5 GB tensor is either "fast" (7.1 ms per launch) or "slow" (8.3 ms: every XCD's stores are 13 - 16 %
-    slower), for as long as it lives, whichever kernel touches it first and wherever it lies; about every second allocation of a fresh
-    process is slow (tools/slow_buffer_probe.py, tools/xcd_finish_times.py).  A loop that owns its observation ring can
-    pay for that once, at start-up: allocate candidates one after the other, time a launch into each, stop as soon as the `count` fastest
-    lie within `spread` of each other (the first two, when both are fast), keep those and free the rest.  The candidates are all held until
-    the choice is made -- a slow allocation that is freed early would be handed out again -- so `candidates` x the buffer must fit the
-    device (it is cut to what does).
-    `repeat_fast`: when fewer than `count` candidates are fast, the returned list repeats the fast ones (a shorter ring) instead of taking a slow one.
-    Returns (buffers, report) with report = dict(first_touch_ms=[...], launch_ms=[...], kept=[indices]) over the candidates tried.
-    The candidates that are not kept go back to the driver (torch.cuda.empty_cache) so that a later allocation does not get them again."""
-    device = torch.device(device)
-    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-    free, _ = torch.cuda.mem_get_info(device)
-    n_max = max(count, min(candidates, int((free - (4 << 30)) // max(nbytes, 1))))
-    cands, first, best = [], [], []
-    while len(cands) < n_max:
-        buf = torch.empty(shape, dtype=dtype, device=device)
-        cands.append(buf)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 2)]
+    def __init__(self, render, device, reps):
+        self.render, self.device, self.reps = render, device, reps
+
+    def _ms(self, fn, reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         ev[0].record()
-        render(buf)                                    # first touch: maps the memory
-        ev[1].record()
         for r in range(reps):
-            render(buf)
-            ev[2 + r].record()
-        torch.cuda.synchronize(device)
-        first.append(ev[0].elapsed_time(ev[1]))
-        best.append(min(ev[1 + r].elapsed_time(ev[2 + r]) for r in range(reps)))
-        if len(cands) >= max(count, 2):
-            top = sorted(best)[:count]
-            if top[-1] <= spread * min(best) and (count > 1 or len(cands) > 1):
-                break
+            fn()
+            ev[r + 1].record()
+        torch.cuda.synchronize(self.device)
+        return [ev[r].elapsed_time(ev[r + 1]) for r in range(reps)]
+
+    def first_touch(self, buf) -> float:
+        return self._ms(lambda: self.render(buf), 1)[0]
+
+    def launch(self, buf) -> float:
+        return min(self._ms(lambda: self.render(buf), self.reps))
+
+    def fill(self, buf) -> float:
+        return min(self._ms(lambda: buf.fill_(0), 2))
+
+
+def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 4, reps: int = 2, fast: float = 0.98,
+                        allow_aliasing: bool = False, timer=None, alloc=None):
+    """`count` DISTINCT caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), each
+    checked to be one the write stream of the launch is served at full rate into.
+
+    Why check: the rasteriser is bound by the write stream, and on MI355X what a write stream reaches depends on the PHYSICAL pages under the
+    buffer -- a 51.5 GB hipMalloc is served at 1, 15/16 or 7/8 of the rate (7.03 / 7.45 / 8.05 ms per launch) for as long as it lives,
+    about one in three at 7/8, while torch's fill_ takes 7.4 - 7.5 ms on all of them (tools/alloc_probe.hip).  The
+    buffers here come from `_ops.owned_image` -- the library's allocator that spreads the physical pages out (csrc/alloc.hip), which has not
+    produced a slow buffer yet -- and every candidate is still MEASURED, against an absolute yardstick of the same run:
+        a candidate is fast  iff  its launch takes at most `fast` x the fill_ time (the fastest fill_ seen over the candidates).
+    Candidates are allocated one after the other and all held until the choice is made (a rejected allocation that is freed would be handed
+    out again); the search ends as soon as `count` fast ones exist, and never before unless `candidates` (cut to what the device holds)
+    are exhausted.  When fewer than `count` are fast, the ring is filled up with the best of the others -- still distinct buffers: step i
+    renders while the consumer of step i - 1 holds the other buffer, so an aliased ring would overwrite a live observation.
+    `allow_aliasing=True` (a loop that consumes every image before the next render) repeats the fast buffer(s) instead; the report says so.
+    A launch that takes more than 1.5 x the fill_ is not bound by the write stream (uint8 output, low resolutions): placement does not
+    matter there and the first `count` candidates are taken.
+    `timer`: an object with first_touch(buf) / launch(buf) / fill(buf) -> ms (tests); `alloc(shape, dtype, device)`: the allocator.
+    Returns (buffers, report); report = dict(first_touch_ms, launch_ms, fill_ms (the yardstick), fast=[bool per candidate], kept=[indices],
+    aliased=bool, write_bound=bool)."""
+    device = torch.device(device)
+    alloc = alloc if alloc is not None else _ops.owned_image
+    timer = timer if timer is not None else _DeviceTimer(render, device, reps)
+    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    n_max = max(count, candidates)
+    if device.type == 'cuda':
+        free, _ = torch.cuda.mem_get_info(device)
+        # every candidate is held until the choice is made; building one needs twice its size for a moment (the spacers of csrc/alloc.hip)
+        n_max = max(count, min(n_max, int((free - (4 << 30)) // max(nbytes, 1)) - 1))
+    cands, first, best, fills = [], [], [], []
+    write_bound = True
+
+    def is_fast(i):
+        return best[i] <= fast * min(fills)
+
+    while len(cands) < n_max:
+        buf = alloc(shape, dtype, device)
+        cands.append(buf)
+        first.append(timer.first_touch(buf))            # maps the memory
+        fills.append(timer.fill(buf))
+        best.append(timer.launch(buf))                  # last: the buffer is handed over holding a rendered image
+        if len(cands) == 1 and best[0] > 1.5 * fills[0]:
+            write_bound = False
+        if not write_bound and len(cands) >= count:
+            break
+        if write_bound and sum(is_fast(i) for i in range(len(cands))) >= count:
+            break
     order = sorted(range(len(cands)), key=lambda i: best[i])
-    fast = [i for i in order if i == order[0] or best[i] <= spread * best[order[0]]]
-    if len(fast) >= count or not repeat_fast:
-        kept = sorted(order[:count])
+    fast_ones = [i for i in order if is_fast(i)] if write_bound else list(range(len(cands)))
+    aliased = False
+    if len(fast_ones) >= count:
+        kept = sorted(fast_ones[:count])
+    elif allow_aliasing and fast_ones:
+        kept, aliased = [fast_ones[i % len(fast_ones)] for i in range(count)], True
     else:
-        # fewer fast allocations than buffers asked for, and the device holds no more candidates: a shorter ring used in turn (entries
-        # repeat) rather than a slow buffer in it -- the renders of one stream are ordered anyway
-        kept = [fast[i % len(fast)] for i in range(count)]
+        kept = sorted(order[:count])                       # the fast ones and the best of the rest: distinct buffers
     out = [cands[i] for i in kept]
+    report = dict(first_touch_ms=first, launch_ms=best, fill_ms=min(fills), fast=[bool(is_fast(i)) for i in range(len(cands))] if write_bound else None,
+                  kept=kept, aliased=aliased, write_bound=write_bound)
     del cands, buf
-    torch.cuda.empty_cache()
-    return out, dict(first_touch_ms=first, launch_ms=best, kept=kept)
+    if device.type == 'cuda':
+        torch.cuda.empty_cache()
+    return out, report

@@ -278,7 +278,8 @@ class Simulator:
         if self.traffic_controls and getattr(self.birdview_mesh_generator, 'traffic_lights_mesh', None) is None:
             self.birdview_mesh_generator.initialize_traffic_controls_mesh(self.traffic_controls)      # simulator.py:373-374
         self._scene_cache = None        # device-resident static maps + actor templates/keys, rebuilt lazily
-        self._fork = None               # (event, stamp, stream) recorded right before the last raster launch, see _beside_render
+        self._fork = None               # (event, stamp, stream, results) recorded right before the last raster launch, see _beside_render
+        self._fork_used = []            # metrics asked for since then: enqueued ahead of the next raster launch
 
     # ------------------------------------------------------------------------------------------------- properties
     @property
@@ -585,23 +586,38 @@ class Simulator:
 
     # ------------------------------------------------------------------------------------------------- infractions beside the rasteriser
     #: The GymEnv.step body (examples/gym_env.py:83-126 of the reference) is step -> render_egocentric -> compute_collision / compute_offroad /
-    #: compute_wrong_way.  The rasteriser is bound by the HBM write stream and the metrics are compute-light and do not read the image, so the
-    #: metrics that are asked for AFTER a render of the same state can be enqueued on a second HIP stream that waits only for what preceded the
-    #: raster launch (an event, no host synchronisation) and is joined to the caller's stream before the result is handed out: they then run
-    #: beside the rasteriser instead of behind it.  Same kernels, same inputs, same bits.
-    #: OFF by default: the headline raster launch is persistent (its workgroups stay on their CUs until the last image is out), so the metric
-    #: kernels only get the slots they grab in the first microseconds, crawl there (off-road: 0.62 instead of 0.15 ms) and cost the launch more
-    #: than they save (B = 1024: 7.51 ms per step beside, 7.30 behind).  It pays where the metrics are expensive next to
-    #: the image -- small or low-resolution renders, agents that have strayed far from the map (the off-road query then walks grid rings).
+    #: compute_wrong_way.  The rasteriser is bound by the HBM write stream and the metrics are compute-light and do not read the image, so they
+    #: can run on a second HIP stream that waits only for what preceded the raster launch (an event, no host synchronisation) and is joined
+    #: to the caller's stream before a result is handed out.  Same kernels, same inputs, same bits.
+    #: The raster launch is PERSISTENT (its workgroups stay on their CUs until the last image is out), so metric kernels enqueued after it only
+    #: get the slots they grab in the first microseconds (round 3: 7.51 ms per step beside, 7.30 behind).  Hence the metrics a loop asked for
+    #: after its previous render are enqueued on the side stream right BEFORE the next raster launch, from inside `render` (`_mark_fork`):
+    #: they take the CUs they need first, the surplus workgroups of the persistent launch start a few microseconds late and still find work,
+    #: and `compute_*` hands the finished result out.  A metric that was not foreseen runs on the side stream after the launch, as in round 3,
+    #: and is foreseen from then on; one that is no longer asked for is dropped after one step.
     overlap_infractions = False
     _side_streams: Dict[int, Any] = {}
 
     def _fork_sources(self):
         return [self.kinematic_model.get_state(), self.present_mask, self.agent_size, self.agent_type]
 
+    def _side_stream(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        side = Simulator._side_streams.get(idx)
+        if side is None:
+            side = Simulator._side_streams[idx] = torch.cuda.Stream(device=device, priority=-1)
+        return side
+
+    def _metric_fn(self, key):
+        name = key[0]
+        if name == 'collision':
+            return lambda: self._compute_collision(None if key[1] is None else list(key[1]))
+        return {'offroad': self._compute_offroad, 'wrong_way': self._compute_wrong_way}[name]
+
     def _mark_fork(self) -> None:
         """called by render() right before the raster launch: everything the metrics read has been enqueued by now"""
         self._fork = None
+        wanted, self._fork_used = getattr(self, '_fork_used', None) or [], []
         state = self.kinematic_model.get_state()
         if not self.overlap_infractions or not state.is_cuda or self.npc_count > 0:
             return
@@ -610,14 +626,28 @@ class Simulator:
         stream = torch.cuda.current_stream(state.device)
         ev = torch.cuda.Event()
         ev.record(stream)
-        self._fork = (ev, [(t, t._version) for t in srcs], stream)
+        ready = {}
+        if wanted:
+            # the metrics of the previous step, ahead of the raster launch on the side stream
+            side = self._side_stream(state.device)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for key in wanted:
+                    out = self._metric_fn(key)()
+                    out.record_stream(stream)                        # allocated in the side stream's pool, consumed on the caller's stream
+                    ready[key] = out
+            done = torch.cuda.Event()
+            done.record(side)
+            ready = {k: (v, done) for k, v in ready.items()}
+        self._fork = (ev, [(t, t._version) for t in srcs], stream, ready)
 
-    def _beside_render(self, fn):
-        """fn() -> Tensor, on the side stream when a render of exactly this state is in flight on the current stream, else in place"""
+    def _beside_render(self, fn, key=None):
+        """fn() -> Tensor: the result computed ahead of the raster launch when `key` was foreseen, else fn() on the side stream when a
+        render of exactly this state is in flight on the current stream, else in place"""
         fork = self._fork
         if fork is None or not self.overlap_infractions:
             return fn()
-        ev, stamp, main = fork
+        ev, stamp, main, ready = fork
         srcs = self._fork_sources()
         state = srcs[0]
         cached = getattr(self, '_sc_cache', None)
@@ -625,10 +655,13 @@ class Simulator:
                 (torch.is_grad_enabled() and any(t.requires_grad for t in srcs)) or torch.cuda.current_stream(state.device) != main or \
                 cached is None or cached[0] is not state or cached[1] != state._version:
             return fn()
-        idx = state.device.index if state.device.index is not None else torch.cuda.current_device()
-        side = Simulator._side_streams.get(idx)
-        if side is None:
-            side = Simulator._side_streams[idx] = torch.cuda.Stream(device=state.device, priority=-1)
+        if key is not None and key not in self._fork_used:
+            self._fork_used.append(key)                              # foreseen at the next render
+        if key is not None and key in ready:
+            out, done = ready[key]
+            main.wait_event(done)
+            return out
+        side = self._side_stream(state.device)
         side.wait_event(ev)
         with torch.cuda.stream(side):
             out = fn()
@@ -636,6 +669,8 @@ class Simulator:
         done = torch.cuda.Event()
         done.record(side)
         main.wait_event(done)
+        if key is not None:
+            ready[key] = (out, done)                             # asked for again before the next render: the same tensor
         return out
 
     # ------------------------------------------------------------------------------------------------- device scene data
@@ -883,7 +918,7 @@ class Simulator:
     def compute_offroad(self) -> Tensor:
         """BxA off-road loss = thresholded squared corner-to-mesh distance x present (simulator.py:1035-1044).
         The whole road_mesh is the driving surface, lane markings included."""
-        return self._beside_render(self._compute_offroad)
+        return self._beside_render(self._compute_offroad, ('offroad',))
 
     def _compute_offroad(self) -> Tensor:
         state = self.get_state()
@@ -904,7 +939,7 @@ class Simulator:
         """Wrong-way metric per agent, -cos of the angle between the agent and the lane it is on where that angle exceeds
         `cfg.wrong_way_angle_threshold` (simulator.py:607-630 -> infractions.lanelet_orientation_loss), times the present mask.
         Zeros without a lanelet map, as the reference.  `lanelet_map`: a list of B `lanelet2.LaneletMap` or None."""
-        return self._beside_render(self._compute_wrong_way)
+        return self._beside_render(self._compute_wrong_way, ('wrong_way',))
 
     def _compute_wrong_way(self) -> Tensor:
         state = self.get_state()
@@ -939,7 +974,7 @@ class Simulator:
     def compute_collision(self, agent_types: Optional[List[str]] = None) -> Tensor:
         """BxA collision metric of the exposed agents against ALL agents (simulator.py:1161-1194).  For `iou` / `discs`:
         collision_i = sum_j o_ij present_j - max_j o_ij present_j, self overlap assumed to be the max."""
-        return self._beside_render(lambda: self._compute_collision(agent_types))
+        return self._beside_render(lambda: self._compute_collision(agent_types), ('collision', None if agent_types is None else tuple(agent_types)))
 
     def _compute_collision(self, agent_types: Optional[List[str]] = None) -> Tensor:
         metric = self.cfg.collision_metric
