@@ -14,6 +14,9 @@ python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/
 for try in 1 2; do          # two traced runs: the launch time of this kernel differs from process to process on one box (7.2 - 7.9 ms); both are kept
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof_$try.log 2>&1
   cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_$try.csv
+  # the per-dispatch rows of the raster kernel (header + its launches): tools/make_profiles.py cuts them to the launches of the timed region
+  T=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
+  (head -1 $T; grep raster_scene_bits_kernel $T) > $OUT/bench_raster_trace_$try.csv
   rm -rf $OUT/kt
 done
 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_plain_after.log 2>/dev/null
@@ -28,6 +31,7 @@ for t in (1, 2):
             avg[t] = float(r[3])
 best = min(avg, key=avg.get)
 shutil.copy(f'{out}/bench_kernel_stats_{best}.csv', f'{out}/bench_kernel_stats.csv')
+shutil.copy(f'{out}/bench_raster_trace_{best}.csv', f'{out}/bench_raster_trace.csv')
 lines = [l for l in open(f'{out}/bench_under_rocprof_{best}.log') if l.startswith('{')]
 open(f'{out}/bench_under_rocprof.log', 'w').write(''.join(lines))
 open(f'{out}/bench_traced_runs.txt', 'w').write(''.join(f'traced run {t}: raster_scene_bits_kernel average {avg[t] / 1e6:.3f} ms over its launches{" (committed)" if t == best else ""}\n' for t in sorted(avg)))
@@ -42,7 +46,7 @@ for mode in f32 u8; do
   extra=""; [ $mode = u8 ] && extra="--u8"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
-             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC"; do
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
     i=$((i+1))
     rocprofv3 --pmc $set --kernel-include-regex "raster" --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py --batch 1024 --iters 2 $extra > $OUT/p$i.log 2>&1
   done

@@ -32,15 +32,27 @@ for name, cmd in commands.items():
     with open(os.path.join(dst, f'{tag}_{name}_kernel_stats.csv'), 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats -- {cmd}   (MI355X; top 15 kernels by total time; kernel source {stamp})\n')
         if name == 'bench':
-            # what the raster launches of this trace are: the average below is over ALL of them, the bench's figure over the 20 timed ones
+            # what the raster launches of this trace are: the average in the table is over ALL of them; the bench line's figure is over the
+            # launches of its timed region, which the per-dispatch rows of the same trace give too (timed_only_avg_ms)
             try:
                 line = [json.loads(l) for l in open(os.path.join(src, 'bench_under_rocprof.log')) if l.startswith('{')][-1]
-                probe = line['roofline']['ring_probe']
-                f.write(f"# raster_scene_bits_kernel launches of this run: 20 timed + 3 warm-up (HIP events over the 20 timed ones: {line['roofline']['avg_launch_ms']:.3f} ms), "
-                        f"3 per candidate of the image ring incl. its first touch (candidates: {[round(x, 2) for x in probe['launch_ms']]} ms, first touches "
-                        f"{[round(x, 1) for x in probe['first_touch_ms']]} ms, kept {probe['kept']}), 6 of the stream-only reference launch ({line['roofline']['measured_stream_ms']:.2f} ms)\n")
+                roof = line['roofline']
+                probe = roof['ring_probe']
+                f.write(f"# raster_scene_bits_kernel launches of this run, in order: 3 per candidate of the image ring incl. its first touch (candidates "
+                        f"{[round(x, 2) for x in probe['launch_ms']]} ms, first touches {[round(x, 1) for x in probe['first_touch_ms']]} ms, kept {probe['kept']}), "
+                        f"3 warm-up, the 20 of the timed region, 6 of the stream-only reference launch ({roof['measured_stream_ms']:.2f} ms), "
+                        f"23 of the loop without out= (default_path)\n")
+                first, end = roof['timed_raster_calls']
+                rows_t = list(csv.DictReader(open(os.path.join(src, 'bench_raster_trace.csv'))))
+                rows_t.sort(key=lambda r: int(r['Start_Timestamp']))
+                timed = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows_t[first:end]]
+                every = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows_t]
+                avg = sum(timed) / len(timed)
+                f.write(f"# timed_only_avg_ms = {avg:.4f} over launches {first}..{end - 1} of {len(every)} in this trace (min {min(timed):.4f}, max {max(timed):.4f}); "
+                        f"the bench line of the same run says avg_launch_ms = {roof['avg_launch_ms']:.4f} (HIP events), i.e. {100 * (roof['avg_launch_ms'] / avg - 1):+.2f} %; "
+                        f"all_launches_avg_ms = {sum(every) / len(every):.4f}\n")
             except Exception as exc:          # noqa: BLE001
-                f.write(f'# (no bench line beside the trace: {exc})\n')
+                f.write(f'# (no bench line / per-dispatch rows beside the trace: {exc})\n')
         w = csv.writer(f)
         for r in rows[:16]:
             r[0] = r[0][:110]
@@ -81,7 +93,11 @@ for mode, bpp in (('f32', 4), ('u8', 1)):
                # the launch is persistent since round 3 (a wave renders many images): per image and wave of its workgroup, the figure of rounds 1 - 2
                valu_instructions_per_image_and_wave=c.get('SQ_INSTS_VALU', 0) / (B * A * 4),
                lds_bank_conflict_share=c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1),
-               valu_utilisation=c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / max(c.get('SQ_BUSY_CYCLES', 0), 1) if c.get('SQ_BUSY_CYCLES') else None)
+               # SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES: the number of SIMDs with a VALU instruction in flight, averaged over the busy cycles
+               # of a shader engine -- out of its 32 SIMDs... NOT a percentage (the old name `valu_utilisation` had no unit)
+               valu_busy_simds_per_se_of_32=c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / max(c.get('SQ_BUSY_CYCLES', 0), 1) if c.get('SQ_BUSY_CYCLES') else None,
+               # lanes doing work per VALU instruction: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (where the pass collected it)
+               valu_lane_occupancy=(c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU'])) if c.get('SQ_THREAD_CYCLES_VALU') and c.get('SQ_ACTIVE_INST_VALU') else None)
     out[mode] = ent
     traffic[mode] = dict(batch=B, agents=A, res=RES, hbm_bytes_per_launch=wb + 2 * fb, kernel_source_sha=stamp, source=f'profiles/{tag}_raster_pmc.json')
 out['notes'] = ('WRITE_SIZE / FETCH_SIZE are reported in KiB. FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (an upper bound here: part '

@@ -1687,6 +1687,89 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     wave_sync();
 }
 
+// The short set-up for SMALL faces (K3r sorts them out chunk by chunk: all three vertices inside the image, in one row or in two adjacent rows).  Such a
+// face has nothing between its vertex rows to scan-convert, every outline edge lies inside the image and is short, i.e. merged into the rows
+// (edge_class: 1 | x-major << 1 | 4) and nothing goes to the edge ring -- what is left of process_batch_bits is the painting of the vertex
+// rows, with the SAME expressions (edge_reach over the half slopes of OpenCV's 16.16 chains); the slope over one row,
+// edge_dx(xs, xe, 1) = trunc((xe - xs) * 65536 + 1/2) with C's truncation, is (xe - xs) << 16 for xe >= xs and ((xe - xs) << 16) + 1 below.
+// lane = face; `e` = the face's list entry (plane | outline edges << 4, three packed vertices); faces that miss the strip are skipped.
+__device__ __forceinline__ int slope_one_row(int xs, int xe) { const int d = xe - xs; return d >= 0 ? d << 16 : (int)(((unsigned)d << 16) + 1u); }
+// TALL = false: faces of one or two rows; TALL = true: up to four rows (yb - yt <= 3) -- the one or two rows between the top and the bottom
+// vertex are painted by the lane too, each either the row of the middle vertex or a row of part 1 (chains T->M, T->B) / part 2 (M->B, T->B)
+// with the expressions of process_batch_bits' row items.  Which of the two serves a launch is decided by the resolution (wave-uniform): the
+// taller variant costs every chunk of faces about twice the instructions and pays where faces of three and four rows are many (128 x 128: 38 %
+// of the faces on top of the 32 % of one and two rows; 64 x 64: 8 % on top of 66 %).
+template <bool TALL>
+__device__ __forceinline__ void process_small_bits(BitCtx &w, bool valid, const uint4 &e) {
+    const int H = w.H, X0 = w.X0, wpr = w.wpr;
+    const int Xhi = min(w.W, X0 + w.TWp) - 1;
+    if (!valid) return;
+    const int i0 = (int)e.y, i1 = (int)e.z, i2 = (int)e.w;
+    const int pT = min(i0, min(i1, i2)), pB = max(i0, max(i1, i2)), pM = max(min(i0, i1), min(max(i0, i1), i2));
+    const int xt = unpack_x((uint32_t)pT), yt = unpack_y((uint32_t)pT), xm = unpack_x((uint32_t)pM), ym = unpack_y((uint32_t)pM);
+    const int xb = unpack_x((uint32_t)pB), yb = unpack_y((uint32_t)pB);
+    const int xmin = min(xt, min(xm, xb)), xmax = max(xt, max(xm, xb));
+    if (xmax < X0 || xmin > Xhi) return;
+    uint32_t *pl = w.planes + (size_t)__umul24(__umul24(e.x & 15u, (unsigned)H), (unsigned)wpr);
+    auto paint_row = [&](int y, int L, int R) {
+        const int s0 = max(L, X0), s1 = min(R, Xhi);
+        if (s0 <= s1) paint_span_bits(pl + y, H, s0 - X0, s1 - X0);
+    };
+    if (yt == yb) { paint_row(yt, xmin, xmax); return; }         // one row: the three (horizontal, merged) edges are one span
+    // classes of the merged short edges: 1 | x-major << 1 | biased (edge_class with both end points inside the image and |dy| <= 100)
+    auto cls = [](int ax, int ay, int bx, int by) { return 5u | ((abs(bx - ax) >= abs(by - ay)) ? 2u : 0u); };
+    const unsigned cTM = cls(xt, yt, xm, ym), cMB = cls(xm, ym, xb, yb), cTB = cls(xt, yt, xb, yb);
+    int sTB, sTM, sMB;
+    if constexpr (TALL) {
+        sTB = edge_dx(xt, xb, yb - yt);
+        sTM = ym > yt ? edge_dx(xt, xm, ym - yt) : 0;
+        sMB = yb > ym ? edge_dx(xm, xb, yb - ym) : 0;
+    } else {
+        sTB = slope_one_row(xt, xb); sTM = ym > yt ? slope_one_row(xt, xm) : 0; sMB = yb > ym ? slope_one_row(xm, xb) : 0;
+    }
+    {
+        int L = xt, R = xt;
+        if (ym > yt) edge_reach(cTM, xt, half_slope(sTM), L, R);
+        else { L = min(xt, xm); R = max(xt, xm); edge_reach(cMB, xm, half_slope(sMB), L, R); }
+        edge_reach(cTB, xt, half_slope(sTB), L, R);
+        paint_row(yt, L, R);
+    }
+    if constexpr (TALL) {
+        int oLb, oRb;
+        edge_offsets(cTB, sTB, oLb, oRb);
+#pragma unroll
+        for (int j = 1; j <= 2; ++j) {
+            const int y = yt + j;
+            if (y >= yb) break;
+            const int xc = (xt << 16) + j * sTB;                     // the chain T->B in this row
+            if (y == ym) {
+                // the row of the middle vertex: T->M ends, M->B starts, T->B passes
+                int L = min(xm, (xc + oLb) >> 16), R = max(xm, (xc + oRb) >> 16);
+                edge_reach(cTM, xm, -half_slope(sTM), L, R);
+                edge_reach(cMB, xm, half_slope(sMB), L, R);
+                paint_row(y, L, R);
+            } else {
+                const bool second = y > ym;                          // part 2: the other chain is M->B, else T->M
+                const int sA = second ? sMB : sTM, xA = second ? xm : xt, yA = second ? ym : yt;
+                int oLa, oRa;
+                edge_offsets(second ? cMB : cTM, sA, oLa, oRa);
+                const int xa = (xA << 16) + (y - yA) * sA;
+                paint_row(y, min(xa + oLa, xc + oLb) >> 16, max(xa + oRa, xc + oRb) >> 16);
+            }
+        }
+    }
+    {
+        int L = 0x7fffffff, R = -0x7fffffff;
+        edge_reach(cTB, xb, -half_slope(sTB), L, R);
+        if (ym < yb) edge_reach(cMB, xb, -half_slope(sMB), L, R);
+        else {
+            edge_reach(cTM, xm, -half_slope(sTM), L, R);
+            L = min(L, min(xm, xb)); R = max(R, max(xm, xb));          // the horizontal bottom edge (merged)
+        }
+        paint_row(yb, L, R);
+    }
+}
+
 // plane of a key = its position in the ascending table (in LDS: broadcast reads)
 __device__ __forceinline__ int key_plane(const uint32_t *keys, int K, uint32_t key) {
     int k = 0;
@@ -2112,6 +2195,10 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
 // and rendered by the fused kernel afterwards (a launch over the marked cameras only), so the result never depends on the capacity.
 // =========================================================================================================
 constexpr int SCAN_WAVES = 4;                 // cameras per workgroup of K3s
+#ifndef TDS_SMALL_TALL_RES
+#define TDS_SMALL_TALL_RES 96
+#endif
+constexpr int SMALL_TALL_RES = TDS_SMALL_TALL_RES;      // from this resolution on K3r's short path takes faces of up to four rows (below: two)
 #ifndef TDS_SCAN_DEPTH
 #define TDS_SCAN_DEPTH 2
 #endif
@@ -2238,7 +2325,7 @@ __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArg
         uint32_t kv = 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < 16; ++i) kv = (tid == i) ? kt.key[i] : kv;
-        lkeys[tid] = tid == 15 ? (uint32_t)BWAVES : kv;                    // entry 15: the next chunk of the list
+        lkeys[tid] = tid == 15 ? (uint32_t)BWAVES : kv;                    // entry 15: the next chunk of the lists
     }
     __syncthreads();
     for (int e = tid; e < 3 * P; e += BBLOCK) {
@@ -2273,9 +2360,18 @@ __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArg
             chunk = __builtin_amdgcn_readfirstlane((int)nxt);
         }
         const int px[3] = {unpack_x(e.y), unpack_x(e.z), unpack_x(e.w)}, py[3] = {unpack_y(e.y), unpack_y(e.z), unpack_y(e.w)};
-        if (c.strips > 1) {                                            // faces that miss this strip are not queued
-            const int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
-            acc = acc && !(xmax < X0 || xmin > Xhi);
+        const int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
+        if (c.strips > 1) acc = acc && !(xmax < X0 || xmin > Xhi);      // faces that miss this strip are not queued
+        // SMALL faces -- the three vertices inside the image, in one row or in two adjacent rows: two thirds of the faces of a 64 x 64 view, a
+        // third at 128 x 128 -- are painted on the spot by their lane (process_small_bits: nothing to scan-convert, no edge to clip or walk);
+        // only the others go through the queue and the full set-up of process_batch_bits
+        if (!(TDS_DBG(c.debug) & 32768)) {
+            const int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
+            const bool inside = acc && xmin >= 0 && xmax < W && ymin >= 0 && ymax < H;
+            bool small;
+            if (res >= SMALL_TALL_RES) { small = inside && ymax - ymin <= 3; process_small_bits<true>(w, small, e); }      // wave-uniform choice
+            else { small = inside && ymax - ymin <= 1; process_small_bits<false>(w, small, e); }
+            acc = acc && !small;
         }
         drain_bits<false>(w, (int)(e.x & 15u), acc, (e.x >> 4) & 7u, px, py, more);
         if (!more) break;
