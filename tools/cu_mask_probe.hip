@@ -83,7 +83,9 @@ __global__ void metric_kernel(const float *table, float *out, int rounds) {
 
 static float elapsed(hipEvent_t a, hipEvent_t b) { float ms = 0; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
-int main() {
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int section = argc > 1 ? atoi(argv[1]) : 0;          // 0 all, 1 the bit -> CU listing only, 2 timings only
     int cus = 0;
     CK(hipSetDevice(0));
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
@@ -115,7 +117,7 @@ int main() {
     printf("\n");
     // 1. which place does bit i stand for?
     printf("bit -> missing place (xcc:hwid bits 15..8) :");
-    for (int bit = 0; bit < std::min(cus, 40); ++bit) {
+    for (int bit = 0; section != 2 && bit < std::min(cus, 40); ++bit) {
         std::vector<uint32_t> m = all;
         m[bit / 32] &= ~(1u << (bit % 32));
         hipStream_t s = masked_stream(m);
@@ -127,6 +129,7 @@ int main() {
         CK(hipStreamDestroy(s));
     }
     printf("\n");
+    if (section == 1) return 0;
     // candidate reservations: k CUs per XCD, assuming bit i belongs to XCC (i % 8) (checked by the listing above)
     const size_t n_img = 65536, bytes = n_img * (size_t)IMG_BYTES;
     char *buf = nullptr;
@@ -179,33 +182,39 @@ int main() {
             CK(hipEventRecord(m1, s_all));
             CK(hipEventSynchronize(m1));
             const float alone_all = elapsed(m0, m1);
-            float rb = 0, mb = 0;
-            for (int r = 0; r < 4; ++r) {
-                CK(hipMemsetAsync(queue, 0, 64, s_keep));
-                CK(hipEventRecord(e0, s_keep));
-                hipLaunchKernelGGL(stream_kernel, dim3(cus * 8), dim3(256), 52 * 1024 - 64, s_keep, buf, (int64_t)n_img, queue, (float)r);
-                CK(hipEventRecord(e1, s_keep));
-                CK(hipEventRecord(m0, s_rest));
-                hipLaunchKernelGGL(metric_kernel, dim3(blocks), dim3(256), 0, s_rest, (const float *)table, mout, 64);
-                CK(hipEventRecord(m1, s_rest));
-                CK(hipEventSynchronize(e1));
-                CK(hipEventSynchronize(m1));
-                rb += elapsed(e0, e1) / 4; mb += elapsed(m0, m1) / 4;
+            printf(" | metric stand-in %d blocks: %.3f ms on all CUs, %.3f alone on the reserved;", blocks, alone_all, alone);
+            // beside the raster launch: with the surplus workgroups of the product's persistent launch (8 per CU launched, 3 resident: the
+            // rest WAITS in the dispatcher) and with exactly as many workgroups as fit the allowed CUs (nothing waits)
+            for (int grid : {cus * 8, 3 * (cus - 8 * k)}) {
+                float rb = 0, mb = 0;
+                for (int r = 0; r < 4; ++r) {
+                    CK(hipMemsetAsync(queue, 0, 64, s_keep));
+                    CK(hipEventRecord(e0, s_keep));
+                    hipLaunchKernelGGL(stream_kernel, dim3(grid), dim3(256), 52 * 1024 - 64, s_keep, buf, (int64_t)n_img, queue, (float)r);
+                    CK(hipEventRecord(e1, s_keep));
+                    CK(hipEventRecord(m0, s_rest));
+                    hipLaunchKernelGGL(metric_kernel, dim3(blocks), dim3(256), 0, s_rest, (const float *)table, mout, 64);
+                    CK(hipEventRecord(m1, s_rest));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventSynchronize(m1));
+                    rb += elapsed(e0, e1) / 4; mb += elapsed(m0, m1) / 4;
+                }
+                printf(" raster grid %d: metric %.3f ms beside the launch, the launch %.3f;", grid, mb, rb);
             }
-            printf(" | metric stand-in %d blocks: %.3f ms on all CUs, %.3f alone on the reserved, %.3f beside the raster launch (raster then %.3f)", blocks, alone_all, alone, mb, rb);
         }
         printf("\n");
         CK(hipStreamDestroy(s_keep)); CK(hipStreamDestroy(s_rest));
     }
     // for comparison: the same pair without any mask (what round 3 measured: the small kernel crawls, the launch stretches)
-    {
+    for (int grid : {cus * 8, cus * 3}) {
         hipStream_t s2;
         CK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, -1));
         float rb = 0, mb = 0;
+        printf("grid %d: ", grid);
         for (int r = 0; r < 4; ++r) {
             CK(hipMemsetAsync(queue, 0, 64, s_all));
             CK(hipEventRecord(e0, s_all));
-            hipLaunchKernelGGL(stream_kernel, dim3(cus * 8), dim3(256), 52 * 1024 - 64, s_all, buf, (int64_t)n_img, queue, (float)r);
+            hipLaunchKernelGGL(stream_kernel, dim3(grid), dim3(256), 52 * 1024 - 64, s_all, buf, (int64_t)n_img, queue, (float)r);
             CK(hipEventRecord(e1, s_all));
             CK(hipEventRecord(m0, s2));
             hipLaunchKernelGGL(metric_kernel, dim3(1024), dim3(256), 0, s2, (const float *)table, mout, 64);

@@ -18,6 +18,7 @@
 //     explicit per-camera RGB mesh.
 // Roofline: HBM write, 3*H*W*4 B per camera (fp32) -- DESIGN.md.
 #include "tds_common.h"
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <type_traits>
@@ -2404,10 +2405,14 @@ inline uint32_t *workspace_queue(void *workspace, int64_t &bytes) {
     bytes = off;
     return (uint32_t *)((char *)workspace + off);
 }
-// workgroups of a persistent launch: enough to fill every CU at the kernel's occupancy twice over (a workgroup that finds the queues empty
-// leaves at once; the surplus takes the place of workgroups that could not start with the others because another stream's kernel held
-// their slots)
-int persistent_grid(int64_t items) {
+// workgroups of a persistent launch: exactly as many as are resident at a time -- three per CU (168 VGPRs: three waves per SIMD), fewer when
+// the LDS of one exceeds a third of the CU's 160 KiB.  Rounds 3 launched 8 per CU ("a surplus takes the place of workgroups that could
+// not start with the others"): a workgroup that cannot start waits in the dispatcher either way, and the waiting surplus costs -- measured
+// in round 4 (same box, debug flag 65536 = the old surplus): float32 B = 1024 7.02 -> 6.97 ms, uint8 5.20 -> 5.10, B = 256 1.88 -> 1.81.
+#ifdef TDS_TESTING
+int g_debug = 0;
+#endif
+int persistent_grid(int64_t items, size_t lds_bytes) {
     constexpr int MAX_DEVICES = 64;
     static std::atomic<int> cus_of[MAX_DEVICES];          // per device: a process may drive several (zero-initialised: not looked up yet)
     int dev = 0, cus = 0;
@@ -2418,7 +2423,10 @@ int persistent_grid(int64_t items) {
         cus = (dev >= 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
         if (dev >= 0) cus_of[dev].store(cus, std::memory_order_relaxed);
     }
-    const int64_t cap = (int64_t)cus * 8;
+    const size_t granted = (lds_bytes + 2047) & ~(size_t)2047;                  // LDS is granted in 2 KiB steps
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(granted, 1)));
+    // (testing build, debug flags 65536 / 131072: 8 / 4 workgroups per CU -- the surplus of round 3)
+    const int64_t cap = (int64_t)cus * ((TDS_DBG(g_debug) & 65536) ? 8 : ((TDS_DBG(g_debug) & 131072) ? 4 : per_cu));
     return (int)(items < cap ? items : cap);
 }
 
@@ -2474,9 +2482,6 @@ inline int pick_tw(int res) {
 }
 
 int g_force_tw = 0;
-#ifdef TDS_TESTING
-int g_debug = 0;
-#endif
 
 }  // namespace
 
@@ -2762,7 +2767,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                     queue = ws_queue;
                     if (tds::zero_async(queue, (size_t)QUEUE_BYTES, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the work queues failed"); return TDS_EHIP; }
                 }
-                dim3 grid((unsigned)(persist ? persistent_grid(only != nullptr ? 512 : n_img * cb.strips) : n_img * cb.strips));
+                dim3 grid((unsigned)(persist ? persistent_grid(only != nullptr ? 512 : n_img * cb.strips, lds) : n_img * cb.strips));
                 const SceneArgs base = a;
                 auto launch_b = [&](auto kern) {            // scenes without per-camera triangles
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
