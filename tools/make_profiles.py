@@ -96,6 +96,10 @@ for mode, bpp in (('f32', 4), ('u8', 1)):
                # SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES: the number of SIMDs with a VALU instruction in flight, averaged over the busy cycles
                # of a shader engine -- out of its 32 SIMDs... NOT a percentage (the old name `valu_utilisation` had no unit)
                valu_busy_simds_per_se_of_32=c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / max(c.get('SQ_BUSY_CYCLES', 0), 1) if c.get('SQ_BUSY_CYCLES') else None,
+               # calibrated (tools/valu_calibrate.hip, profiles/r04_valu_calibration.log): SQ_ACTIVE_INST_VALU reads 1.000 per v_add_u32 of a saturating
+               # dependent chain (3 or 6 waves per SIMD, 64 or 16 active lanes), and the quantity above reads 47.5 there -- so this is the fraction of the
+               # VALU issue rate a pure add chain reaches
+               valu_issue_fraction_of_add_chain=(c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / max(c.get('SQ_BUSY_CYCLES', 0), 1) / 47.5) if c.get('SQ_BUSY_CYCLES') else None,
                # lanes doing work per VALU instruction: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (where the pass collected it)
                valu_lane_occupancy=(c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU'])) if c.get('SQ_THREAD_CYCLES_VALU') and c.get('SQ_ACTIVE_INST_VALU') else None)
     out[mode] = ent
