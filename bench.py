@@ -282,6 +282,7 @@ def other_configs(device, steps, warmup, only=None):
         out.append(ent)
         del sim, ring
         sink.clear()
+        _ops.release_image_pool()         # the blocks the image pool has cached go back to the driver (torch.cuda.empty_cache() leaves a MemPool alone)
         torch.cuda.empty_cache()
     return out
 
@@ -645,6 +646,7 @@ def main():
                 line['roofline_64'] = low_res_mode(device, args.steps, args.warmup, B, A, res=64)
                 del sim, bufs
                 sink.clear()
+                _ops.release_image_pool()
                 torch.cuda.empty_cache()
                 line['configs'] = other_configs(device, args.steps, args.warmup)
             if not args.no_cpu_baseline:

@@ -491,9 +491,9 @@ class _OwnedBuffer:
         self.__cuda_array_interface__ = dict(shape=tuple(int(d) for d in shape), typestr=typestr, data=(int(self._lib.tds_buffer_ptr(self.handle)), False),
                                              version=2, strides=None)
 
-    def __del__(self):
+    def __del__(self, _finalizing=sys.is_finalizing):      # (bound at definition: module globals are gone when the interpreter shuts down)
         h, self.handle = getattr(self, 'handle', None), None
-        if h and not sys.is_finalizing():                  # at interpreter shutdown the driver takes the memory back itself
+        if h and not _finalizing():                        # at interpreter shutdown the driver takes the memory back itself
 
             try:
                 torch.cuda.synchronize(self.device)            # nothing in flight may still write to pages that are about to be unmapped

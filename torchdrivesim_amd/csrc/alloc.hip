@@ -166,7 +166,9 @@ std::unordered_map<void *, tds_buffer *> g_live;
 TDS_EXPORT void *tds_torch_alloc(size_t size, int device, void *stream) {
     (void)stream;
     tds_buffer_t *b = nullptr;
-    if (tds_buffer_create((int64_t)(size ? size : 1), device, 0, &b) != TDS_OK) return nullptr;      // torch reports the failure (out of memory)
+    if (tds_buffer_create((int64_t)(size ? size : 1), device, 0, &b) != TDS_OK &&
+        tds_buffer_create((int64_t)(size ? size : 1), device, TDS_BUFFER_DENSE, &b) != TDS_OK)       // the virtual-memory calls failed: one hipMalloc
+        return nullptr;                                                                              // torch reports the failure (out of memory)
     std::lock_guard<std::mutex> lock(g_mu);
     g_live[b->ptr] = b;
     return b->ptr;

@@ -597,6 +597,7 @@ class Simulator:
     #: and is foreseen from then on; one that is no longer asked for is dropped after one step.
     overlap_infractions = False
     _side_streams: Dict[int, Any] = {}
+    _side_priority = -1          # HIP stream priority of the side stream (-1: high)
 
     def _fork_sources(self):
         return [self.kinematic_model.get_state(), self.present_mask, self.agent_size, self.agent_type]
@@ -605,7 +606,7 @@ class Simulator:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         side = Simulator._side_streams.get(idx)
         if side is None:
-            side = Simulator._side_streams[idx] = torch.cuda.Stream(device=device, priority=-1)
+            side = Simulator._side_streams[idx] = torch.cuda.Stream(device=device, priority=Simulator._side_priority)
         return side
 
     def _metric_fn(self, key):
