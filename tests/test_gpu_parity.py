@@ -470,8 +470,8 @@ def test_k3_golden_scenes_bit_exact(ops, oracle, town, testing_lib):
         mask = np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A)))
         # {bit-plane kernel} + strip widths x {binned, fused} packed-key kernels
         # (with bits=True a strip width >= 32 cuts the bit-plane kernel's image into strips as well)
-        for tw, ws, bits in ((0, True, True), (32, True, True), (64, True, True), (0, True, False), (0, False, False), (64, True, False),
-                             (16, True, False), (16, False, False)):
+        for tw, ws, bits in ((0, True, True), (32, True, True), (64, True, True), (0, False, True), (64, False, True), (0, True, False), (0, False, False),
+                             (64, True, False), (16, True, False), (16, False, False)):      # (ws False, bits True): no work queues, one workgroup per item
             testing_lib.tds_raster_set_strip_width(tw)
             ops.use_workspace, ops.use_bitplanes = ws, bits
             ops._workspaces.clear()
@@ -558,7 +558,7 @@ def test_k3_random_town01_256_bit_exact(ops, oracle, town):
     static = oracle_static(oracle, town['verts'], town['faces'], town['vert_category'], town['categories'])
     sd = dev(state)
     cam_sc = sc_np(ops.heading_sc(sd[..., 2]))
-    for ws, bits in ((True, True), (True, False), (False, False)):
+    for ws, bits in ((True, True), (False, True), (True, False), (False, False)):      # (False, True): no workspace, hence no work queues -- the persistent kernel with one workgroup per camera
         ops.use_workspace, ops.use_bitplanes = ws, bits
         try:
             img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 35.0, 256)
@@ -646,7 +646,7 @@ def test_k3_faces_far_outside_the_packed_coordinate_range(ops, oracle):
     size = np.array([[[4.5, 2.0], [4.5, 2.0]]], np.float32)
     mask = np.ones((1, 2, 2), bool)
     cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
-    for ws, bits in ((True, True), (True, False), (False, False)):
+    for ws, bits in ((True, True), (False, True), (True, False), (False, False)):      # (False, True): no workspace, hence no work queues -- the persistent kernel with one workgroup per camera
         ops.use_workspace, ops.use_bitplanes = ws, bits
         try:
             img, ref = render_both(ops, oracle, smap, static, state, size, mask, state[..., :2].copy(), cam_sc, 5.0, 256)
