@@ -30,6 +30,72 @@ def heading_sc(psi):
     return torch.stack([torch.sin(psi), torch.cos(psi)], dim=-1)
 
 
+_zero_consts = {}
+
+
+def _zeros_const(shape, device):
+    """a zero tensor that is never written (gradient columns that are identically zero are concatenated from it: one launch, no fill)"""
+    key = (tuple(int(d) for d in shape), str(device))
+    z = _zero_consts.get(key)
+    if z is None:
+        if len(_zero_consts) > 64:
+            _zero_consts.clear()
+        z = _zero_consts[key] = torch.zeros(key[0], dtype=f32, device=device)
+    return z
+
+
+class _StateHeadingSC(torch.autograd.Function):
+    """[sin psi, cos psi] of a (..., 4) state tensor as ONE autograd node.  The values are torch.sin / torch.cos of the psi column (what the
+    reference computes, simulator.py:940); the backward is the chain rule in closed form, d/dpsi = g_sin cos - g_cos sin, written into the psi
+    column of a zero state gradient -- three small launches instead of the eight of autograd's select / sin / cos / stack chain, and the
+    consumers of one state (render, collision, off-road) can share the node (Simulator._heading_sc).  Nothing is kept through
+    save_for_backward: the node can be walked again (retain_graph) like plain torch ops."""
+
+    @staticmethod
+    def forward(ctx, state):
+        psi = state[..., 2]
+        sc = torch.empty(state.shape[:-1] + (2,), dtype=state.dtype, device=state.device)
+        torch.sin(psi, out=sc[..., 0])
+        torch.cos(psi, out=sc[..., 1])
+        ctx.sc = sc
+        return sc
+
+    @staticmethod
+    def backward(ctx, g):
+        sc = ctx.sc
+        gpsi = torch.mul(g[..., 0], sc[..., 1]).addcmul_(g[..., 1], sc[..., 0], value=-1.0)
+        z = _zeros_const(gpsi.shape + (2,), gpsi.device)
+        return torch.cat([z, gpsi.unsqueeze(-1), z[..., :1]], dim=-1)          # (..., 4): zeros, zeros, d/dpsi, zeros
+
+
+def state_heading_sc(state):
+    """differentiable [sin psi, cos psi] of a (..., 4) state, one autograd node (see _StateHeadingSC)"""
+    return _StateHeadingSC.apply(state)
+
+
+class _Boxes(torch.autograd.Function):
+    """[x, y, length, width, psi] boxes (simulator.py:1093) from a (..., 4) state and (..., 2) sizes as one autograd node: a cat forward, and a
+    backward that builds both gradients with two launches instead of the zeros + copies + adds of three slice nodes."""
+
+    @staticmethod
+    def forward(ctx, state, size):
+        ctx.need = (state.requires_grad, size.requires_grad)
+        return torch.cat([state[..., :2], size, state[..., 2:3]], dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = gz = None
+        if ctx.need[0]:
+            gs = torch.cat([g[..., :2], g[..., 4:5], _zeros_const(g.shape[:-1] + (1,), g.device)], dim=-1)      # d/d(x, y, psi), 0 for v
+        if ctx.need[1]:
+            gz = g[..., 2:4].contiguous()
+        return gs, gz
+
+
+def state_boxes(state, size):
+    return _Boxes.apply(state, size)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # K1 kinematics
 # ---------------------------------------------------------------------------------------------------------------
@@ -624,7 +690,13 @@ class _RasterScene(torch.autograd.Function):
     to colour boundaries only; otherwise the forward image is kept and tds_raster_scene_bwd_f32 streams image and gradient in full."""
 
     @staticmethod
-    def forward(ctx, state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key, color_keys, trim):
+    def forward(ctx, state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, fov, res, key_table, extra_tri, extra_key, color_keys, trim,
+                ego=0):
+        # ego = Nc > 0: the cameras ARE the first Nc agents (render_egocentric): positions and headings are taken from `state` / `agent_sc` here,
+        # and the backward folds the cameras' gradient into the agents' -- no slice nodes in the graph, no separate gradient tensors
+        ctx.ego = int(ego)
+        if ctx.ego:
+            cam_xy, cam_sc = state[:, :ctx.ego, :2].contiguous(), agent_sc[:, :ctx.ego].contiguous()
         out, slices, keys = raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table,
                                          extra_tri=extra_tri, extra_key=extra_key, index_slices=True, trim=trim) if use_index_slices else \
             (raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=key_table, extra_tri=extra_tri,
@@ -683,8 +755,9 @@ class _RasterScene(torch.autograd.Function):
         ga = g_agent.sum(dim=1) if N > 0 else None                   # over cameras: (B, N, 4)
         g_state = g_sc = None
         if N > 0:
-            g_state = torch.zeros_like(state)
-            g_state[..., :2] = ga[..., :2]
+            if ctx.ego:
+                ga[:, :ctx.ego] += g_cam                               # the camera of agent a is agent a
+            g_state = torch.cat([ga[..., :2], _zeros_const(ga.shape[:-1] + (2,), dev)], dim=-1)
             g_sc = ga[..., 2:].contiguous()
         g_key_colors = None
         if g_color is not None:
@@ -693,18 +766,21 @@ class _RasterScene(torch.autograd.Function):
             pos = {k: i + 1 for i, k in enumerate(ctx.keys)}
             rows = torch.tensor([pos.get(k, -1) for k in ctx.color_keys], device=dev)
             g_key_colors = torch.where((rows >= 0)[:, None], per_key[rows.clamp(min=0)], torch.zeros((), device=dev))
-        return (g_state, g_sc, g_cam[..., :2].contiguous(), g_cam[..., 2:].contiguous(), g_key_colors,
-                None, None if g_tmpl is None else g_tmpl.sum(dim=1), None, None, None, None, None, None, None, None, None)
+        return (g_state, g_sc, None if ctx.ego else g_cam[..., :2].contiguous(), None if ctx.ego else g_cam[..., 2:].contiguous(), g_key_colors,
+                None, None if g_tmpl is None else g_tmpl.sum(dim=1), None, None, None, None, None, None, None, None, None, None)
 
 
 def raster_scene_diff(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, fov, res, key_table=None, extra_tri=None, extra_key=None,
-                      key_colors=None, color_keys=None, trim=True):
+                      key_colors=None, color_keys=None, trim=True, ego_cameras=0):
     """raster_scene with a backward pass (float32 output only; the per-camera triangles get no gradient).
     key_colors (K,3) float tensor + color_keys (K packed keys): a handle for COLOUR gradients -- row r stands for the colour the image shows
     where key color_keys[r] wins; the forward takes its pixels from the keys' own RGB bits (the caller keeps the two consistent), the
     backward returns d loss / d key_colors[r] = the sum of the incoming gradient over those pixels, all cameras (exact)."""
+    if ego_cameras:
+        # `ego_cameras` = Nc: the cameras are the first Nc agents of `state` / `agent_sc` (cam_xy / cam_sc are ignored)
+        cam_xy = cam_sc = None
     return _RasterScene.apply(state, agent_sc, cam_xy, cam_sc, key_colors, smap, tmpl, actor_key, mask, float(fov), int(res), key_table, extra_tri,
-                              extra_key, color_keys, bool(trim))
+                              extra_key, color_keys, bool(trim), int(ego_cameras))
 
 
 def raster_mesh(verts, attrs, faces, cam_xy, cam_sc, levels, scale, res, out_dtype=torch.float32, trim=True):

@@ -89,11 +89,12 @@ class HipRenderer(BirdviewRenderer):
                      camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None,
                      key_table=None, differentiable: bool = False, extra_tri: Optional[Tensor] = None,
                      extra_key: Optional[Tensor] = None, key_colors: Optional[Tensor] = None, color_keys=None,
-                     out: Optional[Tensor] = None) -> Tensor:
+                     out: Optional[Tensor] = None, ego_cameras: int = 0) -> Tensor:
         """-> B x Nc x 3 x H x W.  `out`: a caller-owned contiguous B x Nc x 3 x H x W tensor of the renderer's output dtype to render into
         (the C ABI takes caller buffers, include/tdship.h; the reference allocates per call, rendering/cv2.py:52) -- not for differentiable calls.  `differentiable`: attach the K3 backward (gradients w.r.t. state[..., :2], agent_sc, camera_xy,
         camera_sc; float32 output only).  `extra_tri` (B,Nc,K,3,2) / `extra_key` (B,Nc,K): per-camera world-space triangles.
-        `key_colors` (K,3) / `color_keys` (K packed keys): colour-gradient handle, see _ops.raster_scene_diff."""
+        `key_colors` (K,3) / `color_keys` (K packed keys): colour-gradient handle, see _ops.raster_scene_diff.
+        `ego_cameras` = Nc (differentiable calls): the cameras are the first Nc agents of `state` / `agent_sc` -- their gradient is folded into the agents'."""
         res = self.res if res is None else res
         if res.width != res.height:
             raise RuntimeError('only square resolutions are supported')
@@ -104,7 +105,8 @@ class HipRenderer(BirdviewRenderer):
             if out is not None:
                 raise RuntimeError('`out=` cannot be combined with a differentiable render (autograd owns the image)')
             return _ops.raster_scene_diff(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, key_table=key_table,
-                                          extra_tri=extra_tri, extra_key=extra_key, key_colors=key_colors, color_keys=color_keys, trim=self.trim)
+                                          extra_tri=extra_tri, extra_key=extra_key, key_colors=key_colors, color_keys=color_keys, trim=self.trim,
+                                          ego_cameras=ego_cameras)
         return _ops.raster_scene(static_map, state, agent_sc, tmpl, actor_key, mask, camera_xy, camera_sc, fov, res.height, out_dtype=self.out_dtype,
                                  key_table=key_table, extra_tri=extra_tri, extra_key=extra_key, trim=self.trim, out=out)
 

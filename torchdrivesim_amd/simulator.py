@@ -451,13 +451,20 @@ class Simulator:
 
     def _heading_sc(self) -> Tensor:
         """[sin psi, cos psi] of ALL agents, computed once per state tensor and shared by render / collision / off-road (each of them
-        would otherwise launch its own sin and cos).  Not cached when gradients are being recorded.  The cache is keyed on the
+        would otherwise launch its own sin and cos); when gradients are being recorded, one shared autograd node.  The cache is keyed on the
         IDENTITY of the state tensor (which it keeps alive, so the allocator cannot hand its block to a later state) and on its
         version counter; a kinematic model whose get_state() builds a fresh tensor per call (CompoundKinematicModel) or a scene
         with NPCs (torch.cat per call) therefore never hits it."""
         state = self.get_all_agent_state()
         if state.requires_grad and torch.is_grad_enabled():
-            return _ops.heading_sc(state[..., 2])
+            # gradients are being recorded: ONE autograd node per state tensor (_ops.state_heading_sc), shared by render / collision / off-road
+            # like the plain cache below -- autograd sums the three consumers' gradients before the node's closed-form backward runs once
+            cached = getattr(self, '_sc_cache_grad', None)
+            if cached is not None and cached[0] is state and cached[1] == state._version:
+                return cached[2]
+            sc = _ops.state_heading_sc(state)
+            self._sc_cache_grad = (state, state._version, sc)
+            return sc
         cached = getattr(self, '_sc_cache', None)
         if cached is not None and cached[0] is state and cached[1] == state._version:
             return cached[2]
@@ -808,7 +815,7 @@ class Simulator:
     def render(self, camera_xy: Tensor, camera_psi: Tensor, res: Optional[Resolution] = None, rendering_mask: Optional[Tensor] = None,
                fov: Optional[float] = None, waypoints: Optional[Tensor] = None, waypoints_rendering_mask: Optional[Tensor] = None,
                custom_agent_colors: Optional[Tensor] = None, noisy_perception: bool = False, _camera_sc: Optional[Tensor] = None,
-               out: Optional[Tensor] = None) -> Tensor:
+               out: Optional[Tensor] = None, _ego: bool = False) -> Tensor:
         """Bird's-eye images for BxNx2 camera positions and BxNx1 headings -> BxNx3xHxW (simulator.py:920-992).
         `out` (not in the reference, which allocates per call, rendering/cv2.py:52): a caller-owned contiguous BxNx3xHxW tensor of the
         renderer's output dtype to render into; returned.  HipRenderer only, one static map per batch, not for differentiable calls."""
@@ -822,7 +829,7 @@ class Simulator:
             try:
                 return self.render(camera_xy, camera_psi, res=res, rendering_mask=rendering_mask, fov=fov, waypoints=waypoints,
                                    waypoints_rendering_mask=waypoints_rendering_mask, custom_agent_colors=custom_agent_colors,
-                                   noisy_perception=False, _camera_sc=_camera_sc, out=out)
+                                   noisy_perception=False, _camera_sc=_camera_sc, out=out, _ego=_ego)
             finally:
                 self.birdview_mesh_generator, self.traffic_controls, self._scene_cache = saved
         camera_sc = _camera_sc if _camera_sc is not None else torch.cat([torch.sin(camera_psi), torch.cos(camera_psi)], dim=-1)
@@ -850,7 +857,7 @@ class Simulator:
                 state = torch.cat([state, ctrl['state'].to(state.dtype)], dim=1)
                 tmpl_all = torch.cat([tmpl_all, ctrl['tmpl'].to(tmpl_all.dtype)], dim=1)
                 mask = torch.cat([mask, torch.ones(mask.shape[:-1] + (ctrl['state'].shape[1],), dtype=torch.bool, device=mask.device)], dim=-1)
-            agent_sc = self._heading_sc() if (ctrl is None and not diff) else _ops.heading_sc(state[..., 2])
+            agent_sc = self._heading_sc() if ctrl is None else _ops.heading_sc(state[..., 2])
             wp_tri = wp_on = None
             if waypoints is not None and waypoints.shape[2] > 0:
                 wp_tri, wp_on = self._waypoint_triangles(waypoints.to(state.dtype), waypoints_rendering_mask)
@@ -859,8 +866,12 @@ class Simulator:
             out_arg, out = ({} if out is None else dict(out=out)), []
             if not diff:
                 self._mark_fork()
+            # render_egocentric with gradients: the cameras are the exposed agents themselves -- one autograd node takes state and headings and
+            # folds the cameras' gradient into the agents' (no slice nodes for camera_xy / camera_sc in the graph)
+            ego_n = n_cam if (_ego and diff and ctrl is None and len(scene['maps']) == 1 and n_cam <= state.shape[1]) else 0
             for i_map, ((smap, b), keys, ktab) in enumerate(zip(scene['maps'], scene['keys'], scene['key_tables'])):
                 sl = slice(None) if b is None else slice(b, b + 1)
+                cut = (lambda t: t) if b is None else (lambda t: t[sl])       # (a full slice would still be a node of the autograd graph)
                 k = keys[sl]
                 if custom_agent_colors is not None:
                     # generate() paints the four body vertices of agent a with custom_agent_colors[b, c, a] for camera c
@@ -878,9 +889,9 @@ class Simulator:
                     wk = scene['wp_keys'][i_map]
                     extra = dict(extra_tri=wp_tri[sl], extra_key=torch.full(wp_tri[sl].shape[:3], wk, dtype=torch.int32, device=state.device))
                     ktab = None if ktab is None else sorted(set(ktab) | {wk})
-                out.append(self.renderer.render_scene(smap, state[sl], agent_sc[sl], tmpl_all[sl], k, mask[sl].contiguous(),
-                                                      camera_xy[sl], camera_sc[sl], res=res, fov=fov, key_table=ktab, differentiable=diff, **extra,
-                                                      **out_arg))
+                out.append(self.renderer.render_scene(smap, cut(state), cut(agent_sc), cut(tmpl_all), k, cut(mask).contiguous(),
+                                                      cut(camera_xy), cut(camera_sc), res=res, fov=fov, key_table=ktab, differentiable=diff, **extra,
+                                                      **out_arg, **(dict(ego_cameras=ego_n) if ego_n else {})))
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
         if out is not None:
             raise RuntimeError(f'`out=` is served by HipRenderer only, not by {type(self.renderer).__name__}')
@@ -907,13 +918,15 @@ class Simulator:
             A, total = self.agent_count, self.agent_count + self.npc_count
             rendering_mask = torch.eye(A, total, dtype=torch.bool, device=state.device).unsqueeze(0).expand(self.batch_size, -1, -1)
         cam_sc = None
-        if ego_rotate and not (state.requires_grad and torch.is_grad_enabled()):
-            cam_sc = self._heading_sc()[..., :self.agent_count, :]          # the cameras ARE the exposed agents
+        if ego_rotate:
+            cam_sc = self._heading_sc()                                     # the cameras ARE the exposed agents (differentiable when the state is)
+            if cam_sc.shape[-2] != self.agent_count:
+                cam_sc = cam_sc[..., :self.agent_count, :]
         waypoints = self.get_waypoints(count=n_subsequent_waypoints)                  # simulator.py:1013-1017
         waypoints_mask = self.get_waypoints_mask(count=n_subsequent_waypoints) if waypoints is not None else None
         return self.render(camera_xy, camera_psi, rendering_mask=rendering_mask, res=res, fov=fov, custom_agent_colors=custom_agent_colors,
                            waypoints=waypoints, waypoints_rendering_mask=waypoints_mask, noisy_perception=noisy_perception, _camera_sc=cam_sc,
-                           out=out)
+                           out=out, _ego=ego_rotate)
 
     # ------------------------------------------------------------------------------------------------- infractions
     def compute_offroad(self) -> Tensor:
@@ -928,12 +941,15 @@ class Simulator:
         from torchdrivesim_amd.infractions import _static_maps_for
         maps = _static_maps_for(self.road_mesh, state.device)      # geometry-only device map(s), cached on the mesh
         size, present = self.get_agent_size(), self.get_present_mask()
-        sc_all = None if (state.requires_grad and torch.is_grad_enabled()) else self._heading_sc()[..., :self.agent_count, :]
+        sc_all = self._heading_sc()
+        if sc_all.shape[-2] != self.agent_count:
+            sc_all = sc_all[..., :self.agent_count, :]
         out = []
         for smap, b in maps:
             sl = slice(None) if b is None else slice(b, b + 1)
-            out.append(_ops.offroad(smap, state[sl], size[sl], threshold=self.cfg.offroad_threshold, present=present[sl],
-                                    sc=None if sc_all is None else sc_all[sl]))
+            cut = (lambda t: t) if b is None else (lambda t: t[sl])           # (a full slice would still be a node of the autograd graph)
+            out.append(_ops.offroad(smap, cut(state), cut(size), threshold=self.cfg.offroad_threshold, present=cut(present),
+                                    sc=None if sc_all is None else cut(sc_all)))
         return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 
     def compute_wrong_way(self) -> Tensor:
@@ -962,8 +978,7 @@ class Simulator:
         return torch.zeros(state.shape[0], state.shape[1], dtype=torch.bool, device=state.device)
 
     def _all_boxes(self):
-        states, sizes = self.get_all_agent_state(), self.get_all_agent_size()
-        return torch.cat([states[..., :2], sizes, states[..., 2:3]], dim=-1)
+        return _ops.state_boxes(self.get_all_agent_state(), self.get_all_agent_size())
 
     def _collision_mask(self, agent_types: Optional[List[str]]):
         mask = self.get_all_agent_present_mask()
@@ -985,7 +1000,7 @@ class Simulator:
         if metric in (CollisionMetric.iou, CollisionMetric.discs):
             boxes = self._all_boxes()
             # a NaN heading is scrubbed inside the kernel, so the shared [sin, cos] of the raw headings serves the IoU metric
-            sc = self._heading_sc() if (metric == CollisionMetric.iou and not (boxes.requires_grad and torch.is_grad_enabled())) else None
+            sc = self._heading_sc() if metric == CollisionMetric.iou else None
             return _ops.collision(boxes, self._collision_mask(agent_types), n_exposed=A, metric=metric.value, sc=sc)
         if metric == CollisionMetric.nograd:
             assert agent_types is None, 'The argument `agent_types` is not supported by the selected collision metric.'
