@@ -27,7 +27,12 @@ def _c(t, dtype=f32):
 def heading_sc(psi):
     """[sin, cos] of headings with torch on the tensor's device -- exactly where the reference calls torch.sin/cos
     (simulator.py:940, utils.py:40-53, _iou_utils.py:290-291).  psi: (...,) -> (..., 2); differentiable."""
-    return torch.stack([torch.sin(psi), torch.cos(psi)], dim=-1)
+    if psi.requires_grad and torch.is_grad_enabled():
+        return torch.stack([torch.sin(psi), torch.cos(psi)], dim=-1)
+    sc = torch.empty(psi.shape + (2,), dtype=psi.dtype, device=psi.device)          # two launches instead of three: the same torch.sin / torch.cos, written in place
+    torch.sin(psi, out=sc[..., 0])
+    torch.cos(psi, out=sc[..., 1])
+    return sc
 
 
 _zero_consts = {}
