@@ -26,6 +26,13 @@ namespace {
 #define TDS_BW_BLOCK 256
 #endif
 constexpr int BW_BLOCK = TDS_BW_BLOCK;
+#ifndef TDS_BW_OCC
+#define TDS_BW_OCC 4          // workgroups per CU the index kernel's registers are cut for
+#endif
+#ifndef TDS_BW_QCOLS
+#define TDS_BW_QCOLS 32       // columns of a slab whose boundary cells are queued at a time (32: the whole slab, up to 2 048 cells; 16: 1 024)
+#endif
+constexpr int BW_QCOLS = TDS_BW_QCOLS, BW_QCELLS = 64 * BW_QCOLS;
 constexpr int LANES_PER_AGENT = 8;          // 4 body edges + 3 direction-triangle edges (+1 idle)
 // Where the colours on the two sides of an edge are read.  The forward draws the polygon through the TRUNCATED vertices with OpenCV's
 // rules (fill + outline): in continuous pixel coordinates that is the polygon through the centres of the vertex pixels, grown by about
@@ -309,7 +316,7 @@ struct BwdIdxArgs {
 };
 
 template <int NB>
-__global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxArgs a) {
+__global__ void __launch_bounds__(BW_BLOCK, TDS_BW_OCC) raster_scene_bwd_idx_kernel(BwdIdxArgs a) {
     __shared__ float cam_part[(BW_BLOCK / 64) * 4];
     __shared__ float4 col_tab[16];                                       // colour of key index i (w unused)
     // dynamic LDS: per wave the owner records + cell queue of the camera pass; then (only when grad_color is asked for) reused as
@@ -455,7 +462,7 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
     {
         float Sx = 0.0f, Sy = 0.0f, Cc = 0.0f, Cs = 0.0f;
         constexpr int OWN_DW = (NB * 5 + 1 + 3) & ~3;                         // per quad: its NB x 4 slice words, row 0 of the quad below, bit 0 of the next word column (16-byte records)
-        uint32_t *wl = (uint32_t *)col_priv + wave * (64 * OWN_DW + 1024);    // per wave: 64 owner records, then up to 2048 cells as uint16
+        uint32_t *wl = (uint32_t *)col_priv + wave * (64 * OWN_DW + BW_QCELLS / 2);    // per wave: 64 owner records, then up to BW_QCELLS cells as uint16
         unsigned short *cells = (unsigned short *)(wl + 64 * OWN_DW);
         const int qblocks = (quads + 63) >> 6;
         for (int slab = wave; slab < wprT * qblocks; slab += BW_BLOCK / 64) {
@@ -508,9 +515,11 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
             // The queue is filled COLUMN by column (a ballot per column: which row quads have a boundary there), not lane by lane: neighbouring
             // entries are then neighbouring row quads of one column, i.e. 16-byte pieces of the SAME 64-byte sector of the gradient (out[ch][x][y]:
             // four row quads per sector), and the lanes of a gather share their sectors instead of touching up to 64 different ones.
+            for (int xq = 0; xq < 32; xq += BW_QCOLS) {                       // BW_QCOLS columns of the slab at a time: what the queue holds
             int total = 0;
 #pragma unroll
-            for (int x = 0; x < 32; ++x) {
+            for (int xx = 0; xx < BW_QCOLS; ++xx) {
+                const int x = xq + xx;
                 const bool mine = (m >> x) & 1u;
                 const unsigned long long bq = __ballot(mine);
                 if (mine) cells[total + __builtin_amdgcn_mbcnt_hi((unsigned)(bq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bq, 0))] = (unsigned short)((lane << 5) | x);
@@ -576,6 +585,8 @@ __global__ void __launch_bounds__(BW_BLOCK) raster_scene_bwd_idx_kernel(BwdIdxAr
                     const float dy = (float)(y0 + 4) - half;
                     Sy += D; Cc += D * (cs * dxr + cc * dy); Cs += -D * (cc * dxr - cs * dy);
                 }
+            }
+            wave_sync_bwd();                                              // the queue is refilled for the next columns
             }
         }
         gcam[0] = -k * (cc * Sx - cs * Sy);
@@ -696,7 +707,7 @@ TDS_EXPORT int tds_raster_scene_bwd_idx_f32(const float *state, const float *age
     for (int i = 0; i < 16; ++i) a.keys[i] = i < n_keys ? keys[i] : 0u;
     a.nb = n_keys <= 3 ? 2 : (n_keys <= 7 ? 3 : 4);                 // as bits_index_bits of the forward
     // camera pass: per wave 64 owner records (NB * 5 + 1 words each, padded to 16 bytes) + 2048 uint16 cells; colour pass: 48 x BW_BLOCK floats
-    const size_t lds_cam = (size_t)(BW_BLOCK / 64) * (64 * ((a.nb * 5 + 1 + 3) & ~3) + 1024) * sizeof(uint32_t);
+    const size_t lds_cam = (size_t)(BW_BLOCK / 64) * (64 * ((a.nb * 5 + 1 + 3) & ~3) + BW_QCELLS / 2) * sizeof(uint32_t);
     const size_t lds = std::max(lds_cam, grad_color ? (size_t)48 * BW_BLOCK * sizeof(float) : (size_t)0);
     if (a.nb == 2) hipLaunchKernelGGL(raster_scene_bwd_idx_kernel<2>, dim3((unsigned)n_img), dim3(BW_BLOCK), lds, (hipStream_t)stream, a);
     else if (a.nb == 3) hipLaunchKernelGGL(raster_scene_bwd_idx_kernel<3>, dim3((unsigned)n_img), dim3(BW_BLOCK), lds, (hipStream_t)stream, a);
