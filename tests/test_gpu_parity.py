@@ -491,7 +491,7 @@ def test_k3_split_form_equals_the_fused_kernel_and_the_oracle(ops, oracle, town,
     """Up to 144 x 144 (float32) / 208 x 208 (uint8) the bit-plane path runs as two kernels -- K3s lists every camera's faces, K3r rasterises
     the lists -- with a third launch of the fused kernel over the cameras whose list overflowed.  Every form must paint the same pixels:
     forced either way (debug flags 8192 / 16384 of the testing build), cut into narrow strips (LDS budget), with a workspace so small that
-    most lists overflow, and with K3r's short path for small faces (the three vertices inside the image and in at most two -- from 96 x 96
+    most lists overflow, and with K3r's short path for small faces (the three vertices inside the image and in at most two -- from 112 x 112
     on: four -- rows, painted by their lane on the spot) switched off (32768): the two set-ups paint the same pixels."""
     g = load_golden('g45_mesh_preraster.npz')
     st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']
@@ -502,7 +502,7 @@ def test_k3_split_form_equals_the_fused_kernel_and_the_oracle(ops, oracle, town,
     cam_sc = g['g5_town01_128_cam_sc']
     real_ws = ops._raster_workspace
     try:
-        for res, fov in ((64, 35.0), (92, 120.0), (96, 35.0), (128, 35.0), (192, 60.0), (256, 35.0), (320, 80.0)):
+        for res, fov in ((64, 35.0), (108, 120.0), (112, 35.0), (128, 35.0), (192, 60.0), (256, 35.0), (320, 80.0)):
             ref = None
             for dtype in (torch.float32, torch.uint8):
                 for flags, lds_kb, small_ws in ((8192, 40, False), (16384, 40, False), (16384, 16, False), (16384, 52, False), (16384, 40, True),

@@ -2197,7 +2197,7 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
 // =========================================================================================================
 constexpr int SCAN_WAVES = 4;                 // cameras per workgroup of K3s
 #ifndef TDS_SMALL_TALL_RES
-#define TDS_SMALL_TALL_RES 96
+#define TDS_SMALL_TALL_RES 112
 #endif
 constexpr int SMALL_TALL_RES = TDS_SMALL_TALL_RES;      // from this resolution on K3r's short path takes faces of up to four rows (below: two)
 #ifndef TDS_SCAN_DEPTH
