@@ -134,6 +134,10 @@ int tds_map_create(const float *verts, const int32_t *faces, const float *face_z
 int tds_map_destroy(tds_map_t *map);
 /* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, number of nearest-face candidates */
 int tds_map_info(const tds_map_t *map, int64_t *info);
+/* the distinct face keys of the map (HOST array of `cap` entries; *n receives their number, -1 when there are more than 64): with the caller's
+ * actor keys they decide which rasteriser serves a launch -- at most 15 keys in all: the bit-plane kernels -- and with it how much scratch
+ * tds_raster_scene can use (tds_raster_scene_workspace_bytes_for) */
+int tds_map_keys(const tds_map_t *map, uint32_t *keys, int cap, int *n);
 
 /* Map sets: batches whose scenes have DIFFERENT meshes (the reference supports them as a collated, padded mesh batch, mesh.py:69,
  * 113-123).  A set is a device array of the views of several maps of ONE device that were created with the SAME `levels` table; the
@@ -141,6 +145,7 @@ int tds_map_info(const tds_map_t *map, int64_t *info);
 typedef struct tds_mapset tds_mapset_t;
 int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset_t **out);
 int tds_mapset_destroy(tds_mapset_t *set);
+int tds_mapset_keys(const tds_mapset_t *set, uint32_t *keys, int cap, int *n);      /* tds_map_keys over the union of the set's maps */
 
 /* ------------------------------------------------------------------------------------------------------------
  * K2b  offroad              simulator.py:1035-1044; infractions.py:86-229 (pure-torch path, squared distances)
@@ -235,8 +240,12 @@ int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, co
                            int64_t N, float scale, int res, int out_mode, void *out, void *workspace, int64_t workspace_bytes,
                            const uint32_t *actor_keys, int n_actor_keys, int actor_key_per_camera,
                            const float *extra_tri, const uint32_t *extra_key, int64_t n_extra, tds_raster_aux_t *aux, void *stream);
-/* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used) */
+/* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used): enough for every path */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
+/* the same for a launch of which the caller knows the number of distinct keys (map keys + actor keys, tds_map_keys): with at most 15 the
+ * bit-plane kernels run, which use the face lists up to 144 x 144 (float32) / 208 x 208 (uint8) only and above nothing but the 64 bytes of
+ * work queues -- 128 bytes instead of 32 KB per camera at 256 x 256.  n_keys < 0 or > 15: as tds_raster_scene_workspace_bytes. */
+int tds_raster_scene_workspace_bytes_for(int64_t n_img, int res, int out_mode, int n_keys, int64_t *bytes);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Output buffers with spread-out physical pages (no reference counterpart: rendering/cv2.py:52 allocates a numpy image per call).

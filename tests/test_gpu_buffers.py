@@ -83,3 +83,32 @@ def test_out_is_validated_with_real_errors():
                       (torch.empty(2 * 4 * 3 * 64 * 64 + 1, device=DEV)[1:].view(2, 4, 3, 64, 64), 'aligned')):
         with pytest.raises(RuntimeError, match=word):
             sim.render_egocentric(res=res, out=bad)
+
+
+def test_the_workspace_is_sized_for_the_kernels_that_run():
+    """tds_raster_scene_workspace_bytes_for: with the number of distinct keys known (tds_map_keys + the actors' keys) and at most
+    15 of them the bit-plane kernels serve the launch -- face lists up to 144 x 144 (float32) / 208 x 208 (uint8), above nothing but the 64
+    bytes of work queues -- instead of the 32 KB per camera that would serve every path."""
+    import bench
+    from torchdrivesim_amd import _ops
+    from torchdrivesim_amd.utils import Resolution
+    sim, actions, _ = bench.build_simulator(4, 16, torch.device(DEV), seed=2)
+    keys = sim._scene()['maps'][0][0].face_keys()
+    assert keys is not None and 1 <= len(keys) <= 8 and len(set(keys)) == len(keys)
+    _ops._workspaces.clear()
+    img = sim.render_egocentric(res=Resolution(256, 256), fov=35.0)
+    (ws,) = [w for w in _ops._workspaces.values() if w is not False]
+    assert ws.numel() <= 4096, ws.numel()                                     # the persistent launch's queues, nothing else
+    _ops._workspaces.clear()
+    small = sim.render_egocentric(res=Resolution(64, 64), fov=35.0)
+    (ws64,) = [w for w in _ops._workspaces.values() if w is not False]
+    assert ws64.numel() >= 4 * 16 * 2048 * 16                                   # a list of 2 048 faces per camera for K3s + K3r
+    assert bool(img.any()) and bool(small.any())
+    # without the key count: the size that serves every path
+    import ctypes
+    from torchdrivesim_amd import _native as nat
+    every, bits, u8hi = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    nat.call('tds_raster_scene_workspace_bytes', torch.device(DEV), 64, 256, ctypes.byref(every))
+    nat.call('tds_raster_scene_workspace_bytes_for', torch.device(DEV), 64, 256, nat.OUT_F32, 5, ctypes.byref(bits))
+    nat.call('tds_raster_scene_workspace_bytes_for', torch.device(DEV), 64, 256, nat.OUT_F32, 40, ctypes.byref(u8hi))
+    assert bits.value <= 256 < every.value == u8hi.value

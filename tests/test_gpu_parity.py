@@ -514,7 +514,7 @@ def test_k3_split_form_equals_the_fused_kernel_and_the_oracle(ops, oracle, town,
                         # room for 300 faces per camera: most Town01 views hold more, their cameras go to the fused kernel
                         n_img = B * A
                         nbytes = ((n_img + 1) * 4 + 255) // 256 * 256 + (n_img * 4 + 255) // 256 * 256 + n_img * 300 * 16
-                        ops._raster_workspace = lambda d, n, r: torch.empty(nbytes, dtype=torch.uint8, device=d)
+                        ops._raster_workspace = lambda d, n, r, *rest: torch.empty(nbytes, dtype=torch.uint8, device=d)
                     try:
                         img, r = render_both(ops, oracle, smap, static, st, sz, mask, st[..., :2].copy(), cam_sc, fov, res, dtype)
                     finally:

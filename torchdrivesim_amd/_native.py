@@ -64,6 +64,9 @@ _SIGNATURES = {
     'tds_raster_scene_bwd_idx_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
     'tds_raster_scene_bwd_f32': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
     'tds_raster_scene_workspace_bytes': [_i64, _i32, ctypes.POINTER(_i64)],
+    'tds_raster_scene_workspace_bytes_for': [_i64, _i32, _i32, _i32, ctypes.POINTER(_i64)],
+    'tds_map_keys': [_vp, _vp, _i32, ctypes.POINTER(_i32)],
+    'tds_mapset_keys': [_vp, _vp, _i32, ctypes.POINTER(_i32)],
     'tds_raster_mesh': [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _i32, _vp],
     'tds_buffer_create': [_i64, _i32, _i32, ctypes.POINTER(_vp)],
     'tds_buffer_ptr': [_vp],

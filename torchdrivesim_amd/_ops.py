@@ -344,6 +344,14 @@ class StaticMap:
             raise RuntimeError('StaticMap was destroyed')
         return self._h
 
+    def face_keys(self):
+        """distinct face keys of the map (None: more than 64) -- with the actors' keys they decide which rasteriser serves a launch"""
+        if not hasattr(self, '_face_keys'):
+            buf, n = (ctypes.c_uint32 * 64)(), ctypes.c_int(0)
+            nat.call('tds_map_keys', self.device, self.handle, ctypes.cast(buf, ctypes.c_void_p), 64, ctypes.byref(n))
+            self._face_keys = None if n.value < 0 else [int(buf[i]) for i in range(n.value)]
+        return self._face_keys
+
     def info(self):
         buf = (ctypes.c_int64 * 8)()
         nat.call('tds_map_info', self.device, self.handle, buf)
@@ -389,6 +397,14 @@ class StaticMapSet:
 
     def rank_of(self, level):
         return self.maps[0].rank_of(level)
+
+    def face_keys(self):
+        """distinct face keys over the maps of the set (None: more than 64)"""
+        if not hasattr(self, '_face_keys'):
+            buf, n = (ctypes.c_uint32 * 64)(), ctypes.c_int(0)
+            nat.call('tds_mapset_keys', self.device, self.handle, ctypes.cast(buf, ctypes.c_void_p), 64, ctypes.byref(n))
+            self._face_keys = None if n.value < 0 else [int(buf[i]) for i in range(n.value)]
+        return self._face_keys
 
     def select(self, idx):
         """the same maps for a sub-batch / re-ordered batch"""
@@ -481,13 +497,20 @@ use_bitplanes = True      # test hook: False forces the packed-key kernels
 use_index_slices = True   # test hook: False makes the raster backward read the forward image (the path of the packed-key kernels)
 
 
-def _raster_workspace(dev, n_img, res):
+def _raster_workspace(dev, n_img, res, out_mode=None, n_keys=-1):
+    """n_keys: distinct keys of the launch (map + actors) when the caller knows them (-1: not known) -- with at most 15 the bit-plane kernels
+    run, which above 144 x 144 (float32) / 208 x 208 (uint8) need nothing but their 64 bytes of work queues (128 bytes instead of 2.1 GB at
+    B x A = 65 536 cameras of 256 x 256)"""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident(), n_img, res)
+    n_keys = int(n_keys) if (out_mode is not None and 0 <= n_keys <= 15) else -1
+    key = (idx, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident(), n_img, res, out_mode if n_keys >= 0 else None, n_keys >= 0)
     ws = _workspaces.get(key)
     if ws is None:
         n = ctypes.c_int64(0)
-        nat.call('tds_raster_scene_workspace_bytes', dev, n_img, res, ctypes.byref(n))
+        if n_keys >= 0:
+            nat.call('tds_raster_scene_workspace_bytes_for', dev, n_img, res, out_mode, n_keys, ctypes.byref(n))
+        else:
+            nat.call('tds_raster_scene_workspace_bytes', dev, n_img, res, ctypes.byref(n))
         ws = torch.empty(max(int(n.value), 0), dtype=torch.uint8, device=dev) if n.value > 0 else False
         _workspaces[key] = ws
         while len(_workspaces) > _WORKSPACES_MAX:
@@ -637,7 +660,10 @@ def raster_scene(smap, state, agent_sc, tmpl, actor_key, mask, cam_xy, cam_sc, f
     if key_table is not None and use_bitplanes:
         vals = [int(v) & 0xffffffff for v in key_table]
         kt = (ctypes.c_uint32 * max(len(vals), 1))(*vals)
-    ws = _raster_workspace(dev, B * Nc, int(res)) if use_workspace else None
+    n_keys = -1
+    if kt is not None:
+        n_keys = len(set(vals) | set(smap.face_keys())) if smap.face_keys() is not None else -1
+    ws = _raster_workspace(dev, B * Nc, int(res), mode, n_keys) if use_workspace else None
     ev = None
     if raster_events is not None:          # bench.py: HIP events on the launch stream, right around the kernel
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

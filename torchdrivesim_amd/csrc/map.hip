@@ -350,6 +350,13 @@ TDS_EXPORT int tds_map_destroy(tds_map_t *map) {
     return TDS_OK;
 }
 
+TDS_EXPORT int tds_map_keys(const tds_map_t *map, uint32_t *keys, int cap, int *n) {
+    TDS_CHECK_ARG(map && n && (keys || cap == 0) && cap >= 0, "tds_map_keys: bad arguments");
+    *n = map->n_uniq;
+    for (int i = 0; i < map->n_uniq && i < cap; ++i) keys[i] = map->uniq_keys[i];
+    return TDS_OK;
+}
+
 TDS_EXPORT int tds_map_info(const tds_map_t *map, int64_t *info) {
     TDS_CHECK_ARG(map && info, "tds_map_info: null pointer");
     info[0] = map->V; info[1] = map->F; info[2] = map->view.nx; info[3] = map->view.ny;
@@ -620,6 +627,13 @@ TDS_EXPORT int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset
         return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
     }
     *out = s;
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_mapset_keys(const tds_mapset_t *set, uint32_t *keys, int cap, int *n) {
+    TDS_CHECK_ARG(set && n && (keys || cap == 0) && cap >= 0, "tds_mapset_keys: bad arguments");
+    *n = set->n_uniq;
+    for (int i = 0; i < set->n_uniq && i < cap; ++i) keys[i] = set->uniq_keys[i];
     return TDS_OK;
 }
 

@@ -2594,6 +2594,21 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
     return TDS_OK;
 }
 
+TDS_EXPORT int tds_raster_scene_workspace_bytes_for(int64_t n_img, int res, int out_mode, int n_keys, int64_t *bytes) {
+    TDS_CHECK_ARG(bytes, "tds_raster_scene_workspace_bytes_for: null output");
+    TDS_CHECK_ARG(res > 0 && res <= 4096 && n_img >= 0, "tds_raster_scene_workspace_bytes_for: bad arguments");
+    TDS_CHECK_ARG(out_mode == TDS_OUT_F32 || out_mode == TDS_OUT_U8, "tds_raster_scene_workspace_bytes_for: unknown output mode %d", out_mode);
+    if (n_keys < 0 || n_keys > MAX_KEYS) return tds_raster_scene_workspace_bytes(n_img, res, bytes);
+    // the bit-plane kernels: face lists where the split form can run for this output type, the work queues of the persistent launch always
+    int64_t lists = 0;
+#ifndef TDS_TESTING
+    if (res <= (out_mode == TDS_OUT_F32 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8))
+#endif
+        lists = (((n_img + 1) * 4 + 255) & ~(int64_t)255) + ((n_img * 4 + 255) & ~(int64_t)255) + n_img * LIST_CAPS * 16;
+    *bytes = ((lists + 63) & ~(int64_t)63) + QUEUE_BYTES + 64;
+    return TDS_OK;
+}
+
 namespace {
 // what the scene kernels need to know about the static map(s) of a launch
 struct MapSource {
