@@ -61,3 +61,11 @@ def test_fast_candidates_end_the_search_at_once():
 def test_a_launch_that_is_not_write_bound_takes_the_first_buffers():
     bufs, rep, t = ring([5.1, 5.1, 5.1], fill=1.9)                              # the uint8 mode: 5.1 ms against a 1.9 ms fill
     assert rep['write_bound'] is False and rep['kept'] == [0, 1] and len(rep['launch_ms']) == 2 and rep['fast'] is None
+
+
+def test_an_in_between_buffer_that_passes_the_fill_yardstick_loses_to_a_faster_one():
+    """spread-out pages: fill_ takes 7.8 ms, so a 7.44 ms buffer (the 15/16 class) passes `0.98 x fill` -- but not `1.03 x the fastest launch seen`"""
+    bufs, rep, t = ring([7.44, F, F, F], fill=7.8)
+    assert rep['launch_ms'] == [7.44, F, F] and rep['fast'] == [False, True, True] and rep['kept'] == [1, 2]
+    bufs, rep, t = ring([7.44, 7.45, 7.46, 7.44], fill=7.8, candidates=4)           # nothing faster exists: they are what this device offers
+    assert rep['launch_ms'] == [7.44, 7.45] and rep['kept'] == [0, 1]
