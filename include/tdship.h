@@ -253,7 +253,7 @@ int tds_raster_scene_workspace_bytes_for(int64_t n_img, int res, int out_mode, i
  * The rasteriser is bound by the HBM write stream, and what a write stream reaches on MI355X depends on the PHYSICAL pages under the
  * buffer: a large hipMalloc is served at 1, 15/16 or 7/8 of the rate for as long as it lives, whatever its virtual address and whatever
  * the store pattern (about one 51.5 GB allocation in three is at 7/8); a buffer whose physical pages are spread over twice its size
- * never was (tools/alloc_probe.hip).  tds_buffer_create builds such a buffer: chunks of 8 MiB created alternately
+ * hardly ever is (one of 100 probed, at 15/16; DESIGN.md section 4, tools/alloc_probe.hip).  tds_buffer_create builds such a buffer: chunks of 8 MiB created alternately
  * with spacer chunks that are released once the buffer is mapped (hipMemCreate / hipMemMap; needs twice the size free while it runs,
  * and falls back to dense chunks when that is not there).  Below 256 MiB, or with TDS_BUFFER_DENSE, it is one hipMalloc.
  * These are explicit create / destroy calls like tds_map_create: no per-step entry point allocates.
