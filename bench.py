@@ -446,7 +446,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help="skip the extra `configs` / `roofline_u8` entries (BASELINE.json's configs 2, 3, 5; N = 1 only)")
     ap.add_argument('--cpu-scenes', type=int, default=768, help='scenes of the CPU-baseline sample (all usable cores, about 10 s at 16 of them); the single-thread run uses 16')
-    ap.add_argument('--overlap', action='store_true', help='compute_collision / compute_offroad on a second stream, enqueued ahead of the raster launch (Simulator.overlap_infractions = True)')
+    ap.add_argument('--overlap', choices=('reserved', 'stream', 'off'), default='reserved',
+                    help="where compute_collision / compute_offroad run: 'reserved' (default) -- the loop runs on a stream that is kept off 4 CUs per XCD and the "
+                         "metrics on a stream confined to those 32 CUs, beside the raster launch (Simulator.overlap_infractions = 'reserved'); 'stream' -- a plain "
+                         "second stream (slower: nothing fits beside the persistent launch); 'off' -- behind the launch on the caller's stream")
     ap.add_argument('--no-default-path', action='store_true', help='skip the `default_path` entry (the loop without out=; N = 1 only)')
     ap.add_argument('--ring-candidates', type=int, default=4, help='output allocations probed at most for the two-buffer image ring')
     ap.add_argument('--dry-run', action='store_true', help='no GPU, no kernels: exercises launch, barrier, reduction and the JSON line only')
@@ -539,7 +542,13 @@ def main():
         # it saw is reported per rank (`roofline.ring_probe`, `per_rank`).  The reference-shaped call without `out=` is measured after the
         # timed region and reported beside (`default_path`).
         from torchdrivesim_amd.rendering import allocate_image_ring
-        sim.overlap_infractions = args.overlap
+        # The metrics run BESIDE the raster launch: the loop's stream (sim.raster_stream()) is kept off four CUs per XCD -- the write-bound launch loses
+        # nothing on 224 of 256 CUs -- and the metric kernels, foreseen from the previous step, are enqueued on a stream confined to those 32 CUs
+        # (tds_stream_create, hipExtStreamCreateWithCUMask).  Same kernels, same bits; `--overlap off` puts them behind the launch.
+        sim.overlap_infractions = {'reserved': 'reserved', 'stream': True, 'off': False}[args.overlap]
+        loop_stream = sim.raster_stream() if args.overlap == 'reserved' else torch.cuda.current_stream(device)
+        torch.cuda.synchronize(device)
+        torch.cuda.set_stream(loop_stream)
         bufs, ring_probe = allocate_image_ring(lambda out: sim.render_egocentric(res=res, fov=FOV, out=out), (B, A, 3, RES, RES), torch.float32, device,
                                                count=2, candidates=args.ring_candidates)
         first_touch_ms = float(np.mean(ring_probe['first_touch_ms']))
@@ -601,7 +610,11 @@ def main():
                           **same_run))
         line['methodology'] = ('images are rendered into a two-buffer ring the loop owns (rendering.allocate_image_ring: buffers from the library\'s '
                                'allocator, each measured against the fill_ rate of the same run; `roofline.ring_probe`); `default_path` is the same '
-                               'loop with the reference-shaped call render_egocentric() without out= (a fresh tensor per step from the image pool)')
+                               'loop with the reference-shaped call render_egocentric() without out= (a fresh tensor per step from the image pool); '
+                               + {'reserved': 'the loop runs on a stream kept off 4 CUs per XCD (224 of 256 CUs for the raster launch) and the metric kernels on a '
+                                              'stream confined to those 32 CUs, beside the launch (Simulator.overlap_infractions = \'reserved\'; --overlap off: behind it)',
+                                  'stream': 'the metric kernels on a plain second stream', 'off': 'the metric kernels behind the raster launch on the same stream'}[args.overlap])
+        line['overlap'] = args.overlap
         if world > 1:
             line['per_rank_agent_steps_per_s'] = [B * A * args.steps / t for t in per_rank]
             line['per_rank'] = all_reports
@@ -640,6 +653,8 @@ def main():
                                             min_launch_ms=float(np.min(ms)), max_launch_ms=float(np.max(ms)),
                                             image_allocation='torch memory pool over tds_torch_alloc (csrc/alloc.hip)' if _ops.use_image_pool else 'torch.empty')
                 bufs = None
+            torch.cuda.synchronize(device)
+            torch.cuda.set_stream(torch.cuda.default_stream(device))      # the other entries build their own simulators on the default stream, all CUs
             if not args.no_configs:
                 line['roofline_u8'] = u8_mode(device, args.steps, args.warmup, B, A)
                 line['roofline_128'] = low_res_mode(device, args.steps, args.warmup, B, A)

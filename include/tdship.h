@@ -270,6 +270,21 @@ int tds_buffer_destroy(tds_buffer_t *buf);
 void *tds_torch_alloc(size_t size, int device, void *stream);          /* NULL on failure */
 void tds_torch_free(void *ptr, size_t size, int device, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Streams confined to a part of the device's CUs (no reference counterpart).
+ *
+ * The persistent raster launch holds every CU it may use until its last image is out, so nothing runs beside it -- unless it is kept off
+ * a few CUs.  tds_stream_create makes a stream whose kernels only run on the CUs of `cu_mask` (hipExtStreamCreateWithCUMask: bit i of the
+ * mask is CU i / 8 of XCD i % 8 on MI355X; `n_words` 32-bit words, 8 for 256 CUs; NULL = all CUs).  A loop renders on a stream that leaves
+ * four CUs per XCD out and computes its metrics on a stream confined to those 32: the write-bound launch loses nothing (tools/cu_mask_probe.hip)
+ * and the metrics run beside it (Simulator.overlap_infractions = 'reserved').  tds_raster_scene sizes its persistent launch for the CUs of the
+ * stream it is given.  Explicit create / destroy, like the other handles.
+ * ---------------------------------------------------------------------------------------------------------- */
+int tds_stream_create(int device, const uint32_t *cu_mask, int n_words, void **stream);
+int tds_stream_destroy(int device, void *stream);
+int tds_device_cu_count(int device, int *cus);
+
+
 /* Backward of tds_raster_scene with respect to the poses of the actors and cameras.  The CV2 backend of the reference has no
  * gradient (rendering/cv2.py:27-70 runs in numpy); this one is build-defined (edge sampling of the actors' outlines against the
  * forward image, DESIGN.md "K3 backward") and plays the role of the pytorch3d backend's soft-blend gradient

@@ -579,6 +579,40 @@ def test_foreseen_infractions_are_enqueued_ahead_of_the_raster_launch():
     assert torch.equal(sim.compute_collision(), ref.compute_collision())
 
 
+@pytest.mark.parametrize('own_stream', [False, True])
+def test_metrics_on_reserved_cus_beside_the_raster_launch(own_stream):
+    """overlap_infractions = 'reserved' (round 4): the raster launch runs on a stream that is kept off four CUs per XCD (tds_stream_create,
+    hipExtStreamCreateWithCUMask) and the metrics on a stream confined to those -- either with the loop itself on the raster stream
+    (`with torch.cuda.stream(sim.raster_stream())`) or with the library's detour from the caller's stream.  Same kernels, same bits as the serial
+    order, step after step (loop: examples/gym_env.py:83-126 of the reference)."""
+    import bench, contextlib
+    from torchdrivesim_amd import _ops
+    from torchdrivesim_amd.utils import Resolution
+    sim, actions, _ = bench.build_simulator(16, 64, torch.device(DEV), seed=9)
+    ref, _, _ = bench.build_simulator(16, 64, torch.device(DEV), seed=9)
+    rs, ms = _ops.reserved_streams(torch.device(DEV))
+    assert rs.cuda_stream != ms.cuda_stream and sim.raster_stream().cuda_stream == rs.cuda_stream
+    res = Resolution(256, 256)
+    sim.overlap_infractions = 'reserved'
+    out = torch.empty(16, 64, 3, 256, 256, device=DEV)
+    torch.cuda.synchronize()
+    with (torch.cuda.stream(rs) if own_stream else contextlib.nullcontext()):
+        for i in range(4):
+            sim.step(actions[i])
+            img = sim.render_egocentric(res=res, fov=35.0, out=out)
+            col, off = sim.compute_collision(), sim.compute_offroad()
+            if i >= 1:
+                assert col is sim._fork[3][('collision', None)][0]               # foreseen: enqueued on the reserved CUs ahead of the launch
+            ref.step(actions[i])
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(img, ref.render_egocentric(res=res, fov=35.0))
+            assert torch.equal(col, ref.compute_collision()) and torch.equal(off, ref.compute_offroad())
+        # without out=: the image comes from the pool, written on the raster stream, consumed here
+        img2 = sim.render_egocentric(res=res, fov=35.0)
+        assert torch.equal(img2, out)
+    torch.cuda.synchronize()
+
+
 def test_image_ring_is_chosen_among_candidates():
     """rendering.allocate_image_ring on the device: the buffers come from the library's allocator (spread-out physical pages, not torch's
     pool), are distinct, hold a rendered image, and the report carries the yardstick.  The decision logic itself is tested on the CPU with

@@ -605,6 +605,41 @@ def owned_image(shape, dtype=torch.float32, device="cuda", dense=False) -> torch
     return torch.as_tensor(_OwnedBuffer(shape, dtype, device, dense=dense), device=device)
 
 
+# ---- streams confined to a part of the CUs ---------------------------------------------------------------------------------------------
+_reserved_streams = {}       # (device index, CUs per XCD) -> (raster stream, metric stream, handles kept alive)
+
+
+def reserved_streams(device, per_xcd: int = 4):
+    """(raster_stream, metric_stream) of `device`: two torch.cuda.ExternalStream over tds_stream_create -- the first may use every CU but
+    `per_xcd` per XCD, the second ONLY those (mask bit i is CU i / 8 of XCD i % 8 on MI355X, tools/cu_mask_probe.hip).  The persistent raster
+    launch holds every CU it may use until its last image is out; kept off 32 of the 256 it loses nothing (it is bound by the write stream)
+    and the metric kernels have somewhere to run beside it (Simulator.overlap_infractions = 'reserved').  Created once per device."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _reserved_streams.get((idx, per_xcd))
+    if ent is None:
+        L = nat.lib()
+        cus = ctypes.c_int(0)
+        nat.check(L.tds_device_cu_count(idx, ctypes.byref(cus)), 'tds_device_cu_count')
+        n_words = (cus.value + 31) // 32
+        reserved = [0] * n_words
+        for bit in range(min(8 * per_xcd, cus.value)):
+            reserved[bit // 32] |= 1 << (bit % 32)
+        every = [0] * n_words
+        for bit in range(cus.value):
+            every[bit // 32] |= 1 << (bit % 32)
+        rest = [e & ~r for e, r in zip(every, reserved)]
+        handles = []
+        for mask in (rest, reserved):
+            arr = (ctypes.c_uint32 * n_words)(*mask)
+            h = ctypes.c_void_p()
+            nat.check(L.tds_stream_create(idx, ctypes.cast(arr, ctypes.c_void_p), n_words, ctypes.byref(h)), 'tds_stream_create')
+            handles.append(h)
+        ent = _reserved_streams[(idx, per_xcd)] = (torch.cuda.ExternalStream(handles[0].value, device=torch.device('cuda', idx)),
+                                                   torch.cuda.ExternalStream(handles[1].value, device=torch.device('cuda', idx)), handles)
+    return ent[0], ent[1]
+
+
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch
 raster_events = None
 #: the same for the launches of the raster backward kernel

@@ -2412,7 +2412,7 @@ inline uint32_t *workspace_queue(void *workspace, int64_t &bytes) {
 #ifdef TDS_TESTING
 int g_debug = 0;
 #endif
-int persistent_grid(int64_t items, size_t lds_bytes) {
+int persistent_grid(int64_t items, size_t lds_bytes, hipStream_t stream) {
     constexpr int MAX_DEVICES = 64;
     static std::atomic<int> cus_of[MAX_DEVICES];          // per device: a process may drive several (zero-initialised: not looked up yet)
     int dev = 0, cus = 0;
@@ -2422,6 +2422,17 @@ int persistent_grid(int64_t items, size_t lds_bytes) {
         int n = 0;
         cus = (dev >= 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
         if (dev >= 0) cus_of[dev].store(cus, std::memory_order_relaxed);
+    }
+    // a stream confined to a part of the CUs (tds_stream_create): the launch is sized for those
+    if (stream != nullptr) {
+        uint32_t mask[16] = {0};
+        if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess) {
+            int n = 0;
+            for (int i = 0; i < 16; ++i) n += __builtin_popcount(mask[i]);
+            if (n > 0 && n < cus) cus = n;
+        } else {
+            (void)hipGetLastError();
+        }
     }
     const size_t granted = (lds_bytes + 2047) & ~(size_t)2047;                  // LDS is granted in 2 KiB steps
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(granted, 1)));
@@ -2782,7 +2793,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                     queue = ws_queue;
                     if (tds::zero_async(queue, (size_t)QUEUE_BYTES, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the work queues failed"); return TDS_EHIP; }
                 }
-                dim3 grid((unsigned)(persist ? persistent_grid(only != nullptr ? 512 : n_img * cb.strips, lds) : n_img * cb.strips));
+                dim3 grid((unsigned)(persist ? persistent_grid(only != nullptr ? 512 : n_img * cb.strips, lds, (hipStream_t)stream) : n_img * cb.strips));
                 const SceneArgs base = a;
                 auto launch_b = [&](auto kern) {            // scenes without per-camera triangles
                     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -605,16 +605,27 @@ class Simulator:
     overlap_infractions = False
     _side_streams: Dict[int, Any] = {}
     _side_priority = -1          # HIP stream priority of the side stream (-1: high)
+    #: overlap_infractions = 'reserved' (round 4): the raster launch runs on a stream that is kept off `_reserved_per_xcd` CUs per XCD, the metrics on a
+    #: stream confined to exactly those (`_ops.reserved_streams`, hipExtStreamCreateWithCUMask).  The write-bound launch loses nothing on 224 of 256
+    #: CUs (tools/cu_mask_probe.hip) and the metrics -- served slowly beside the saturated write stream, but served -- finish well inside its 7 ms.
+    _reserved_per_xcd = 4
 
     def _fork_sources(self):
         return [self.kinematic_model.get_state(), self.present_mask, self.agent_size, self.agent_type]
 
     def _side_stream(self, device):
+        if self.overlap_infractions == 'reserved':
+            return _ops.reserved_streams(device, Simulator._reserved_per_xcd)[1]          # confined to the CUs the raster launch is kept off
         idx = device.index if device.index is not None else torch.cuda.current_device()
         side = Simulator._side_streams.get(idx)
         if side is None:
             side = Simulator._side_streams[idx] = torch.cuda.Stream(device=device, priority=Simulator._side_priority)
         return side
+
+    def raster_stream(self):
+        """The stream that is kept off the reserved CUs (overlap_infractions = 'reserved'): a loop that runs under
+        `with torch.cuda.stream(sim.raster_stream()):` renders on it without a detour, and its metrics run beside on the reserved CUs."""
+        return _ops.reserved_streams(self.kinematic_model.get_state().device, Simulator._reserved_per_xcd)[0]
 
     def _metric_fn(self, key):
         name = key[0]
@@ -889,9 +900,26 @@ class Simulator:
                     wk = scene['wp_keys'][i_map]
                     extra = dict(extra_tri=wp_tri[sl], extra_key=torch.full(wp_tri[sl].shape[:3], wk, dtype=torch.int32, device=state.device))
                     ktab = None if ktab is None else sorted(set(ktab) | {wk})
-                out.append(self.renderer.render_scene(smap, cut(state), cut(agent_sc), cut(tmpl_all), k, cut(mask).contiguous(),
-                                                      cut(camera_xy), cut(camera_sc), res=res, fov=fov, key_table=ktab, differentiable=diff, **extra,
-                                                      **out_arg, **(dict(ego_cameras=ego_n) if ego_n else {})))
+                launch = lambda: self.renderer.render_scene(smap, cut(state), cut(agent_sc), cut(tmpl_all), k, cut(mask).contiguous(),     # noqa: E731
+                                                            cut(camera_xy), cut(camera_sc), res=res, fov=fov, key_table=ktab, differentiable=diff, **extra,
+                                                            **out_arg, **(dict(ego_cameras=ego_n) if ego_n else {}))
+                if self.overlap_infractions == 'reserved' and not diff and self._fork is not None and state.is_cuda and \
+                        self._fork[2] != _ops.reserved_streams(state.device, Simulator._reserved_per_xcd)[0]:
+                    # the launch goes to the stream that is kept off the reserved CUs: it waits for what the caller's stream has enqueued so far
+                    # (the fork event) and the caller's stream waits for it -- beside it, on the reserved CUs, the foreseen metrics are running.
+                    # (A loop that makes that stream its current one -- `with torch.cuda.stream(sim.raster_stream()):` -- saves these two waits.)
+                    main = self._fork[2]
+                    rs = _ops.reserved_streams(state.device, Simulator._reserved_per_xcd)[0]
+                    rs.wait_event(self._fork[0])
+                    with torch.cuda.stream(rs):
+                        img = launch()
+                    img.record_stream(main)
+                    done = torch.cuda.Event()
+                    done.record(rs)
+                    main.wait_event(done)
+                    out.append(img)
+                else:
+                    out.append(launch())
             return out[0] if len(out) == 1 else torch.cat(out, dim=0)
         if out is not None:
             raise RuntimeError(f'`out=` is served by HipRenderer only, not by {type(self.renderer).__name__}')
