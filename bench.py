@@ -196,7 +196,7 @@ class _ImageProbe(torch.autograd.Function):
         return ctx.saved_tensors[0], None
 
 
-def other_configs(device, steps, warmup, only=None):
+def other_configs(device, steps, warmup, only=None, overlap='reserved'):
     """BASELINE.json's other single-GPU configurations (2, 3, 5) and the uint8 output mode of the headline kernel, measured in
     this run after the timed region: ms/step, agent-steps/s, the dominant kernel and its fraction of the HBM roof."""
     from torchdrivesim_amd import _ops, lanelet2
@@ -228,6 +228,12 @@ def other_configs(device, steps, warmup, only=None):
         state0 = sim.get_state().clone()
 
         ring = None
+        if not name.startswith('config5') and overlap == 'reserved':
+            # as the headline: the loop's stream is kept off four CUs per XCD, the metrics run beside the raster launch on those (the differentiable
+            # configuration cannot: its render is an autograd node of the caller's stream)
+            sim.overlap_infractions = 'reserved'
+            torch.cuda.synchronize(device)
+            torch.cuda.set_stream(sim.raster_stream())
         if not name.startswith('config5'):
             # the forward-only configurations render into a two-buffer ring like the headline (the differentiable one cannot: autograd owns its image)
             from torchdrivesim_amd.rendering import allocate_image_ring
@@ -257,6 +263,8 @@ def other_configs(device, steps, warmup, only=None):
             # gradient of a mean: the loss costs one fused multiply-reduce over the image instead of round 1's mean + its materialised gradient
             sink['w'] = torch.rand(B, A, 3, RES, RES, device=device)
         dt, k_fwd, k_bwd = timed(fwd_bwd if name.startswith('config5') else fwd)
+        torch.cuda.synchronize(device)
+        torch.cuda.set_stream(torch.cuda.default_stream(device))
         what = {'config2': 'step + render_egocentric 256x256 + compute_collision(iou)',
                 'config3': 'config2 + compute_offroad + compute_wrong_way (Town01 lane map)',
                 'config5': 'step + render + collision + offroad, then backward through kinematics, IoU, off-road and the rasteriser; '
@@ -268,6 +276,7 @@ def other_configs(device, steps, warmup, only=None):
                    dominant_kernel_frac_of_hbm_peak=None if not k_fwd else B * A * ALGO_BYTES_PER_IMAGE / (k_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS)
         if ring is not None:
             ent['ring_probe'] = dict(launch_ms=ring_rep['launch_ms'], fast=ring_rep['fast'], kept=ring_rep['kept'])
+            ent['overlap'] = overlap
         else:
             # autograd owns the image of the differentiable step: a fresh tensor per step from the image pool (spread-out physical pages)
             ent['image_allocation'] = 'per step, torch memory pool over tds_torch_alloc (csrc/alloc.hip)'
@@ -663,7 +672,7 @@ def main():
                 sink.clear()
                 _ops.release_image_pool()
                 torch.cuda.empty_cache()
-                line['configs'] = other_configs(device, args.steps, args.warmup)
+                line['configs'] = other_configs(device, args.steps, args.warmup, overlap=args.overlap)
             if not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline(host, min(args.cpu_scenes, B), A)
         print(json.dumps(line), flush=True)
