@@ -137,7 +137,7 @@ class _DeviceTimer:
 
 
 def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 4, reps: int = 2, fast: float = 0.98,
-                        spread: float = 1.03, allow_aliasing: bool = False, timer=None, alloc=None):
+                        spread: float = 1.015, allow_aliasing: bool = False, timer=None, alloc=None):
     """`count` DISTINCT caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), each
     checked to be one the write stream of the launch is served at full rate into.
 
@@ -149,7 +149,8 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
         a candidate is fast  iff  its launch takes at most `fast` x the fill_ time (the fastest fill_ seen over the candidates)
                              and  at most `spread` x the fastest launch seen over the candidates
     (the second clause catches the in-between class -- 7.45 ms where 7.03 is possible -- that passes the first when fill_ itself is slow into
-    spread-out pages: 7.6 - 7.9 ms instead of 7.45; it cannot reject a candidate before a faster one has been seen).
+    spread-out pages: 7.6 - 7.9 ms instead of 7.45 -- and, at 1.5 %, the buffers that are merely a little slower: spread-out buffers differ by 1 - 2 % among
+    themselves, for as long as they live; it cannot reject a candidate before a faster one has been seen).
     Candidates are allocated one after the other and all held until the choice is made (a rejected allocation that is freed would be handed
     out again); the search ends as soon as `count` fast ones exist, and never before unless `candidates` (cut to what the device holds)
     are exhausted.  When fewer than `count` are fast, the ring is filled up with the best of the others -- still distinct buffers: step i
