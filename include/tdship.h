@@ -283,6 +283,11 @@ void tds_torch_free(void *ptr, size_t size, int device, void *stream);
 int tds_stream_create(int device, const uint32_t *cu_mask, int n_words, void **stream);
 int tds_stream_destroy(int device, void *stream);
 int tds_device_cu_count(int device, int *cus);
+/* Where do the kernels of `stream` run?  Enqueues `n` one-wave workgroups that each keep their CU busy for a moment and write
+ * XCC_ID << 16 | (HW_ID bits 15..8: SE, SH, CU) of the CU they ran on to places[blockIdx] (device memory, n words).  With n of a few
+ * thousand every CU the stream may use shows up.  The caller synchronises and reads; the mask layout documented above is an observation of
+ * one MI355X in SPX mode, and this is how the host verifies it on the device at hand before it relies on it (_ops.reserved_streams). */
+int tds_stream_places(void *stream, uint32_t *places, int n);
 
 
 /* Backward of tds_raster_scene with respect to the poses of the actors and cameras.  The CV2 backend of the reference has no

@@ -65,7 +65,7 @@ def test_two_real_workers_under_torch_distributed_run():
 def test_eight_real_workers_on_one_gpu():
     """The largest world the driver launches (BASELINE.json config 4: 8 GPUs), with eight real workers sharing the one GPU of a test box:
     rendezvous of eight children, eight image rings probed side by side, eight per-rank reports in the one line."""
-    args = ['--gpus', '8', '--batch', '32', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-configs']
+    args = ['--gpus', '8', '--batch', '32', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-configs', '--ring-candidates', '2']
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=1500,
                        env=clean_env(HIP_VISIBLE_DEVICES='0,0,0,0,0,0,0,0'))
     assert r.returncode == 0, r.stderr[-3000:]

@@ -112,3 +112,74 @@ def test_the_workspace_is_sized_for_the_kernels_that_run():
     nat.call('tds_raster_scene_workspace_bytes_for', torch.device(DEV), 64, 256, nat.OUT_F32, 5, ctypes.byref(bits))
     nat.call('tds_raster_scene_workspace_bytes_for', torch.device(DEV), 64, 256, nat.OUT_F32, 40, ctypes.byref(u8hi))
     assert bits.value <= 256 < every.value == u8hi.value
+
+
+def test_a_headline_sized_buffer_is_built_in_seconds():
+    """51.5 GB = the image of the headline shard: 6 144 chunks + their spacers, 12 k hipMemCreate and 6 k hipMemMap -- about a second on the
+    boxes of rounds 4 and 5.  The time is printed so that the driver's log shows it (that run took 642 s and nothing said where)."""
+    import time
+    from torchdrivesim_amd import _native as nat
+    L = nat.lib()
+    h = ctypes.c_void_p()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nat.check(L.tds_buffer_create(1024 * 64 * 3 * 256 * 256 * 4, 0, 0, ctypes.byref(h)), 'tds_buffer_create')
+    t1 = time.perf_counter()
+    chunks, spread = ctypes.c_int64(), ctypes.c_int()
+    nat.check(L.tds_buffer_info(h, None, ctypes.byref(chunks), ctypes.byref(spread)), 'tds_buffer_info')
+    nat.check(L.tds_buffer_destroy(h), 'tds_buffer_destroy')
+    t2 = time.perf_counter()
+    print(f'tds_buffer_create(51.5 GB): {t1 - t0:.2f} s, destroy {t2 - t1:.2f} s, {chunks.value} chunks, spread {spread.value}')
+    assert (chunks.value, spread.value) == (6144, 1)
+    assert t1 - t0 < 5.0, f'building a 51.5 GB buffer took {t1 - t0:.1f} s'
+
+
+def test_a_buffer_that_does_not_fit_with_its_spacers_is_built_dense_and_nothing_leaks():
+    """create_spread's low-memory branch (alloc.hip: the spacers are given back when hipMemCreate runs out) and tds_torch_alloc's dense fallback:
+    with most of the device held, a buffer that fits only WITHOUT spacers must still come (its tail as dense as a hipMalloc), one that does not
+    fit at all must fail with TDS_ENOMEM, and either way the driver has all of it back afterwards."""
+    from torchdrivesim_amd import _native as nat
+    L = nat.lib()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free0, total = torch.cuda.mem_get_info(DEV)
+    want = 6 << 30
+    # leave room for the buffer and half of its spacers: the spacer chunks run out on the way
+    hold_bytes = free0 - want - (want // 2)
+    assert hold_bytes > 0
+    hold = ctypes.c_void_p()
+    nat.check(L.tds_buffer_create(hold_bytes, 0, nat.BUFFER_DENSE, ctypes.byref(hold)), 'tds_buffer_create(dense)')
+    try:
+        free1, _ = torch.cuda.mem_get_info(DEV)
+        assert free1 < want * 2
+        h = ctypes.c_void_p()
+        nat.check(L.tds_buffer_create(want, 0, 0, ctypes.byref(h)), 'tds_buffer_create')
+        n, chunks, spread = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        nat.check(L.tds_buffer_info(h, ctypes.byref(n), ctypes.byref(chunks), ctypes.byref(spread)), 'tds_buffer_info')
+        assert n.value == want and chunks.value == want >> 23 and spread.value == 1
+        # the memory is usable end to end
+        probe = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+        ptr = L.tds_buffer_ptr(h)
+        L_hip = ctypes.CDLL('libamdhip64.so')
+        for off in (0, want // 2, want - (1 << 20)):
+            assert L_hip.hipMemset(ctypes.c_void_p(ptr + off), 0x5a, ctypes.c_size_t(1 << 20)) == 0
+            assert L_hip.hipMemcpy(ctypes.c_void_p(probe.data_ptr()), ctypes.c_void_p(ptr + off), ctypes.c_size_t(1 << 20), 3) == 0
+            assert int(probe.min()) == 0x5a == int(probe.max())
+        # nothing at all is left for a second one: TDS_ENOMEM, and what the attempt took on the way is given back
+        free2, _ = torch.cuda.mem_get_info(DEV)
+        h2 = ctypes.c_void_p()
+        rc = L.tds_buffer_create(free2 + (4 << 30), 0, 0, ctypes.byref(h2))
+        assert rc == nat.E_NOMEM and not h2.value, rc
+        free3, _ = torch.cuda.mem_get_info(DEV)
+        assert abs(free3 - free2) < (64 << 20)
+        # the entry point torch's pluggable allocator binds: same size, spread impossible -> falls back, or reports out of memory with a null
+        p = L.tds_torch_alloc(ctypes.c_size_t(free2 + (4 << 30)), 0, None)
+        assert not p
+        free4, _ = torch.cuda.mem_get_info(DEV)
+        assert abs(free4 - free2) < (64 << 20)
+        nat.check(L.tds_buffer_destroy(h), 'tds_buffer_destroy')
+    finally:
+        nat.check(L.tds_buffer_destroy(hold), 'tds_buffer_destroy')
+    torch.cuda.synchronize()
+    free5, _ = torch.cuda.mem_get_info(DEV)
+    assert abs(free5 - free0) < (128 << 20)

@@ -1,7 +1,8 @@
 """The whole step -- Simulator.step -> render_egocentric(out=) -> compute_collision -> compute_offroad -- captured into a HIP graph and
 replayed, with the metrics behind the launch, beside it on a plain second stream, and beside it on reserved CUs (the CU masks
 are not carried into a graph; the results are): no per-call entry point of the library allocates or synchronises (the work queues of the persistent raster
-launch live in the caller's workspace and are cleared by a memset node), so a captured step equals the eager one bit for bit.
+launch live in the caller's workspace and are cleared by a zeroing KERNEL, tds::zero_async -- a memset node of a captured graph is not ordered before
+the kernel node that follows it on ROCm 7.0), so a captured step equals the eager one bit for bit.
 Loop matched: examples/gym_env.py:83-126 of the reference."""
 import pytest
 import torch

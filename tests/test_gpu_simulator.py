@@ -455,10 +455,17 @@ def test_headline_shard_full_size(oracle):
     img = sim.render_egocentric(res=res, fov=35.0)
     col, off = sim.compute_collision(), sim.compute_offroad()
     assert img.shape == (B, A, 3, 256, 256) and img.dtype == torch.float32 and col.shape == off.shape == (B, A)
-    # a caller-owned output buffer receives the same image, and the metrics are the same whether they ran beside the rasteriser or after it
-    buf = torch.empty_like(img)
-    assert sim.render_egocentric(res=res, fov=35.0, out=buf) is buf and torch.equal(buf, img)
-    del buf
+    # a caller-owned output buffer receives the same image, and the metrics are the same whether they ran beside the rasteriser or after it.
+    # The SAME 51.5 GB block serves as that buffer (a second one costs 12 k hipMemCreate and twice its size transiently: VERDICT r4 item 5):
+    # every 16th scene is kept as a copy, every camera as two checksums of its bits; the block is cleared and rendered into through `out=`.
+    def checksums(t):
+        bits = t.view(torch.int32).flatten(2)
+        return bits.sum(-1, dtype=torch.int64), (bits[..., ::7].to(torch.int64) * 31 + bits[..., 3::7].to(torch.int64)).sum(-1)
+    keep, sums = img[::16].clone(), checksums(img)
+    img.zero_()
+    assert sim.render_egocentric(res=res, fov=35.0, out=img) is img and torch.equal(img[::16], keep)
+    assert all(torch.equal(a, b) for a, b in zip(checksums(img), sums))
+    del keep, sums
     sim.overlap_infractions = False                   # ... and behind it (the default)
     assert torch.equal(sim.compute_collision(), col) and torch.equal(sim.compute_offroad(), off)
     # sub-batches (first, middle, last scene and a run across the XCD boundaries of the launch) reproduce the full batch bit for bit

@@ -277,3 +277,30 @@ def test_scene_cache_is_keyed_on_its_sources():
     sim.agent_size.mul_(1.5)                                            # in-place edit of the sizes: rebuilt
     s = sim._scene()
     assert len(built) == 3 and torch.allclose(s['tmpl'][:, :3].abs().amax((1, 2, 3)), torch.full((2,), 0.75))
+
+
+def test_reserved_cu_layout_is_judged_from_where_the_streams_really_ran():
+    """overlap_infractions = 'reserved' (Simulator, loop matched: examples/gym_env.py:83-126 of the reference) relies on the meaning of the bits of a
+    CU mask, observed on one MI355X in SPX mode.  _ops.check_reserved_layout judges the places a probe kernel reported (XCC_ID << 16 | SE/SH/CU):
+    the documented layout passes; a layout whose first 32 bits are the 32 CUs of ONE XCD, overlapping streams, and a 32-CU partition do not."""
+    from torchdrivesim_amd import _ops
+    cu_words = [se << 5 | sh << 4 | cu for se in range(4) for sh in range(1) for cu in range(8)]        # 32 CUs of an XCD as HW_ID bits 15..8
+    every = [(x << 16) | w for x in range(8) for w in cu_words]
+    assert len(set(every)) == 256
+    # MI355X, SPX: mask bit i = CU i / 8 of XCD i % 8 -> four CUs of every XCD on the metric stream
+    metric = [(x << 16) | cu_words[k] for x in range(8) for k in range(4)]
+    raster = [p for p in every if p not in set(metric)]
+    assert _ops.check_reserved_layout(raster, metric, 4, 256) == (True, 'ok')
+    # a part whose mask bits run through one XCD first: all 32 reserved CUs on XCD 0
+    shifted = [p for p in every if p >> 16 == 0]
+    ok, why = _ops.check_reserved_layout([p for p in every if p >> 16 != 0], shifted, 4, 256)
+    assert not ok and 'per XCD' in why
+    # masks that are not honoured (both streams everywhere)
+    ok, why = _ops.check_reserved_layout(every, metric, 4, 256)
+    assert not ok and 'both streams' in why
+    # a CPX partition: 32 CUs
+    ok, why = _ops.check_reserved_layout(every[:28], every[28:32], 4, 32)
+    assert not ok and '32 CUs' in why
+    # CUs that neither stream reaches
+    ok, why = _ops.check_reserved_layout(raster[:-8], metric, 4, 256)
+    assert not ok and 'cover' in why

@@ -69,3 +69,19 @@ def test_an_in_between_buffer_that_passes_the_fill_yardstick_loses_to_a_faster_o
     assert rep['launch_ms'] == [7.44, F, F] and rep['fast'] == [False, True, True] and rep['kept'] == [1, 2]
     bufs, rep, t = ring([7.44, 7.45, 7.46, 7.44], fill=7.8, candidates=4)           # nothing faster exists: they are what this device offers
     assert rep['launch_ms'] == [7.44, 7.45] and rep['kept'] == [0, 1]
+
+
+def test_short_launches_stop_after_one_more_candidate_and_say_that_the_yardstick_does_not_apply():
+    """B = 256: a 12.9 GB launch (1.85 ms) never beats its fill_ (1.84 ms), whatever the buffer (all four candidates were built
+    to then keep the first two).  Three agreeing candidates end the search; the report says why.  At the headline size the same ratios keep searching."""
+    bufs, rep, t = ring([1.85, 1.86, 1.85, 1.85, 1.85], fill=1.84)
+    assert rep['launch_ms'] == [1.85, 1.86, 1.85] and rep['kept'] == [0, 1] and rep['yardstick'] == 'not applicable' and rep['write_bound']
+    assert rep['fast'] == [False, False, False] and not rep['aliased']
+    # candidates that do NOT agree (a slower placement class among them) are searched on
+    bufs, rep, t = ring([1.85, 1.99, 1.85, 1.85, 1.85], fill=1.84)
+    assert len(rep['launch_ms']) == 5 and rep['yardstick'] == 'fill' and sorted(rep['kept']) == [0, 2]
+    # long launches in the dead band (slow pages at the headline size) are searched to the end, as before
+    bufs, rep, t = ring([S, S, S, S, S])
+    assert len(rep['launch_ms']) == 5 and rep['yardstick'] == 'fill'
+    bufs, rep, t = ring([5.1, 5.1, 5.1], fill=1.9)
+    assert rep['yardstick'] == 'not write-bound'

@@ -77,6 +77,7 @@ _SIGNATURES = {
     'tds_stream_create': [_i32, _vp, _i32, ctypes.POINTER(_vp)],
     'tds_stream_destroy': [_i32, _vp],
     'tds_device_cu_count': [_i32, ctypes.POINTER(_i32)],
+    'tds_stream_places': [_vp, _vp, _i32],
     'tds_lanelet_centerline_f64': [_vp, _i32, _vp, _i32, _vp, ctypes.POINTER(_i32)],
     'tds_lanes_create': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, ctypes.POINTER(_vp)],
     'tds_lanes_destroy': [_vp],

@@ -39,13 +39,21 @@ _zero_consts = {}
 
 
 def _zeros_const(shape, device):
-    """a zero tensor that is never written (gradient columns that are identically zero are concatenated from it: one launch, no fill)"""
-    key = (tuple(int(d) for d in shape), str(device))
+    """a zero tensor that is never written (gradient columns that are identically zero are concatenated from it: one launch, no fill).
+    Cached per (shape, device) once it exists on the device for every stream: created outside stream capture only (a captured
+    torch.zeros is a graph node in the graph's private pool, not memory an eager backward may read later) and followed by ONE
+    synchronisation of the creating stream, so that a first use from another stream is ordered behind the fill."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        return torch.zeros(tuple(int(d) for d in shape), dtype=f32, device=dev)
+    key = (tuple(int(d) for d in shape), str(dev))
     z = _zero_consts.get(key)
     if z is None:
         if len(_zero_consts) > 64:
             _zero_consts.clear()
-        z = _zero_consts[key] = torch.zeros(key[0], dtype=f32, device=device)
+        z = _zero_consts[key] = torch.zeros(key[0], dtype=f32, device=dev)
+        if dev.type == 'cuda':
+            torch.cuda.current_stream(dev).synchronize()
     return z
 
 
@@ -53,8 +61,9 @@ class _StateHeadingSC(torch.autograd.Function):
     """[sin psi, cos psi] of a (..., 4) state tensor as ONE autograd node.  The values are torch.sin / torch.cos of the psi column (what the
     reference computes, simulator.py:940); the backward is the chain rule in closed form, d/dpsi = g_sin cos - g_cos sin, written into the psi
     column of a zero state gradient -- three small launches instead of the eight of autograd's select / sin / cos / stack chain, and the
-    consumers of one state (render, collision, off-road) can share the node (Simulator._heading_sc).  Nothing is kept through
-    save_for_backward: the node can be walked again (retain_graph) like plain torch ops."""
+    consumers of one state (render, collision, off-road) can share the node (Simulator._heading_sc).  The output is kept through
+    save_for_backward (autograd holds an OUTPUT without a reference cycle -- a plain attribute on ctx made output -> grad_fn -> ctx -> output,
+    freed only by the cycle collector, which GPU memory pressure does not wake -- and checks its version, so an in-place edit of sc is caught)."""
 
     @staticmethod
     def forward(ctx, state):
@@ -62,12 +71,12 @@ class _StateHeadingSC(torch.autograd.Function):
         sc = torch.empty(state.shape[:-1] + (2,), dtype=state.dtype, device=state.device)
         torch.sin(psi, out=sc[..., 0])
         torch.cos(psi, out=sc[..., 1])
-        ctx.sc = sc
+        ctx.save_for_backward(sc)
         return sc
 
     @staticmethod
     def backward(ctx, g):
-        sc = ctx.sc
+        sc, = ctx.saved_tensors
         gpsi = torch.mul(g[..., 0], sc[..., 1]).addcmul_(g[..., 1], sc[..., 0], value=-1.0)
         z = _zeros_const(gpsi.shape + (2,), gpsi.device)
         return torch.cat([z, gpsi.unsqueeze(-1), z[..., :1]], dim=-1)          # (..., 4): zeros, zeros, d/dpsi, zeros
@@ -549,7 +558,10 @@ def image_pool(device):
 
 def release_image_pool(device=None) -> None:
     """Drop the image pool(s): their cached blocks go back to the driver once the tensors in them are gone."""
-    for idx in list(_image_pools) if device is None else [torch.device(device).index or 0]:
+    def _index(d):
+        d = torch.device(d)
+        return d.index if d.index is not None else torch.cuda.current_device()
+    for idx in list(_image_pools) if device is None else [_index(device)]:
         pool = _image_pools.pop(idx, None)
         del pool                                          # the pool dies here, while its allocator is alive
 
@@ -609,11 +621,57 @@ def owned_image(shape, dtype=torch.float32, device="cuda", dense=False) -> torch
 _reserved_streams = {}       # (device index, CUs per XCD) -> (raster stream, metric stream, handles kept alive)
 
 
+def check_reserved_layout(raster_places, metric_places, per_xcd: int, cus: int):
+    """Is what the two masked streams REALLY run on the layout `overlap_infractions = 'reserved'` relies on?  `*_places`: the distinct
+    XCC_ID << 16 | SE/SH/CU words that tds_stream_places reported for the raster stream and for the metric stream.  Wanted: the metric
+    stream on exactly `per_xcd` CUs of EVERY XCD, the raster stream on all the others, no CU in both, at least 64 CUs in all (a CPX partition
+    of 32 CUs has nothing to give away).  -> (ok, reason).  Pure host logic: tests/test_host_logic.py feeds it good, shifted and small layouts."""
+    raster, metric = set(int(p) for p in raster_places), set(int(p) for p in metric_places)
+    if cus < 64:
+        return False, f'the device reports {cus} CUs: too few to keep {per_xcd} per XCD free of the raster launch'
+    if not raster or not metric:
+        return False, 'a masked stream ran nowhere'
+    if raster & metric:
+        return False, f'{len(raster & metric)} CUs serve both streams: the mask bits do not mean what they mean on an MI355X in SPX mode'
+    xcds = sorted({p >> 16 for p in raster | metric})
+    per = {x: sum(1 for p in metric if p >> 16 == x) for x in xcds}
+    if any(n != per_xcd for n in per.values()):
+        return False, f'the metric stream has {per} CUs per XCD instead of {per_xcd} on each'
+    if len(raster) + len(metric) != cus:
+        return False, f'the two streams cover {len(raster) + len(metric)} of {cus} CUs'
+    return True, 'ok'
+
+
+def stream_places(stream, n: int = 8192):
+    """the distinct places (XCC_ID << 16 | SE/SH/CU) the kernels of a torch stream run on (tds_stream_places; synchronises)"""
+    dev = stream.device
+    out = torch.full((n,), -1, dtype=i32, device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    nat.check(nat.lib().tds_stream_places(ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(out.data_ptr()), n), 'tds_stream_places')
+    stream.synchronize()
+    return sorted(set(out.cpu().tolist()))
+
+
 def reserved_streams(device, per_xcd: int = 4):
     """(raster_stream, metric_stream) of `device`: two torch.cuda.ExternalStream over tds_stream_create -- the first may use every CU but
     `per_xcd` per XCD, the second ONLY those (mask bit i is CU i / 8 of XCD i % 8 on MI355X, tools/cu_mask_probe.hip).  The persistent raster
     launch holds every CU it may use until its last image is out; kept off 32 of the 256 it loses nothing (it is bound by the write stream)
-    and the metric kernels have somewhere to run beside it (Simulator.overlap_infractions = 'reserved').  Created once per device."""
+    and the metric kernels have somewhere to run beside it (Simulator.overlap_infractions = 'reserved').  Created once per device; the
+    layout is VERIFIED on the device when the streams are made (reserved_layout_ok)."""
+    ent = _reserved_entry(device, per_xcd)
+    if ent[0] is None:
+        raise RuntimeError(f"no CU-masked streams on this device: {ent[3][1]}")
+    return ent[0], ent[1]
+
+
+def reserved_layout_ok(device, per_xcd: int = 4):
+    """(ok, reason): can `overlap_infractions = 'reserved'` be used on this device?  The mask layout is an observation of one part in one
+    partition mode; here a probe kernel on each of the two streams reports where it really ran (tds_stream_places) and check_reserved_layout
+    judges it.  Never raises: a device too small for the masks answers (False, why)."""
+    return _reserved_entry(device, per_xcd)[3]
+
+
+def _reserved_entry(device, per_xcd):
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ent = _reserved_streams.get((idx, per_xcd))
@@ -629,15 +687,24 @@ def reserved_streams(device, per_xcd: int = 4):
         for bit in range(cus.value):
             every[bit // 32] |= 1 << (bit % 32)
         rest = [e & ~r for e, r in zip(every, reserved)]
-        handles = []
-        for mask in (rest, reserved):
-            arr = (ctypes.c_uint32 * n_words)(*mask)
-            h = ctypes.c_void_p()
-            nat.check(L.tds_stream_create(idx, ctypes.cast(arr, ctypes.c_void_p), n_words, ctypes.byref(h)), 'tds_stream_create')
-            handles.append(h)
-        ent = _reserved_streams[(idx, per_xcd)] = (torch.cuda.ExternalStream(handles[0].value, device=torch.device('cuda', idx)),
-                                                   torch.cuda.ExternalStream(handles[1].value, device=torch.device('cuda', idx)), handles)
-    return ent[0], ent[1]
+        if cus.value < 64 or not any(rest) or not any(reserved):
+            ent = (None, None, [], (False, f'the device reports {cus.value} CUs: too few to keep {per_xcd} per XCD free of the raster launch'))
+        else:
+            handles = []
+            for mask in (rest, reserved):
+                arr = (ctypes.c_uint32 * n_words)(*mask)
+                h = ctypes.c_void_p()
+                nat.check(L.tds_stream_create(idx, ctypes.cast(arr, ctypes.c_void_p), n_words, ctypes.byref(h)), 'tds_stream_create')
+                handles.append(h)
+            rs = torch.cuda.ExternalStream(handles[0].value, device=torch.device('cuda', idx))
+            ms = torch.cuda.ExternalStream(handles[1].value, device=torch.device('cuda', idx))
+            if torch.cuda.is_current_stream_capturing():
+                verdict = (True, 'not verified: created under stream capture')
+            else:
+                verdict = check_reserved_layout(stream_places(rs), stream_places(ms), per_xcd, cus.value)
+            ent = (rs, ms, handles, verdict)
+        _reserved_streams[(idx, per_xcd)] = ent
+    return ent
 
 
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch

@@ -51,12 +51,22 @@ int create_spread(tds_buffer *b, size_t bytes, int device) {
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = device;
+    // the chunk size and the 2 MiB alignment of the range must be multiples of what the device maps at (2 MiB on MI355X with this driver):
+    // asked once per call, so that another ASIC / driver takes the dense path at once instead of after thousands of failed hipMemCreate
+    size_t gran = 0;
+    hipError_t eg = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (eg != hipSuccess || gran == 0 || CHUNK % gran != 0) {
+        (void)hipGetLastError();
+        tds::set_error("tds_buffer_create: the device maps memory in units of %zu bytes, which do not divide the %zu-byte chunks", gran, CHUNK);
+        return TDS_ELIMIT;
+    }
+    const size_t align = gran > ((size_t)2 << 20) ? gran : ((size_t)2 << 20);
     const size_t n = (bytes + CHUNK - 1) / CHUNK, total = n * CHUNK;
     b->spread = 1;
     b->reserved = total;
     b->bytes = bytes;
     b->device = device;
-    hipError_t e = hipMemAddressReserve(&b->ptr, total, (size_t)2 << 20, nullptr, 0);
+    hipError_t e = hipMemAddressReserve(&b->ptr, total, align, nullptr, 0);
     if (e != hipSuccess) { b->ptr = nullptr; tds::set_error("tds_buffer_create: reserving %zu bytes of address space failed: %s", total, hipGetErrorString(e)); return TDS_EHIP; }
     std::vector<hipMemGenericAllocationHandle_t> spacers;
     spacers.reserve(n);
@@ -138,6 +148,15 @@ TDS_EXPORT int tds_buffer_create(int64_t bytes, int device, int flags, tds_buffe
         }
     } else {
         rc = create_spread(b, (size_t)bytes, device);
+        if (rc == TDS_ELIMIT) {
+            // no usable mapping granularity: one hipMalloc (the placement is then the driver's)
+            *b = tds_buffer();
+            b->bytes = (size_t)bytes;
+            b->device = device;
+            hipError_t e = hipMalloc(&b->ptr, (size_t)bytes);
+            rc = e == hipSuccess ? TDS_OK : (e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP);
+            if (e != hipSuccess) { (void)hipGetLastError(); tds::set_error("tds_buffer_create: hipMalloc of %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e)); }
+        }
     }
     if (rc != TDS_OK) { delete b; return rc; }
     *out = b;
@@ -217,6 +236,23 @@ TDS_EXPORT int tds_stream_create(int device, const uint32_t *cu_mask, int n_word
         TDS_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
     }
     *stream = (void *)s;
+    return TDS_OK;
+}
+
+namespace {
+// every workgroup reports the CU it ran on after keeping it busy for a while (so that the dispatcher has to use them all)
+__global__ void places_kernel(uint32_t *out, int spin) {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);          // HW_ID bits 15:0 (CU_ID 11:8, SH_ID 12, SE_ID 15:13)
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;              // XCC_ID
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) out[blockIdx.x] = (xcc << 16) | ((hw >> 8) & 0xffu);
+}
+}  // namespace
+
+TDS_EXPORT int tds_stream_places(void *stream, uint32_t *places, int n) {
+    TDS_CHECK_ARG(places && n > 0 && n <= (1 << 20), "tds_stream_places: bad arguments");
+    hipLaunchKernelGGL(places_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, places, 200);
+    TDS_LAUNCH_CHECK("places_kernel");
     return TDS_OK;
 }
 

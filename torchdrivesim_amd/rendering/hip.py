@@ -137,7 +137,7 @@ class _DeviceTimer:
 
 
 def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count: int = 2, candidates: int = 4, reps: int = 2, fast: float = 0.98,
-                        spread: float = 1.015, allow_aliasing: bool = False, timer=None, alloc=None):
+                        spread: float = 1.015, allow_aliasing: bool = False, timer=None, alloc=None, short_ms: float = 3.0):
     """`count` DISTINCT caller-owned output buffers for `render(out=buffer)` (e.g. `lambda out: sim.render_egocentric(res=res, out=out)`), each
     checked to be one the write stream of the launch is served at full rate into.
 
@@ -160,7 +160,8 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
     matter there and the first `count` candidates are taken.
     `timer`: an object with first_touch(buf) / launch(buf) / fill(buf) -> ms (tests); `alloc(shape, dtype, device)`: the allocator.
     Returns (buffers, report); report = dict(first_touch_ms, launch_ms, fill_ms (the yardstick), fast=[bool per candidate], kept=[indices],
-    aliased=bool, write_bound=bool)."""
+    aliased=bool, write_bound=bool, yardstick='fill' | 'not applicable' (short launches: none of count + 1 agreeing candidates beats its
+    fill_; the first `count` are kept) | 'not write-bound')."""
     device = torch.device(device)
     alloc = alloc if alloc is not None else _ops.owned_image
     timer = timer if timer is not None else _DeviceTimer(render, device, reps)
@@ -171,7 +172,7 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
         # every candidate is held until the choice is made; building one needs twice its size for a moment (the spacers of csrc/alloc.hip)
         n_max = max(count, min(n_max, int((free - (4 << 30)) // max(nbytes, 1)) - 1))
     cands, first, best, fills = [], [], [], []
-    write_bound = True
+    write_bound, yardstick = True, 'fill'
 
     def is_fast(i):
         return best[i] <= fast * min(fills) and best[i] <= spread * min(best)
@@ -188,8 +189,20 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
             break
         if write_bound and sum(is_fast(i) for i in range(len(cands))) >= count:
             break
+        # The dead band between `fast` x fill_ and 1.5 x fill_: a SHORT write-bound launch (12.9 GB at B = 256: 1.85 ms, its ramp and tail weigh
+        # 5 %) never beats its fill_, whatever the buffer -- but neither does a launch into slow pages at the headline size.  So only for
+        # launches whose fill_ takes less than `short_ms` (3 ms: ramp and tail above the 2 % the yardstick resolves): once count + 1 candidates
+        # have been seen, none passes and all lie within `spread` of the fastest (one placement class), the yardstick says nothing at this
+        # size and probing on would only build more buffers to keep the first ones.
+        if write_bound and min(fills) < short_ms and len(cands) >= count + 1 and not any(b <= fast * min(fills) for b in best) and \
+                max(best) <= spread * min(best):
+            yardstick = 'not applicable'
+            break
     order = sorted(range(len(cands)), key=lambda i: best[i])
     fast_ones = [i for i in order if is_fast(i)] if write_bound else list(range(len(cands)))
+    if yardstick == 'not applicable':
+        fast_ones = []                                      # nothing to choose by: the first `count`, as for a launch that is not write-bound
+        order = list(range(len(cands)))
     aliased = False
     if len(fast_ones) >= count:
         kept = sorted(fast_ones[:count])
@@ -199,7 +212,7 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
         kept = sorted(order[:count])                       # the fast ones and the best of the rest: distinct buffers
     out = [cands[i] for i in kept]
     report = dict(first_touch_ms=first, launch_ms=best, fill_ms=min(fills), fast=[bool(is_fast(i)) for i in range(len(cands))] if write_bound else None,
-                  kept=kept, aliased=aliased, write_bound=write_bound)
+                  kept=kept, aliased=aliased, write_bound=write_bound, yardstick=yardstick if write_bound else 'not write-bound')
     del cands, buf
     if device.type == 'cuda':
         torch.cuda.empty_cache()

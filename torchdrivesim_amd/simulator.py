@@ -562,6 +562,7 @@ class Simulator:
         assert_equal(agent_action.shape[0], self.batch_size)
         assert_equal(agent_action.shape[-2], self.agent_count)
         self.npc_controller.advance_npcs(self)
+        self._sc_cache_grad = None               # the shared [sin, cos] node of the state that is being left: do not pin its graph
         self.kinematic_model.step(agent_action)
         if self.traffic_controls is not None:                       # simulator.py:857-859
             for control in self.traffic_controls.values():
@@ -580,6 +581,7 @@ class Simulator:
         k, full = agent_state.shape[-1], current.shape[-1]
         assert k <= full
         state = agent_state if k == full else torch.cat([agent_state, current[..., (k - full):]], dim=-1)
+        self._sc_cache_grad = None
         self.kinematic_model.set_state(state.where(mask.unsqueeze(-1).expand_as(state), current))
 
     def update_present_mask(self, present_mask: Tensor) -> None:
@@ -625,7 +627,26 @@ class Simulator:
     def raster_stream(self):
         """The stream that is kept off the reserved CUs (overlap_infractions = 'reserved'): a loop that runs under
         `with torch.cuda.stream(sim.raster_stream()):` renders on it without a detour, and its metrics run beside on the reserved CUs."""
-        return _ops.reserved_streams(self.kinematic_model.get_state().device, Simulator._reserved_per_xcd)[0]
+        device = self.kinematic_model.get_state().device
+        if not self._reserved_usable(device):
+            return torch.cuda.current_stream(device)                # (warned once): the loop then simply runs on the caller's stream
+        return _ops.reserved_streams(device, Simulator._reserved_per_xcd)[0]
+
+    _reserved_warned = False
+
+    def _reserved_usable(self, device) -> bool:
+        """overlap_infractions = 'reserved' rests on what the bits of a CU mask stand for, which was OBSERVED on an MI355X in SPX mode
+        (tools/cu_mask_probe.hip).  _ops.reserved_layout_ok launches a probe on both masked streams once per device and checks that the
+        metric stream really runs on `_reserved_per_xcd` CUs of every XCD and the raster stream on all the others; on any other layout, or a
+        device with fewer than 64 CUs (a CPX partition), the mode falls back to overlap_infractions = False with ONE warning -- it neither
+        raises out of render() nor lets the "reserved" stream silently share the raster launch's CUs."""
+        ok, why = _ops.reserved_layout_ok(device, Simulator._reserved_per_xcd) if device.type == 'cuda' else (False, 'not a GPU tensor')
+        if not ok and not Simulator._reserved_warned:
+            Simulator._reserved_warned = True
+            import warnings
+            warnings.warn(f"overlap_infractions='reserved' is not usable on {device} ({why}): the infraction metrics run behind the raster "
+                          f"launch, as with overlap_infractions=False")
+        return ok
 
     def _metric_fn(self, key):
         name = key[0]
@@ -633,12 +654,23 @@ class Simulator:
             return lambda: self._compute_collision(None if key[1] is None else list(key[1]))
         return {'offroad': self._compute_offroad, 'wrong_way': self._compute_wrong_way}[name]
 
-    def _mark_fork(self) -> None:
-        """called by render() right before the raster launch: everything the metrics read has been enqueued by now"""
-        self._fork = None
+    def _mark_fork(self, write_bound: bool = True) -> None:
+        """called by render() right before the raster launch: everything the metrics read has been enqueued by now.
+        `write_bound`: the launch that follows is bound by the HBM write stream (float32 images above 208 x 208: the fused persistent kernel).
+        Only then does 'reserved' pay -- a compute-bound launch (uint8, low resolutions) would give an eighth of its CUs away for nothing, so
+        the mode is skipped for it (the metrics run behind the launch)."""
+        prev, self._fork = self._fork, None
         wanted, self._fork_used = getattr(self, '_fork_used', None) or [], []
         state = self.kinematic_model.get_state()
+        if prev is not None:
+            # a foreseen metric the loop did not ask for again was never joined: its kernels read state / present / [sin, cos] that the
+            # caller's stream is about to overwrite or free.  Join them here -- the launch they ran beside is long over, the wait is free
+            # (and a captured graph has no dangling fork).
+            for _, done in prev[3].values():
+                prev[2].wait_event(done)
         if not self.overlap_infractions or not state.is_cuda or self.npc_count > 0:
+            return
+        if self.overlap_infractions == 'reserved' and (not write_bound or not self._reserved_usable(state.device)):
             return
         self._heading_sc()                                        # the shared [sin, cos] exists before the fork
         srcs = self._fork_sources()
@@ -876,7 +908,8 @@ class Simulator:
                 raise RuntimeError('`out=` needs a batch that is served by one launch')
             out_arg, out = ({} if out is None else dict(out=out)), []
             if not diff:
-                self._mark_fork()
+                r = res if res is not None else getattr(self.renderer, 'res', None)
+                self._mark_fork(write_bound=self.renderer.out_dtype == torch.float32 and (r is None or min(r.height, r.width) > 208))
             # render_egocentric with gradients: the cameras are the exposed agents themselves -- one autograd node takes state and headings and
             # folds the cameras' gradient into the agents' (no slice nodes for camera_xy / camera_sc in the graph)
             ego_n = n_cam if (_ego and diff and ctrl is None and len(scene['maps']) == 1 and n_cam <= state.shape[1]) else 0
@@ -910,7 +943,11 @@ class Simulator:
                     # (A loop that makes that stream its current one -- `with torch.cuda.stream(sim.raster_stream()):` -- saves these two waits.)
                     main = self._fork[2]
                     rs = _ops.reserved_streams(state.device, Simulator._reserved_per_xcd)[0]
-                    rs.wait_event(self._fork[0])
+                    # NOT the fork event: the per-launch inputs (per-camera colour keys, traffic-control keys, waypoint triangles and their
+                    # keys) were built on the caller's stream AFTER it -- the launch waits for an event recorded here, behind all of them
+                    built = torch.cuda.Event()
+                    built.record(main)
+                    rs.wait_event(built)
                     with torch.cuda.stream(rs):
                         img = launch()
                     img.record_stream(main)
