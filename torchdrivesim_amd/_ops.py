@@ -61,9 +61,11 @@ class _StateHeadingSC(torch.autograd.Function):
     """[sin psi, cos psi] of a (..., 4) state tensor as ONE autograd node.  The values are torch.sin / torch.cos of the psi column (what the
     reference computes, simulator.py:940); the backward is the chain rule in closed form, d/dpsi = g_sin cos - g_cos sin, written into the psi
     column of a zero state gradient -- three small launches instead of the eight of autograd's select / sin / cos / stack chain, and the
-    consumers of one state (render, collision, off-road) can share the node (Simulator._heading_sc).  The output is kept through
-    save_for_backward (autograd holds an OUTPUT without a reference cycle -- a plain attribute on ctx made output -> grad_fn -> ctx -> output,
-    freed only by the cycle collector, which GPU memory pressure does not wake -- and checks its version, so an in-place edit of sc is caught)."""
+    consumers of one state (render, collision, off-road) can share the node (Simulator._heading_sc).  The node is shared, so it must be walkable
+    more than once without retain_graph (autograd.grad of the collisions, then of the off-road loss: save_for_backward would free the values after
+    the first walk) -- the values are kept on ctx, as a DETACHED ALIAS of the output: the output itself on ctx made the cycle
+    output -> grad_fn -> ctx -> output, which only the cycle collector frees (GPU memory pressure does not wake it); the alias shares the
+    storage and references nothing.  (An in-place edit of the returned tensor is therefore not caught by autograd's version check.)"""
 
     @staticmethod
     def forward(ctx, state):
@@ -71,12 +73,12 @@ class _StateHeadingSC(torch.autograd.Function):
         sc = torch.empty(state.shape[:-1] + (2,), dtype=state.dtype, device=state.device)
         torch.sin(psi, out=sc[..., 0])
         torch.cos(psi, out=sc[..., 1])
-        ctx.save_for_backward(sc)
+        ctx.sc = sc.detach()
         return sc
 
     @staticmethod
     def backward(ctx, g):
-        sc, = ctx.saved_tensors
+        sc = ctx.sc
         gpsi = torch.mul(g[..., 0], sc[..., 1]).addcmul_(g[..., 1], sc[..., 0], value=-1.0)
         z = _zeros_const(gpsi.shape + (2,), gpsi.device)
         return torch.cat([z, gpsi.unsqueeze(-1), z[..., :1]], dim=-1)          # (..., 4): zeros, zeros, d/dpsi, zeros
