@@ -132,7 +132,8 @@ typedef struct tds_map tds_map_t;
 int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
                    int64_t F, const float *levels, int n_levels, float cell_size, tds_map_t **out);
 int tds_map_destroy(tds_map_t *map);
-/* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, number of nearest-face candidates */
+/* info[0..9] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, number of nearest-face candidates,
+ * entries of the rendering grid (lone faces + pairs, tds_common.h: QuadEntry), pairs of same-key faces that share an edge */
 int tds_map_info(const tds_map_t *map, int64_t *info);
 /* the distinct face keys of the map (HOST array of `cap` entries; *n receives their number, -1 when there are more than 64): with the caller's
  * actor keys they decide which rasteriser serves a launch -- at most 15 keys in all: the bit-plane kernels -- and with it how much scratch

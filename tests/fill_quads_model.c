@@ -219,6 +219,66 @@ static void model_pair(const int32_t *P, const int *b, int a1) {
         }
 }
 
+/* ---- the same pair as the KERNEL organises it (raster.hip, process_batch_bits): two lanes, one per triangle, each with its own set-up.
+ * The lane of T1 is the pair's MASTER: it owns every row strictly inside T1 -- its own two chains plus, where T2 has rows of its own, T2's
+ * chain that is not the shared edge (the "third chain"; the shared edge is one of the master's own two there) -- in up to three parts cut at
+ * the rows of T1's middle vertex and of T2's apex.  A part that starts at such a row starts WITH it: at the row of T1's middle vertex its own
+ * short chain is left out (that row is T1's vertex row, painted by its lane; what remains -- the long chain, i.e. the shared edge, and the
+ * third chain -- is T2's interval there), at the row of T2's apex the third chain is left out (T2's vertex row, painted by its lane).  The lane
+ * of T2 owns the rows of T2 beyond T1's (at most one run, on the side of its apex), as a lone triangle would. */
+static int chain_iv(int xv, int yv, int s, int oL, int oR, int y, int *L, int *R) {
+    const int64_t x = ((int64_t)xv << 16) + (int64_t)(y - yv) * s;
+    *L = (int)((x + oL) >> 16); *R = (int)((x + oR) >> 16);
+    return 1;
+}
+static void model_pair_x(const int32_t *P, const int *b, int a1) {
+    int32_t p1[6] = {P[0], P[1], P[2], P[3], P[4], P[5]}, p2[6];
+    for (int i = 0; i < 3; ++i) { p2[2 * i] = P[2 * b[i]]; p2[2 * i + 1] = P[2 * b[i] + 1]; }
+    tri t1, t2;
+    tri_setup(&t1, p1); tri_setup(&t2, p2);
+    const int s0 = a1 == 0 ? 1 : 0, s1 = a1 == 2 ? 1 : 2;
+    const int ydT = imin(P[2 * s0 + 1], P[2 * s1 + 1]), ydB = imax(P[2 * s0 + 1], P[2 * s1 + 1]);
+    const int ya1 = P[2 * a1 + 1], ya2 = P[7];
+    const int one_side = (ya1 < ydT && ya2 < ydT) || (ya1 > ydB && ya2 > ydB);
+    if (one_side) { ++g_pairs_split; tri_vertex_rows(&t1); tri_vertex_rows(&t2); tri_interior_rows(&t1); tri_interior_rows(&t2); return; }
+    ++g_pairs_merged;
+    /* a pair is set up as a whole: both triangles when the bounding box of the four points meets the image */
+    t1.hit = t2.hit = t1.hit || t2.hit;
+    tri_vertex_rows(&t1); tri_vertex_rows(&t2);
+    if (!t1.hit) return;
+    /* where T2's apex sits among T2's vertices by (row, column): 0 top, 1 middle, 2 bottom (the kernel compares packed vertices) */
+    const int xa2 = P[6];
+    const int apos = (xa2 == t2.xt && ya2 == t2.yt) ? 0 : ((xa2 == t2.xm && ya2 == t2.ym) ? 1 : 2);
+    const int yt = t1.yt, ym = t1.ym, yb = t1.yb, yt2 = t2.yt, ym2 = t2.ym, yb2 = t2.yb;
+    /* master (the lane of T1): every row strictly inside T1 */
+    for (int y = imax(yt + 1, 0); y < yb && y < g_H; ++y) {
+        const int third = yt2 < y && y < yb2 && y != ym2;                       /* T2 has a row of its own here */
+        const int own_short = y != ym, own_long = y != ym || third;             /* T1's middle vertex row: only what stands for T2's interval */
+        int L = 0x7fffffff, R = -0x7fffffff, l, r;
+        if (own_long) { chain_iv(t1.xt, t1.yt, t1.sTB, t1.oL_TB, t1.oR_TB, y, &l, &r); L = imin(L, l); R = imax(R, r); }
+        if (own_short) {
+            if (y < ym) chain_iv(t1.xt, t1.yt, t1.sTM, t1.oL_TM, t1.oR_TM, y, &l, &r);
+            else chain_iv(t1.xm, t1.ym, t1.sMB, t1.oL_MB, t1.oR_MB, y, &l, &r);
+            L = imin(L, l); R = imax(R, r);
+        }
+        if (third) {
+            /* T2's chain that is not the shared edge: below the row of T2's apex the edge apex -> bottom end of the shared edge, above it
+             * top end of the shared edge -> apex; in terms of T2's vertices by row: */
+            const int dn = apos == 0 ? 1 : (apos == 1 ? y > ym2 : 0);
+            if (dn) { if (apos == 0) chain_iv(t2.xt, t2.yt, t2.sTB, t2.oL_TB, t2.oR_TB, y, &l, &r); else chain_iv(t2.xm, t2.ym, t2.sMB, t2.oL_MB, t2.oR_MB, y, &l, &r); }
+            else { if (apos == 2) chain_iv(t2.xt, t2.yt, t2.sTB, t2.oL_TB, t2.oR_TB, y, &l, &r); else chain_iv(t2.xt, t2.yt, t2.sTM, t2.oL_TM, t2.oR_TM, y, &l, &r); }
+            L = imin(L, l); R = imax(R, r);
+        }
+        if (L <= R) paint(y, L, R);
+    }
+    /* the lane of T2: the rows of T2 strictly beyond T1's rows, as a lone triangle paints them */
+    for (int y = imax(yt2 + 1, 0); y < yb2 && y < g_H; ++y) {
+        int L, R;
+        if ((y < yt || y > yb) && tri_row(&t2, y, &L, &R)) paint(y, L, R);
+    }
+}
+static int g_kernel_form = 0;
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint32_t rnd(void) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 16); }
 static int rnd_range(int lo, int hi) { return lo + (int)(rnd() % (uint32_t)(hi - lo + 1)); }
@@ -235,7 +295,7 @@ static void check(const int32_t *P, const int *b, int a1, float *img) {
     for (int i = 0; i < 3; ++i) { p2[2 * i] = P[2 * b[i]]; p2[2 * i + 1] = P[2 * b[i] + 1]; }
     orc_fill_convex_poly(img, W, H, P, 3, one);                        /* the reference: one call per face */
     orc_fill_convex_poly(img, W, H, p2, 3, one);
-    model_pair(P, b, a1);
+    if (g_kernel_form) model_pair_x(P, b, a1); else model_pair(P, b, a1);
     ++g_checked;
     int bad = 0;
     for (int yy = by0; yy <= by1 && !bad; ++yy) for (int xx = bx0; xx <= bx1 && !bad; ++xx) {
@@ -268,6 +328,7 @@ int main(int argc, char **argv) {
     if (argc < 5) { fprintf(stderr, "usage: %s exhaustive RES LO HI [A1 PERM] | random RES COUNT SEED | one RES 8 coords A1 PERM\n", argv[0]); return 2; }
     if (!strncmp(argv[1], "always-", 7)) { g_always_pair = 1; argv[1] += 7; }
     if (!strncmp(argv[1], "noapex-", 7)) { g_skip_apex_row = 1; argv[1] += 7; }
+    if (!strncmp(argv[1], "kernel-", 7)) { g_kernel_form = 1; argv[1] += 7; }       /* the pair as the kernel's two lanes organise it */
     g_W = g_H = atoi(argv[2]);
     float *img = (float *)calloc((size_t)3 * g_W * g_H, sizeof(float));
     g_line_img = (float *)calloc((size_t)3 * g_W * g_H, sizeof(float));

@@ -39,7 +39,12 @@ def main():
     # ablation switches / tuning knobs exist only in the testing build; a plain timing or counter run measures the PRODUCT library
     plain = args.tw == [0] and args.debug == [0] and args.bits_waves == [4] and not args.list_lds and not args.lib and not args.list_waves
     if args.lib:
+        # another build (e.g. an older round's, for a same-box comparison): entry points it does not have yet are simply not bound
         _native.TESTING_LIB_PATH = os.path.abspath(args.lib)
+        probe = ctypes.CDLL(_native.TESTING_LIB_PATH)
+        for table in (_native._SIGNATURES, _native._TESTING_SIGNATURES):
+            for name in [n for n in table if not hasattr(probe, n)]:
+                del table[name]
     L = None
     if not plain:
         L = _native.testing_lib()

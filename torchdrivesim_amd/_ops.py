@@ -364,9 +364,10 @@ class StaticMap:
         return self._face_keys
 
     def info(self):
-        buf = (ctypes.c_int64 * 8)()
+        buf = (ctypes.c_int64 * 10)()
         nat.call('tds_map_info', self.device, self.handle, buf)
-        return dict(V=buf[0], F=buf[1], nx=buf[2], ny=buf[3], entries=buf[4], bytes=buf[5], n_levels=buf[6], near_candidates=buf[7])
+        return dict(V=buf[0], F=buf[1], nx=buf[2], ny=buf[3], entries=buf[4], bytes=buf[5], n_levels=buf[6], near_candidates=buf[7],
+                    render_entries=buf[8], pairs=buf[9])
 
     def rank_of(self, level):
         """1-based painter rank of a rendering level (larger = drawn later = on top)"""

@@ -197,8 +197,63 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
             }
         }
     }
+    // Pairs for the rendering grid (tds::QuadEntry): two faces of the same key that share an edge -- bit-identical end points -- become ONE
+    // entry.  Greedy in face order: a face takes the unpaired partner of lowest index over any of its three edges (meshes of triangulated
+    // quads list the two halves one after the other).  Nothing about the shape is required: the rasteriser decides pair by pair, in pixel space,
+    // whether the rows of the two halves can be painted as one (raster.hip), and draws every triangle with its own vertex order either way.
+    std::vector<int64_t> partner((size_t)F, -1);
+    int64_t n_pairs = 0;
+    if (face_z) {
+        struct EdgeKey { uint32_t a[4]; uint32_t key; bool operator==(const EdgeKey &o) const { return memcmp(this, &o, sizeof(EdgeKey)) == 0; } };
+        struct EdgeHash { size_t operator()(const EdgeKey &k) const { size_t h = 1469598103934665603ull; for (int i = 0; i < 4; ++i) h = (h ^ k.a[i]) * 1099511628211ull; return (h ^ k.key) * 1099511628211ull; } };
+        std::unordered_map<EdgeKey, std::vector<int64_t>, EdgeHash> by_edge;
+        by_edge.reserve((size_t)F * 3);
+        auto vx = [&](int64_t f, int k) { return verts + 2 * faces[3 * f + k]; };
+        auto same = [&](const float *p, const float *q) { return memcmp(p, q, 8) == 0; };
+        auto face_key = [&](int64_t f, uint32_t &key) {
+            for (int l = 0; l < n_levels; ++l) if (levels[l] == face_z[f]) { key = ((uint32_t)(l + 1) << 24) | (face_rgb[f] & 0xFFFFFFu); return true; }
+            return false;
+        };
+        auto usable = [&](int64_t f) {          // finite, three distinct points
+            for (int k = 0; k < 3; ++k) if (!std::isfinite(vx(f, k)[0]) || !std::isfinite(vx(f, k)[1])) return false;
+            return !same(vx(f, 0), vx(f, 1)) && !same(vx(f, 1), vx(f, 2)) && !same(vx(f, 0), vx(f, 2));
+        };
+        auto edge_key = [&](int64_t f, int l, uint32_t key) {
+            const float *p = vx(f, l), *q = vx(f, (l + 1) % 3);
+            if (p[0] > q[0] || (p[0] == q[0] && p[1] > q[1])) std::swap(p, q);
+            EdgeKey ek;
+            memcpy(&ek.a[0], p, 8); memcpy(&ek.a[2], q, 8);
+            ek.key = key;
+            return ek;
+        };
+        for (int64_t f = 0; f < F; ++f) {
+            uint32_t key;
+            if (!face_key(f, key) || !usable(f)) continue;
+            for (int l = 0; l < 3; ++l) by_edge[edge_key(f, l, key)].push_back(f);
+        }
+        for (int64_t f = 0; f < F; ++f) {
+            uint32_t key;
+            if (partner[(size_t)f] >= 0 || !face_key(f, key) || !usable(f)) continue;
+            int64_t best = -1;
+            for (int l = 0; l < 3; ++l) {
+                const float *apex = vx(f, (l + 2) % 3);
+                for (int64_t g : by_edge[edge_key(f, l, key)]) {
+                    if (g == f || partner[(size_t)g] >= 0 || (best >= 0 && g >= best)) continue;
+                    // g's third vertex must be a fourth point
+                    int shared = 0, other = -1;
+                    for (int k = 0; k < 3; ++k) {
+                        if (same(vx(g, k), vx(f, l)) || same(vx(g, k), vx(f, (l + 1) % 3))) ++shared; else other = k;
+                    }
+                    if (shared == 2 && other >= 0 && !same(vx(g, other), apex)) best = g;
+                }
+            }
+            if (best >= 0) { partner[(size_t)f] = best; partner[(size_t)best] = f; ++n_pairs; }
+        }
+    }
     std::vector<int32_t> cell_start;
     std::vector<GridEntry> entries;
+    std::vector<int32_t> qcell_start;
+    std::vector<tds::QuadEntry> qentries;
     int nx = 0, ny = 0;
     float ox = minx, oy = miny, inv = 1.0f / cell;
     for (int attempt = 0; attempt < 24 && any; ++attempt) {
@@ -266,6 +321,61 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         break;
     }
     if (!any) { nx = ny = 0; cell_start.assign(1, 0); entries.clear(); }
+    // ---- the rendering grid with paired faces: the same cells, one entry per lone face or pair and cell of ITS bounding box
+    if (face_z && any && nx > 0) {
+        auto rank_of = [&](int64_t f) { for (int l = 0; l < n_levels; ++l) if (levels[l] == face_z[f]) return l + 1; return -1; };
+        auto build = [&](int64_t f, tds::QuadEntry &q, float &bx0, float &by0, float &bx1, float &by1) {
+            const float *p[3] = {verts + 2 * faces[3 * f], verts + 2 * faces[3 * f + 1], verts + 2 * faces[3 * f + 2]};
+            for (int k = 0; k < 3; ++k) if (!std::isfinite(p[k][0]) || !std::isfinite(p[k][1])) return false;
+            q.x0 = p[0][0]; q.y0 = p[0][1]; q.x1 = p[1][0]; q.y1 = p[1][1]; q.x2 = p[2][0]; q.y2 = p[2][1];
+            q.x3 = q.x2; q.y3 = q.y2;
+            q.key = ((uint32_t)rank_of(f) << 24) | (face_rgb[f] & 0xFFFFFFu);
+            q.flags = (uint32_t)dup[(size_t)f] << 9;
+            q.pad = 0;
+            bx0 = std::min(q.x0, std::min(q.x1, q.x2)); bx1 = std::max(q.x0, std::max(q.x1, q.x2));
+            by0 = std::min(q.y0, std::min(q.y1, q.y2)); by1 = std::max(q.y0, std::max(q.y1, q.y2));
+            const int64_t g = partner[(size_t)f];
+            if (g >= 0) {
+                uint32_t b = 0, in_t2 = 0;
+                for (int k = 0; k < 3; ++k) {
+                    const float *v = verts + 2 * faces[3 * g + k];
+                    int slot = 3;
+                    for (int j = 0; j < 3; ++j) if (memcmp(v, p[j], 8) == 0) slot = j;
+                    if (slot == 3) { q.x3 = v[0]; q.y3 = v[1]; } else in_t2 |= 1u << slot;
+                    b |= (uint32_t)slot << (2 * k);
+                }
+                const uint32_t a1 = !(in_t2 & 1u) ? 0u : (!(in_t2 & 2u) ? 1u : 2u);
+                q.flags |= b | (a1 << 6) | (1u << 8) | ((uint32_t)dup[(size_t)g] << 12);
+                bx0 = std::min(bx0, q.x3); bx1 = std::max(bx1, q.x3); by0 = std::min(by0, q.y3); by1 = std::max(by1, q.y3);
+            }
+            return true;
+        };
+        qcell_start.assign((size_t)nx * ny + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<int32_t> cursor;
+            if (pass == 1) {
+                for (size_t i = 1; i < qcell_start.size(); ++i) qcell_start[i] += qcell_start[i - 1];
+                qentries.resize((size_t)qcell_start.back());
+                cursor.assign(qcell_start.begin(), qcell_start.end() - 1);
+            }
+            for (int64_t f = 0; f < F; ++f) {
+                if (partner[(size_t)f] >= 0 && partner[(size_t)f] < f) continue;       // the second half of a pair: in its partner's entry
+                if (rank_of(f) < 0) continue;
+                tds::QuadEntry q;
+                float bx0, by0, bx1, by1;
+                if (!build(f, q, bx0, by0, bx1, by1)) continue;
+                const int cx0 = tds::cell_coord(bx0, ox, inv), cx1 = tds::cell_coord(bx1, ox, inv);
+                const int cy0 = tds::cell_coord(by0, oy, inv), cy1 = tds::cell_coord(by1, oy, inv);
+                for (int cy = cy0; cy <= cy1; ++cy)
+                    for (int cx = cx0; cx <= cx1; ++cx) {
+                        if (pass == 0) { qcell_start[(size_t)cy * nx + cx + 1]++; continue; }
+                        q.own = (uint32_t)cx0 | ((uint32_t)cx1 << 13) | (cx > cx0 ? (1u << 26) : 0u) | (cy > cy0 ? (1u << 27) : 0u);
+                        qentries[(size_t)cursor[(size_t)cy * nx + cx]++] = q;
+                    }
+            }
+        }
+    }
+    if (qcell_start.empty()) qcell_start.assign((size_t)std::max(nx, 0) * std::max(ny, 0) + 1, 0);
 
     tds_map *m = new (std::nothrow) tds_map();
     if (!m) { tds::set_error("tds_map_create: out of host memory"); return TDS_ENOMEM; }
@@ -294,6 +404,17 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
     if (e == hipSuccess) e = hipMalloc(&m->d_cell_start, bc);
     if (e == hipSuccess && !entries.empty()) e = hipMemcpy(m->d_entries, entries.data(), entries.size() * sizeof(GridEntry), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_cell_start, cell_start.data(), bc, hipMemcpyHostToDevice);
+    m->d_qentries = nullptr; m->d_qcell_start = nullptr;
+    m->n_qentries = (int64_t)qentries.size(); m->n_pairs = n_pairs;
+    size_t bq = 0;
+    if (face_z) {
+        const size_t bqe = std::max<size_t>(qentries.size(), 1) * sizeof(tds::QuadEntry), bqc = qcell_start.size() * sizeof(int32_t);
+        if (e == hipSuccess) e = hipMalloc(&m->d_qentries, bqe);
+        if (e == hipSuccess) e = hipMalloc(&m->d_qcell_start, bqc);
+        if (e == hipSuccess && !qentries.empty()) e = hipMemcpy(m->d_qentries, qentries.data(), qentries.size() * sizeof(tds::QuadEntry), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(m->d_qcell_start, qcell_start.data(), bqc, hipMemcpyHostToDevice);
+        bq = bqe + bqc;
+    }
     size_t bn = 0;
     if (e == hipSuccess && !cand.empty()) {
         void *dc = nullptr, *ds = nullptr, *df = nullptr;
@@ -312,6 +433,8 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         tds::set_error("tds_map_create: %s", hipGetErrorString(e));
         if (m->d_entries) (void)hipFree(m->d_entries);
         if (m->d_cell_start) (void)hipFree(m->d_cell_start);
+        if (m->d_qentries) (void)hipFree(m->d_qentries);
+        if (m->d_qcell_start) (void)hipFree(m->d_qcell_start);
         if (m->near.cand) (void)hipFree((void *)m->near.cand);
         if (m->near.cand_start) (void)hipFree((void *)m->near.cand_start);
         if (m->near.faces) (void)hipFree((void *)m->near.faces);
@@ -326,9 +449,11 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         if (m->n_uniq == 64) { m->n_uniq = -1; break; }
         m->uniq_keys[m->n_uniq++] = ge.key;
     }
-    m->bytes = (int64_t)(be + bc + bn);
+    m->bytes = (int64_t)(be + bc + bn + bq);
     m->view.entries = (const GridEntry *)m->d_entries;
     m->view.cell_start = (const int32_t *)m->d_cell_start;
+    m->view.qentries = (const tds::QuadEntry *)m->d_qentries;
+    m->view.qcell_start = (const int32_t *)m->d_qcell_start;
     m->view.ox = ox; m->view.oy = oy; m->view.inv_cell = inv; m->view.cell = cell;
     m->view.nx = nx; m->view.ny = ny; m->view.n_faces = F;
     *out = m;
@@ -341,6 +466,8 @@ TDS_EXPORT int tds_map_destroy(tds_map_t *map) {
     (void)hipGetDevice(&cur);
     if (cur != map->device) (void)hipSetDevice(map->device);
     hipError_t e1 = hipFree(map->d_entries), e2 = hipFree(map->d_cell_start);
+    if (map->d_qentries) (void)hipFree(map->d_qentries);
+    if (map->d_qcell_start) (void)hipFree(map->d_qcell_start);
     if (map->near.cand) (void)hipFree((void *)map->near.cand);
     if (map->near.cand_start) (void)hipFree((void *)map->near.cand_start);
     if (map->near.faces) (void)hipFree((void *)map->near.faces);
@@ -361,6 +488,7 @@ TDS_EXPORT int tds_map_info(const tds_map_t *map, int64_t *info) {
     TDS_CHECK_ARG(map && info, "tds_map_info: null pointer");
     info[0] = map->V; info[1] = map->F; info[2] = map->view.nx; info[3] = map->view.ny;
     info[4] = map->n_entries; info[5] = map->bytes; info[6] = map->n_levels; info[7] = map->n_cand;
+    info[8] = map->n_qentries; info[9] = map->n_pairs;
     return TDS_OK;
 }
 

@@ -697,7 +697,7 @@ struct ScanState {
     // the chunk of entries in flight (scan_fetch): this lane's entry index | its grid row within the block << 25 (-1: none) and data
     bool have;
     int cur_i;
-    uint4 pu0, pu1;
+    uint4 pu0, pu1, pu2;                                 // (pu2: the third 16 bytes of a QuadEntry, bit-plane kernels)
     MapView map;                                         // the map of this camera's scene (wave-uniform)
     uint32_t *dyn;                                       // LDS counter that deals the chunks to the waves as they ask (nullptr: round-robin)
     int done;                                            // chunks of the blocks of grid rows already left behind (the counter numbers them all)
@@ -758,20 +758,29 @@ __device__ __forceinline__ void scan_load_rows(ScanState &st, const MapView &m, 
 }
 
 // window = pixel columns [X0, X0 + TWw) of the image (the whole image when binning)
-template <typename SA>
+// POLY: the walk is over the rendering grid with paired faces (MapView::qentries / qcell_start: the bit-plane kernels); the cells are the same
+template <typename SA, bool POLY = false>
 __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane, int wave, int X0,
                                           int TWw) {   // wave = index among the cooperating waves
     st.map = a.map;
     if (a.views != nullptr) st.map = a.views[a.scene_map[img / a.Nc]];
+    if constexpr (POLY) st.map.cell_start = st.map.qcell_start;
     const MapView &m = st.map;
     const int res = c.res;
     st.phase = (a.N > 0 && !(TDS_DBG(c.debug) & 2)) ? 0 : 2;      // 0 actors, 1 masked-agent dot, 3 per-camera triangles, 2 static map
+    if constexpr (POLY) {
+        // The scan kernel of the split form reads the first phase through the launch's (always zero, in the product) debug word: a phase the
+        // compiler knows at compile time makes it restructure the phases so that scan_faces_kernel needs 368 instead of 112 bytes of scratch per
+        // lane and takes 0.98 instead of 0.72 ms at B = 1024 x 64.  (Found because the testing build was the faster one; an opaque register
+        // in place of the kernel argument does not have the effect.)
+        st.phase = (a.N > 0 && !(c.debug & 2)) ? 0 : 2;
+    }
     if constexpr (has_extras<SA>::value) { if (st.phase == 2 && a.K > 0) st.phase = 3; }
     st.a0 = 0; st.masked_seen = false;
     st.cx0 = 0; st.cx1 = -1; st.cy0 = 0; st.nrows = 0; st.row = 0; st.chunk = __builtin_amdgcn_readfirstlane(wave); st.prev_rw = SCAN_EMPTY_ROW;
     st.rw = SCAN_EMPTY_ROW; st.rex = st.rbase = st.rfe = 0; st.rtotal = 0;
     st.have = false; st.cur_i = -1; st.dyn = nullptr; st.done = 0;
-    st.pu0 = st.pu1 = make_uint4(0, 0, 0, 0);
+    st.pu0 = st.pu1 = st.pu2 = make_uint4(0, 0, 0, 0);
     if (m.nx > 0 && !(TDS_DBG(c.debug) & 1)) {
         // world-space bounding box of the window (2 px margin: int truncation moves a vertex by < 1 px) -> grid cell rectangle
         float wx0 = 3.0e38f, wx1 = -3.0e38f, wy0 = 3.0e38f, wy1 = -3.0e38f;
@@ -800,7 +809,7 @@ __device__ __forceinline__ void scan_init(ScanState &st, const SA &a, const Comm
 // the current block form ONE list -- lane r holds row r's range, a wave prefix sum numbers the entries -- which is cut into chunks of 64
 // dealt round-robin to the cooperating waves: every chunk but the last of a block is full whatever the rows hold (with a chunk per row
 // range the tails of 6 - 9 short ranges per view idled a third of the lanes).  A lane finds the row of its entry by bisection.
-template <int NW>
+template <int NW, bool POLY = false>
 __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, const CommonArgs &c, const Camera &cam, int lane, int X0, int TWw) {
     while (st.row < st.nrows) {
         const int nblk = min(64, st.nrows - st.row);
@@ -819,8 +828,13 @@ __device__ __forceinline__ bool scan_fetch(ScanState &st, const MapView &m, cons
             const int i = __shfl(st.rbase, r) + v;
             st.cur_i = v < total ? (i | (r << 25)) : -1;
             if (v < total) {
-                const uint4 *ep = (const uint4 *)(m.entries + i);
-                st.pu0 = ep[0]; st.pu1 = ep[1];
+                if constexpr (POLY) {
+                    const uint4 *ep = (const uint4 *)(m.qentries + i);
+                    st.pu0 = ep[0]; st.pu1 = ep[1]; st.pu2 = ep[2];
+                } else {
+                    const uint4 *ep = (const uint4 *)(m.entries + i);
+                    st.pu0 = ep[0]; st.pu1 = ep[1];
+                }
             }
             if (st.dyn != nullptr) {
                 // the next chunk goes to whichever wave asks first: the waves of a camera finish together (they meet at a barrier before the
@@ -980,6 +994,191 @@ __device__ __forceinline__ bool scan_step(ScanState &st, const SA &a, const Comm
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The producer of the bit-plane kernels: faces come as POLYS -- one triangle, or two triangles of the same key that share an edge
+// (tds_common.h: QuadEntry; the actors' body is such a pair too) -- fetched, projected and trimmed once.  A poly RECORD is what the
+// queues and the lists of the split form hold: a flags word and four packed pixel vertices,
+//   T1 = (P0, P1, P2), T2 = (P[b0], P[b1], P[b2]) -- each triangle in its own vertex order (cv::fillConvexPoly draws Line(v2,v0),
+//   Line(v0,v1), Line(v1,v2) and cv::clipLine depends on the direction) --
+//   flags: bits 0..3 plane index (set when the record is queued), 4..6 / 7..9 outline edges of T1 / T2 that have to be drawn (edge_mask),
+//          10..15 b0, b1, b2, 16..17 a1 = the vertex of T1 that T2 does not have, bit 18: there is a T2.
+// The reference trims face by face (cv2.py:32-41: a face is kept iff one of ITS vertices is in view): a pair of which only one triangle
+// survives becomes a lone triangle (T2 re-slotted as T1).
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t PF_HAS2 = 1u << 18;
+__device__ __forceinline__ uint32_t sel4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t i) {
+    return i == 0u ? v0 : (i == 1u ? v1 : (i == 2u ? v2 : v3));
+}
+
+// qf: QuadEntry::flags (b0..b2, a1, bit 8 has T2, dup bits of T1 at 9, of T2 at 12).  -> accepted; P = packed record vertices, pf = record
+// flags (without the plane index), big = a coordinate outside the packed range (the record cannot hold the poly: exact sequential path)
+__device__ inline bool trim_project_poly(const Camera &cam, float scale, int res, int X0, int TW, const float *sx, const float *sy, uint32_t qf,
+                                         uint32_t (&P)[4], uint32_t &pf, bool &big, int (&px)[4], int (&py)[4], int no_trim) {
+    const bool has2 = (qf & 256u) != 0u;
+    float fx[4], fy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) project(cam, scale, res, sx[k], sy[k], px[k], py[k], fx[k], fy[k]);
+    if (!has2) { px[3] = px[2]; py[3] = py[2]; fx[3] = fx[2]; fy[3] = fy[2]; }
+    // one bounding-box reject for the whole entry (a triangle that misses the window paints nothing there either way)
+    const int xmin = min(min(px[0], px[1]), min(px[2], px[3])), xmax = max(max(px[0], px[1]), max(px[2], px[3]));
+    const int ymin = min(min(py[0], py[1]), min(py[2], py[3])), ymax = max(max(py[0], py[1]), max(py[2], py[3]));
+    pf = 0u; big = false;
+    if (xmax < X0 || xmin >= X0 + TW || ymax < 0 || ymin >= res) return false;
+    unsigned ins = 15u;
+    if (!no_trim) {
+        // as trim_project: pixel-space test away from the border of the 1.05 x view, the reference's own half-plane test near it
+        const float lo = -0.025f * (float)res, hi = 1.025f * (float)res, band = 0.0625f * fmaxf(1.0f, (float)res * (1.0f / 256.0f));
+        unsigned amb = 0;
+        ins = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float mn = fminf(fx[k], fy[k]), mx = fmaxf(fx[k], fy[k]), sum = fx[k] + fy[k];
+            const bool fin = sum == sum;
+            const bool in = fin && mn > lo + band && mx < hi - band;
+            const bool out = fin && (mn < lo - band || mx > hi + band);
+            ins |= in ? (1u << k) : 0u;
+            amb |= (!in && !out) ? (1u << k) : 0u;
+        }
+        if (__builtin_expect(__ballot(amb != 0) != 0, 0)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((amb >> k) & 1u) ins |= inside_polygon(cam, sx[k], sy[k]) ? (1u << k) : 0u;
+        }
+    }
+    const uint32_t b0 = qf & 3u, b1 = (qf >> 2) & 3u, b2 = (qf >> 4) & 3u, a1 = (qf >> 6) & 3u;
+    const bool acc1 = (ins & 7u) != 0u, acc2 = has2 && (ins & (15u & ~(1u << a1))) != 0u;
+    if (!acc1 && !acc2) return false;
+    big = max(max(max(abs(px[0]), abs(px[1])), max(abs(px[2]), abs(px[3]))), max(max(abs(py[0]), abs(py[1])), max(abs(py[2]), abs(py[3])))) >= COORD_LIMIT;
+    const unsigned ins2 = ((ins >> b0) & 1u) | (((ins >> b1) & 1u) << 1) | (((ins >> b2) & 1u) << 2);
+    const uint32_t e1 = edge_mask((qf >> 9) & 7u, ins & 7u), e2 = edge_mask((qf >> 12) & 7u, ins2);
+    if (acc1) {
+        pf = (e1 << 4) | (acc2 ? ((e2 << 7) | ((qf & 63u) << 10) | (a1 << 16) | PF_HAS2) : 0u);
+    } else {
+        // only T2 is kept: it becomes the record's T1, in its own vertex order
+        const int qx[3] = {(int)sel4(px[0], px[1], px[2], px[3], b0), (int)sel4(px[0], px[1], px[2], px[3], b1), (int)sel4(px[0], px[1], px[2], px[3], b2)};
+        const int qy[3] = {(int)sel4(py[0], py[1], py[2], py[3], b0), (int)sel4(py[0], py[1], py[2], py[3], b1), (int)sel4(py[0], py[1], py[2], py[3], b2)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { px[k] = qx[k]; py[k] = qy[k]; }
+        pf = e2 << 4;
+    }
+    if (!(pf & PF_HAS2)) { px[3] = px[2]; py[3] = py[2]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P[k] = pack_xy(px[k], py[k]);
+    return true;
+}
+
+// one entry of the rendering grid with paired faces (see scan_candidate): the owner rule, then projection and trim of the poly
+__device__ __forceinline__ void scan_candidate_poly(const ScanState &st, const CommonArgs &c, const Camera &cam, int X0, int TWw, int ci, const uint4 &u0,
+                                                    const uint4 &u1, const uint4 &u2, bool &acc, uint32_t &key, uint32_t (&P)[4], uint32_t &pf, bool &big,
+                                                    int (&px)[4], int (&py)[4]) {
+    const int i = ci & 0x1ffffff, r = ci >= 0 ? ci >> 25 : 0;
+    const int first_end = __shfl(st.rfe, r);
+    const int above = __shfl(st.rw, (r + 63) & 63);
+    const int pw = r > 0 ? above : st.prev_rw;
+    const int plo = pw & 0xffff, phi = pw >> 16;
+    const bool top = st.row + r == 0;
+    if (ci >= 0) {
+        const unsigned own = u2.y;
+        const int bx0 = (int)(own & 0x1fffu), bx1 = (int)((own >> 13) & 0x1fffu);
+        const bool first_in_row = !(own & (1u << 26)) || (i < first_end);
+        const bool none_above = !(own & (1u << 27)) || top || bx1 < plo || bx0 > phi;
+        if (first_in_row && none_above && !(TDS_DBG(c.debug) & 1024)) {
+            const float sxv[4] = {__uint_as_float(u0.x) + (-cam.cx), __uint_as_float(u0.z) + (-cam.cx), __uint_as_float(u1.x) + (-cam.cx), __uint_as_float(u1.z) + (-cam.cx)};
+            const float syv[4] = {__uint_as_float(u0.y) + (-cam.cy), __uint_as_float(u0.w) + (-cam.cy), __uint_as_float(u1.y) + (-cam.cy), __uint_as_float(u1.w) + (-cam.cy)};
+            key = u2.x;
+            acc = trim_project_poly(cam, c.scale, c.res, X0, TWw, sxv, syv, u2.z, P, pf, big, px, py, c.no_trim);
+        }
+    }
+}
+
+// one producer step of the bit-plane kernels: at most one poly per lane; returns false when the producer is exhausted
+template <int NW = RWAVES, typename SA = SceneArgsEx>
+__device__ __forceinline__ bool scan_step_poly(ScanState &st, const SA &a, const CommonArgs &c, const Camera &cam, int64_t img, int lane, int wave, int X0,
+                                               int TWw, bool &acc, uint32_t &key, uint32_t (&P)[4], uint32_t &pf, bool &big, int (&px)[4], int (&py)[4]) {
+    const MapView &m = st.map;
+    const int res = c.res;
+    const int64_t b = img / a.Nc;
+    acc = false; key = 0; pf = 0; big = false;
+    if (st.phase == 0) {
+        // actors (mesh.py:1071-1103): 7 template vertices per agent, faces [0,1,3], [1,3,2] (the body: ONE poly, the two faces share the edge
+        // 1-3) and [4,5,6] (direction).  One lane per (agent, poly): 32 agents per wave and step, dealt round-robin to the cooperating waves;
+        // agents are culled by distance before anything else is loaded.
+        const int slot = lane >> 1, f = lane & 1;
+        const int ag = st.a0 + slot * NW + wave;
+        if (ag < a.N) {
+            const int64_t ia = b * a.N + ag;
+            const bool on = a.mask[img * a.N + ag] != 0;
+            st.masked_seen = st.masked_seen || !on;
+            if (on) {
+                const float view_r = 1.05f * 1.41421356f / c.scale;
+                const float4 s = a.state[ia];
+                const float2 t0 = a.tmpl[ia * 7];
+                float reach = view_r + sqrtf(t0.x * t0.x + t0.y * t0.y);
+                reach = reach * 1.01f + 0.01f;
+                const float ddx = s.x - cam.cx, ddy = s.y - cam.cy;
+                if (!(ddx * ddx + ddy * ddy > reach * reach)) {
+                    const int64_t ik = a.key_per_cam ? img * a.N + ag : ia;
+                    key = a.actor_key[2 * ik + f];
+                    if (key != 0u) {
+                        const float2 sc = a.agent_sc[ia];
+                        // body: T1 = [0,1,3] in slots 0..2, vertex 2 in slot 3, T2 = [1,3,2] = slots (1,2,3); direction: [4,5,6]
+                        const float2 ta = a.tmpl[ia * 7 + (f ? 4 : 0)], tb = a.tmpl[ia * 7 + (f ? 5 : 1)], tc = a.tmpl[ia * 7 + (f ? 6 : 3)], td = a.tmpl[ia * 7 + (f ? 6 : 2)];
+                        // utils.transform :82-96, then mesh.translate(-cameras.xy) cv2.py:29-31
+                        const float fx[4] = {((sc.y * ta.x + (-sc.x) * ta.y) + s.x) + (-cam.cx), ((sc.y * tb.x + (-sc.x) * tb.y) + s.x) + (-cam.cx),
+                                             ((sc.y * tc.x + (-sc.x) * tc.y) + s.x) + (-cam.cx), ((sc.y * td.x + (-sc.x) * td.y) + s.x) + (-cam.cx)};
+                        const float fy[4] = {((sc.x * ta.x + sc.y * ta.y) + s.y) + (-cam.cy), ((sc.x * tb.x + sc.y * tb.y) + s.y) + (-cam.cy),
+                                             ((sc.x * tc.x + sc.y * tc.y) + s.y) + (-cam.cy), ((sc.x * td.x + sc.y * td.y) + s.y) + (-cam.cy)};
+                        // T2's edge 1 (its v0 - v1 = template vertices 1 - 3) repeats T1's
+                        const uint32_t qf = f ? 0u : (1u | (2u << 2) | (3u << 4) | (0u << 6) | 256u | (2u << 12));
+                        acc = trim_project_poly(cam, c.scale, res, X0, TWw, fx, fy, qf, P, pf, big, px, py, c.no_trim);
+                    }
+                }
+            }
+        }
+        st.a0 += 32 * NW;
+        if (st.a0 >= a.N) st.phase = 1;
+        return true;
+    }
+    if (st.phase == 1) {
+        // every face of a masked agent collapses onto vertex 0 of agent 0 (mesh.py:1083-1089): a one-pixel dot, see scan_step
+        if (__ballot(st.masked_seen) != 0) {
+            float4 s0 = a.state[b * a.N];
+            float2 sc0 = a.agent_sc[b * a.N];
+            float2 t0 = a.tmpl[b * a.N * 7];
+            float wx = (sc0.y * t0.x + (-sc0.x) * t0.y) + s0.x, wy = (sc0.x * t0.x + sc0.y * t0.y) + s0.y;
+            const float fx[4] = {wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx), wx + (-cam.cx)}, fy[4] = {wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy), wy + (-cam.cy)};
+            const bool ok = trim_project_poly(cam, c.scale, res, X0, TWw, fx, fy, 0u, P, pf, big, px, py, c.no_trim);
+            acc = (lane == 0) && ok;
+            key = a.actor_key[2 * (a.key_per_cam ? img * a.N : b * a.N)];
+        }
+        st.phase = 2;
+        if constexpr (has_extras<SA>::value) { st.a0 = 0; if (a.K > 0) st.phase = 3; }
+        return true;
+    }
+    if constexpr (has_extras<SA>::value) if (st.phase == 3) {
+        // per-camera triangles, already in world coordinates: one lane each, lone triangles
+        const int t = st.a0 + wave * 64 + lane;
+        if (t < a.K) {
+            key = a.extra_key[img * a.K + t];
+            if (key != 0u) {
+                const float2 *v = (const float2 *)a.extra_tri + (img * a.K + t) * 3;
+                const float2 va = v[0], vb = v[1], vc = v[2];
+                const float fx[4] = {va.x + (-cam.cx), vb.x + (-cam.cx), vc.x + (-cam.cx), vc.x + (-cam.cx)}, fy[4] = {va.y + (-cam.cy), vb.y + (-cam.cy), vc.y + (-cam.cy), vc.y + (-cam.cy)};
+                acc = trim_project_poly(cam, c.scale, res, X0, TWw, fx, fy, 0u, P, pf, big, px, py, c.no_trim);
+            }
+        }
+        st.a0 += 64 * NW;
+        if (st.a0 >= a.K) st.phase = 2;
+        return true;
+    }
+    // static map: as scan_step, over the rendering grid with paired faces
+    if (!st.have) st.have = scan_fetch<NW, true>(st, m, c, cam, lane, X0, TWw);
+    if (!st.have) return false;
+    scan_candidate_poly(st, c, cam, X0, TWw, st.cur_i, st.pu0, st.pu1, st.pu2, acc, key, P, pf, big, px, py);
+    st.have = scan_fetch<NW, true>(st, m, c, cam, lane, X0, TWw);
+    return true;
+}
+
 // Fused single-pass kernel: one workgroup per (camera, strip); every strip scans the grid itself.  Used when the caller
 // gives no workspace; also the semantics reference for the binned kernel below.
 template <int TW, typename OutT>
@@ -1100,7 +1299,7 @@ struct KeyTable { uint32_t key[16]; int n; };      // ascending = painter order 
 
 struct BitCtx {
     uint32_t *planes;   // [K][wpr][H]: plane, word column, row (see paint_span_bits)
-    uint32_t *q;        // [4][QCAP]: plane index, then the three packed vertices
+    uint32_t *q;        // [4][QCAP]: plane index | outline edges to draw << 4, then the three packed vertices of a triangle
     uint32_t *slots;    // [64] owner markers of wave_owner()
     uint32_t *eq;       // [2][EQCAP] ring of outline edges waiting to be drawn: end points + plane index (pack_xyk)
     int qlen, lane, H, W, X0, TWp, wpr, debug, gen, eq_head, eq_count;
@@ -1701,17 +1900,17 @@ __device__ __forceinline__ int slope_one_row(int xs, int xe) { const int d = xe 
 // taller variant costs every chunk of faces about twice the instructions and pays where faces of three and four rows are many (128 x 128: 38 %
 // of the faces on top of the 32 % of one and two rows; 64 x 64: 8 % on top of 66 %).
 template <bool TALL>
-__device__ __forceinline__ void process_small_bits(BitCtx &w, bool valid, const uint4 &e) {
+__device__ __forceinline__ void process_small_bits(BitCtx &w, bool valid, uint32_t plane, uint32_t v0, uint32_t v1, uint32_t v2) {
     const int H = w.H, X0 = w.X0, wpr = w.wpr;
     const int Xhi = min(w.W, X0 + w.TWp) - 1;
     if (!valid) return;
-    const int i0 = (int)e.y, i1 = (int)e.z, i2 = (int)e.w;
+    const int i0 = (int)v0, i1 = (int)v1, i2 = (int)v2;
     const int pT = min(i0, min(i1, i2)), pB = max(i0, max(i1, i2)), pM = max(min(i0, i1), min(max(i0, i1), i2));
     const int xt = unpack_x((uint32_t)pT), yt = unpack_y((uint32_t)pT), xm = unpack_x((uint32_t)pM), ym = unpack_y((uint32_t)pM);
     const int xb = unpack_x((uint32_t)pB), yb = unpack_y((uint32_t)pB);
     const int xmin = min(xt, min(xm, xb)), xmax = max(xt, max(xm, xb));
     if (xmax < X0 || xmin > Xhi) return;
-    uint32_t *pl = w.planes + (size_t)__umul24(__umul24(e.x & 15u, (unsigned)H), (unsigned)wpr);
+    uint32_t *pl = w.planes + (size_t)__umul24(__umul24(plane & 15u, (unsigned)H), (unsigned)wpr);
     auto paint_row = [&](int y, int L, int R) {
         const int s0 = max(L, X0), s1 = min(R, Xhi);
         if (s0 <= s1) paint_span_bits(pl + y, H, s0 - X0, s1 - X0);
@@ -1811,6 +2010,63 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, int k, bool acc, unsigned 
             w.qlen = 0;
         }
         if (pending == 0) break;
+    }
+}
+
+// Queue the triangles of the polys of a producer step (at most one poly per lane: one or two triangles, each in its own vertex order) and
+// rasterise the queue whenever it is full.  `flags`: the poly record's (plane index included).  The rasteriser works triangle by triangle:
+// painting the rows of a pair as one was built and measured in round 5 (tests/fill_quads_model.c is the exact rule) and lost -- the third
+// chain and the extra cut rows cost the row items more than the halved row count gives back.
+// BIG: polys outside the packed coordinate range may come along (px, py: their unpacked vertices): they take the exact sequential path,
+// triangle by triangle, on the spot; the list kernel never sees one.
+template <bool BIG = true>
+__device__ __forceinline__ void drain_poly(BitCtx &w, bool acc, uint32_t flags, const uint32_t (&P)[4], bool big, const int (&px)[4], const int (&py)[4], bool more) {
+    const uint32_t b0 = (flags >> 10) & 3u, b1 = (flags >> 12) & 3u, b2 = (flags >> 14) & 3u;
+    if constexpr (BIG) {
+        big = big && acc;
+        if (__builtin_expect(__ballot(big) != 0, 0)) {
+            if (big) {
+                uint32_t *pl = w.planes + (size_t)(flags & 15u) * w.H * w.wpr;
+                fill_generic_bits(pl, w.H, w.W, w.X0, w.TWp, w.wpr, px[0], py[0], px[1], py[1], px[2], py[2]);
+                if (flags & PF_HAS2)
+                    fill_generic_bits(pl, w.H, w.W, w.X0, w.TWp, w.wpr, (int)sel4(px[0], px[1], px[2], px[3], b0), (int)sel4(py[0], py[1], py[2], py[3], b0),
+                                      (int)sel4(px[0], px[1], px[2], px[3], b1), (int)sel4(py[0], py[1], py[2], py[3], b1),
+                                      (int)sel4(px[0], px[1], px[2], px[3], b2), (int)sel4(py[0], py[1], py[2], py[3], b2));
+            }
+            acc = acc && !big;
+        }
+    }
+    // two rounds: the first triangles of all polys, then the second ones (a triangle of the queue is plane | outline edges << 4 + three vertices)
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const bool mine = acc && (h == 0 || (flags & PF_HAS2));
+        const bool last = more ? false : (h == 1);
+        if (h == 1 && __ballot(mine) == 0) { if (!more) { process_batch_bits(w, w.qlen, true); w.qlen = 0; } break; }
+        const uint32_t q0 = (flags & 15u) | (((flags >> (h ? 7 : 4)) & 7u) << 4);
+        const uint32_t v0 = h ? sel4(P[0], P[1], P[2], P[3], b0) : P[0], v1 = h ? sel4(P[0], P[1], P[2], P[3], b1) : P[1], v2 = h ? sel4(P[0], P[1], P[2], P[3], b2) : P[2];
+        unsigned long long pending = __ballot(mine);
+        for (;;) {
+            if (pending != 0) {
+                const int room = QCAP - w.qlen;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pending >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pending, 0));
+                const bool take = mine && ((pending >> w.lane) & 1) && rank < room;
+                if (take) {
+                    const int slot = w.qlen + rank;
+                    w.q[slot] = q0;
+                    w.q[1 * QCAP + slot] = v0;
+                    w.q[2 * QCAP + slot] = v1;
+                    w.q[3 * QCAP + slot] = v2;
+                }
+                const unsigned long long taken = __ballot(take);
+                w.qlen += __popcll(taken);
+                pending &= ~taken;
+            }
+            if (w.qlen == QCAP || (last && pending == 0)) {          // the last call also empties the edge queue
+                process_batch_bits(w, w.qlen, last && pending == 0);
+                w.qlen = 0;
+            }
+            if (pending == 0) break;
+        }
     }
 }
 
@@ -2159,6 +2415,9 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
             make_polygon(cam, ci.scale, ci.res);
         }
         __syncthreads();
+        // (the fused kernel walks the grid of single triangles: the 48-byte entries of the grid with paired faces cost it four more registers
+        // for the chunk in flight, and it has none to spare -- measured on one box, uint8 256 x 256: 5.09 ms with triangles, 5.53 with pairs;
+        // the split form, whose scan kernel holds nothing else, takes the pairs: scan_faces_kernel)
         ScanState st;
         scan_init(st, a, ci, cam, img, lane, wave, X0, TWp);
         st.dyn = lkeys + 15;
@@ -2201,18 +2460,20 @@ constexpr int SCAN_WAVES = 4;                 // cameras per workgroup of K3s
 #endif
 constexpr int SMALL_TALL_RES = TDS_SMALL_TALL_RES;      // from this resolution on K3r's short path takes faces of up to four rows (below: two)
 #ifndef TDS_SCAN_DEPTH
-#define TDS_SCAN_DEPTH 2
+#define TDS_SCAN_DEPTH 1
 #endif
 #ifndef TDS_SCAN_OCC
-#define TDS_SCAN_OCC 6
+#define TDS_SCAN_OCC 5
 #endif
 constexpr int SCAN_DEPTH = TDS_SCAN_DEPTH;    // chunks of 64 grid entries whose loads K3s keeps in flight
 constexpr uint32_t LIST_POISON = 0xffffffffu;
 
-// (chunks in flight x waves per SIMD the registers are cut for, ms at B = 1024 x 64: 4 x 3 1.18, 4 x 4 0.98, 3 x 5 0.87, 2 x 6 0.85, 2 x 8 1.00)
+// (chunks in flight x waves per SIMD the registers are cut for, ms at B = 1024 x 64, round 3, 32-byte triangle entries: 4 x 3 1.18, 4 x 4 0.98,
+// 3 x 5 0.87, 2 x 6 0.85, 2 x 8 1.00; round 5, 48-byte entries of the rendering grid with paired faces -- half as many, 12 registers each --:
+// 2 x 6 1.35 (468 bytes of scratch per lane), 1 x 8 0.97, 1 x 6 0.85, 2 x 4 0.78, 1 x 5 0.72)
 template <typename SA>
 __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kernel(SA a, CommonArgs c, KeyTable kt, uint32_t *__restrict__ counts, uint4 *__restrict__ lists,
-                                                                     int caps, uint32_t *__restrict__ poisoned) {
+                                                                     uint32_t *__restrict__ lists3, int caps, uint32_t *__restrict__ poisoned) {
     __shared__ uint32_t lkeys[16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x < 16) {
@@ -2231,58 +2492,57 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
         cam.cx = xy.x; cam.cy = xy.y; cam.s = sc.x; cam.c = sc.y;
         make_polygon(cam, c.scale, res);
     }
+    // the list of this camera: poly records (scan_step_poly) -- flags | plane index, P0, P1, P2 in `lists`, P3 in `lists3`
     uint4 *mine = lists + (size_t)img * caps;
+    uint32_t *mine3 = lists3 + (size_t)img * caps;
     ScanState st;
-    scan_init(st, a, c, cam, img, lane, 0, 0, res);
+    scan_init<SA, true>(st, a, c, cam, img, lane, 0, 0, res);
     int count = 0;
     bool poison = false;
-    auto emit = [&](bool acc, uint32_t key, const int (&px)[3], const int (&py)[3], unsigned edges) {
-        const bool big = acc && (max(max(abs(px[0]), abs(px[1])), max(max(abs(px[2]), abs(py[0])), max(abs(py[1]), abs(py[2])))) >= COORD_LIMIT);
-        poison = poison || (__ballot(big) != 0);
+    auto emit = [&](bool acc, uint32_t key, uint32_t pf, const uint32_t (&P)[4], bool big) {
+        poison = poison || (__ballot(acc && big) != 0);
         const unsigned long long bm = __ballot(acc);
         if (bm != 0) {
             const int k = key_plane(lkeys, K, key);
             const int slot = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-            if (acc && slot < caps) mine[slot] = make_uint4((uint32_t)k | (edges << 4), pack_xy(px[0], py[0]), pack_xy(px[1], py[1]), pack_xy(px[2], py[2]));
+            if (acc && slot < caps) { mine[slot] = make_uint4((uint32_t)k | pf, P[0], P[1], P[2]); mine3[slot] = P[3]; }
             count += __popcll(bm);
         }
     };
     // actors, the masked-agent dot, per-camera triangles: the producer steps of the fused kernel, up to the static map
     while (st.phase != 2) {
-        bool acc;
-        uint32_t key;
-        int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-        unsigned edges;
-        (void)scan_step<1, SA>(st, a, c, cam, img, lane, 0, 0, res, acc, key, px, py, edges);
-        emit(acc, key, px, py, edges);
+        bool acc, big;
+        uint32_t key, pf, P[4] = {0, 0, 0, 0};
+        int px[4], py[4];
+        (void)scan_step_poly<1, SA>(st, a, c, cam, img, lane, 0, 0, res, acc, key, P, pf, big, px, py);
+        emit(acc, key, pf, P, big);
     }
-    // The static map.  With nothing to rasterise between two chunks of entries the walk would wait for every load (1.2 us each, 28 chunks
-    // per camera): the entries are taken SCAN_DEPTH chunks at a time, all their loads in flight together.
+    // The static map.  With nothing to rasterise between two chunks of entries the walk would wait for every load (1.2 us each):
+    // the entries are taken SCAN_DEPTH chunks at a time, all their loads in flight together.
     if (!(TDS_DBG(c.debug) & 1)) {
         const MapView &m = st.map;
         while (st.row < st.nrows) {
             const int nblk = min(64, st.nrows - st.row);
             for (int base = 0; base < st.rtotal; base += 64 * SCAN_DEPTH) {
                 int ci[SCAN_DEPTH];
-                uint4 u0[SCAN_DEPTH], u1[SCAN_DEPTH];
+                uint4 u0[SCAN_DEPTH], u1[SCAN_DEPTH], u2[SCAN_DEPTH];
 #pragma unroll
                 for (int u = 0; u < SCAN_DEPTH; ++u) {
                     ci[u] = (base + 64 * u < st.rtotal) ? scan_locate(st, nblk, base + 64 * u + lane) : -1;
-                    u0[u] = u1[u] = make_uint4(0, 0, 0, 0);
+                    u0[u] = u1[u] = u2[u] = make_uint4(0, 0, 0, 0);
                     if (ci[u] >= 0) {
-                        const uint4 *ep = (const uint4 *)(m.entries + (ci[u] & 0x1ffffff));
-                        u0[u] = ep[0]; u1[u] = ep[1];
+                        const uint4 *ep = (const uint4 *)(m.qentries + (ci[u] & 0x1ffffff));
+                        u0[u] = ep[0]; u1[u] = ep[1]; u2[u] = ep[2];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < SCAN_DEPTH; ++u) {
                     if (base + 64 * u >= st.rtotal) break;                   // wave-uniform
-                    bool acc = false;
-                    uint32_t key = 0;
-                    int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-                    unsigned edges = 7u;
-                    scan_candidate(st, c, cam, 0, res, ci[u], u0[u], u1[u], acc, key, px, py, edges);
-                    emit(acc, key, px, py, edges);
+                    bool acc = false, big = false;
+                    uint32_t key = 0, pf = 0, P[4] = {0, 0, 0, 0};
+                    int px[4], py[4];
+                    scan_candidate_poly(st, c, cam, 0, res, ci[u], u0[u], u1[u], u2[u], acc, key, P, pf, big, px, py);
+                    emit(acc, key, pf, P, big);
                 }
             }
             st.row += 64;
@@ -2305,7 +2565,7 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
 // between the barriers of a workgroup (SQ_WAIT_ANY 40 % of the wave cycles) -- small images get fewer waves per workgroup and more workgroups.
 template <int NB, typename OutT, int BWAVES>
 __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
-                                                                      const uint4 *__restrict__ lists, int caps) {
+                                                                      const uint4 *__restrict__ lists, const uint32_t *__restrict__ lists3, int caps) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -2347,6 +2607,7 @@ __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArg
     w.qlen = 0; w.lane = lane; w.H = H; w.W = W; w.X0 = X0; w.TWp = TWp; w.wpr = wpr; w.debug = c.debug; w.gen = 0;
     __syncthreads();
     const uint4 *lst = lists + (size_t)img * caps;
+    const uint32_t *lst3 = lists3 + (size_t)img * caps;
     const int Xhi = min(W, X0 + TWp) - 1;
     int chunk = __builtin_amdgcn_readfirstlane(wave);                  // chunks of 64 faces, dealt to the waves as they ask
     for (;;) {
@@ -2354,27 +2615,39 @@ __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArg
         const bool more = i0 < n;
         bool acc = more && (i0 + (uint32_t)lane < n);
         uint4 e = make_uint4(0, 0, 0, 0);
-        if (acc) e = lst[i0 + lane];
+        uint32_t e3 = 0;
+        if (acc) { e = lst[i0 + lane]; e3 = lst3[i0 + lane]; }
         if (more) {
             unsigned nxt = 0;
             if (lane == 0) nxt = atomicAdd(lkeys + 15, 1u);
             chunk = __builtin_amdgcn_readfirstlane((int)nxt);
         }
-        const int px[3] = {unpack_x(e.y), unpack_x(e.z), unpack_x(e.w)}, py[3] = {unpack_y(e.y), unpack_y(e.z), unpack_y(e.w)};
-        const int xmin = min(px[0], min(px[1], px[2])), xmax = max(px[0], max(px[1], px[2]));
-        if (c.strips > 1) acc = acc && !(xmax < X0 || xmin > Xhi);      // faces that miss this strip are not queued
-        // SMALL faces -- the three vertices inside the image, in one row or in two adjacent rows: two thirds of the faces of a 64 x 64 view, a
-        // third at 128 x 128 -- are painted on the spot by their lane (process_small_bits: nothing to scan-convert, no edge to clip or walk);
-        // only the others go through the queue and the full set-up of process_batch_bits
+        const uint32_t P[4] = {e.y, e.z, e.w, e3};
+        const int px[4] = {unpack_x(e.y), unpack_x(e.z), unpack_x(e.w), unpack_x(e3)}, py[4] = {unpack_y(e.y), unpack_y(e.z), unpack_y(e.w), unpack_y(e3)};
+        const int xmin = min(min(px[0], px[1]), min(px[2], px[3])), xmax = max(max(px[0], px[1]), max(px[2], px[3]));
+        if (c.strips > 1) acc = acc && !(xmax < X0 || xmin > Xhi);      // polys that miss this strip are not queued
+        // SMALL polys -- every vertex inside the image, in one row or in two adjacent rows (up to four from SMALL_TALL_RES on): two thirds of
+        // the faces of a 64 x 64 view, a third at 128 x 128 -- are painted on the spot by their lane, triangle by triangle
+        // (process_small_bits: nothing to scan-convert, no edge to clip or walk); only the others go through the queue and the full set-up
         if (!(TDS_DBG(c.debug) & 32768)) {
-            const int ymin = min(py[0], min(py[1], py[2])), ymax = max(py[0], max(py[1], py[2]));
+            const int ymin = min(min(py[0], py[1]), min(py[2], py[3])), ymax = max(max(py[0], py[1]), max(py[2], py[3]));
             const bool inside = acc && xmin >= 0 && xmax < W && ymin >= 0 && ymax < H;
+            const bool has2 = (e.x & PF_HAS2) != 0u;
+            const uint32_t b0 = (e.x >> 10) & 3u, b1 = (e.x >> 12) & 3u, b2 = (e.x >> 14) & 3u;
+            const uint32_t t0 = sel4(P[0], P[1], P[2], P[3], b0), t1 = sel4(P[0], P[1], P[2], P[3], b1), t2 = sel4(P[0], P[1], P[2], P[3], b2);
             bool small;
-            if (res >= SMALL_TALL_RES) { small = inside && ymax - ymin <= 3; process_small_bits<true>(w, small, e); }      // wave-uniform choice
-            else { small = inside && ymax - ymin <= 1; process_small_bits<false>(w, small, e); }
+            if (res >= SMALL_TALL_RES) {                                  // wave-uniform choice
+                small = inside && ymax - ymin <= 3;
+                process_small_bits<true>(w, small, e.x, P[0], P[1], P[2]);
+                process_small_bits<true>(w, small && has2, e.x, t0, t1, t2);
+            } else {
+                small = inside && ymax - ymin <= 1;
+                process_small_bits<false>(w, small, e.x, P[0], P[1], P[2]);
+                process_small_bits<false>(w, small && has2, e.x, t0, t1, t2);
+            }
             acc = acc && !small;
         }
-        drain_bits<false>(w, (int)(e.x & 15u), acc, (e.x >> 4) & 7u, px, py, more);
+        drain_poly<false>(w, acc, e.x, P, false, px, py, more);
         if (!more) break;
     }
     __syncthreads();
@@ -2742,11 +3015,13 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                     if (TDS_DBG(g_debug) & 16384) split = !want_slices && nwv == 4 && workspace != nullptr;      // testing: the split form everywhere
                     const size_t off_counts = (((size_t)n_img + 1) * 4 + 255) & ~(size_t)255;
                     const size_t off_lists = (off_counts + (size_t)n_img * 4 + 255) & ~(size_t)255;
-                    int64_t caps = split && (size_t)workspace_bytes > off_lists ? ((int64_t)workspace_bytes - (int64_t)off_lists) / (n_img * 16) : 0;
+                    // a poly record is 20 bytes: 16 in `lists` (flags, P0, P1, P2), 4 in `lists3` (P3)
+                    int64_t caps = split && (size_t)workspace_bytes > off_lists ? (((int64_t)workspace_bytes - (int64_t)off_lists) / (n_img * 20)) & ~(int64_t)3 : 0;
                     if (caps > 8192) caps = 8192;
-                    if (split && caps >= 256) {
+                    if (split && caps >= 128) {
                         uint32_t *poisoned = (uint32_t *)workspace, *counts = (uint32_t *)((char *)workspace + off_counts);
                         uint4 *lists = (uint4 *)((char *)workspace + off_lists);
+                        uint32_t *lists3 = (uint32_t *)(lists + (size_t)n_img * (size_t)caps);
                         // strip width of K3r: the widest multiple of 32 columns whose workgroup stays within the LDS budget (four workgroups per CU)
                         // waves per workgroup of K3r: by the pixels of a strip (testing hook: g_list_waves)
                         int lw = g_list_waves;
@@ -2762,7 +3037,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                             cs.strips = 1; cs.slices = nullptr;
                             const dim3 sgrid((unsigned)((n_img + SCAN_WAVES - 1) / SCAN_WAVES));
                             const SceneArgs sbase = a;
-                            auto launch_s = [&](auto kern, const auto &args) { hipLaunchKernelGGL(kern, sgrid, dim3(SCAN_WAVES * 64), 0, (hipStream_t)stream, args, cs, kt, counts, lists, (int)caps, poisoned); };
+                            auto launch_s = [&](auto kern, const auto &args) { hipLaunchKernelGGL(kern, sgrid, dim3(SCAN_WAVES * 64), 0, (hipStream_t)stream, args, cs, kt, counts, lists, lists3, (int)caps, poisoned); };
                             if (a.K != 0) launch_s(scan_faces_kernel<SceneArgsEx>, a);
                             else launch_s(scan_faces_kernel<SceneArgs>, sbase);
                             TDS_LAUNCH_CHECK("scan_faces_kernel");
@@ -2771,7 +3046,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                             const dim3 rgrid((unsigned)(n_img * cr.strips));
                             auto launch_r = [&](auto kern) {
                                 if (lds_s > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-                                hipLaunchKernelGGL(kern, rgrid, dim3(lw * 64), lds_s, (hipStream_t)stream, cr, kt, tws, (const uint32_t *)counts, (const uint4 *)lists, (int)caps);
+                                hipLaunchKernelGGL(kern, rgrid, dim3(lw * 64), lds_s, (hipStream_t)stream, cr, kt, tws, (const uint32_t *)counts, (const uint4 *)lists, (const uint32_t *)lists3, (int)caps);
                             };
 #define TDS_LIST_DISPATCH_W(T, W) do { if (nb == 2) launch_r(raster_list_bits_kernel<2, T, W>); else if (nb == 3) launch_r(raster_list_bits_kernel<3, T, W>); else launch_r(raster_list_bits_kernel<4, T, W>); } while (0)
 #define TDS_LIST_DISPATCH(T) do { if (lw == 2) TDS_LIST_DISPATCH_W(T, 2); else TDS_LIST_DISPATCH_W(T, 4); } while (0)

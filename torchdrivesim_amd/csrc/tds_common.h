@@ -67,12 +67,30 @@ struct GridEntry {          // 32 bytes, one per (cell, face whose bounding box 
                                     //   face with the same key (identical end points)
 };
 
+// A face of the RENDERING grid (maps with rendering data; raster.hip, bit-plane kernels): one triangle, or TWO triangles of the same key that
+// share an edge -- road and lane-marking meshes are triangulated quads (Town01: 95 - 100 % of the faces of a view come in such pairs).  The
+// pair is fetched, projected and trimmed once (four vertices instead of six) and the rows between its vertex rows are painted once
+// (raster.hip: process_batch_bits; tests/fill_quads_model.c proves the row rule).  Every triangle is still drawn with the reference's
+// per-face semantics (rendering/cv2.py:44-59: one cv2.fillConvexPoly per face): the vertex ORDER of both triangles is kept.
+struct QuadEntry {          // 48 bytes, one per (cell, face or pair whose bounding box touches the cell)
+    float x0, y0, x1, y1, x2, y2;   // T1 = (v0, v1, v2), world coordinates, in the face's own vertex order
+    float x3, y3;                   // the vertex of T2 that T1 does not have (unused for a lone triangle)
+    uint32_t key;                   // rank << 24 | 0x00RRGGBB
+    uint32_t own;                   // as GridEntry::own, bits 0..27, for the bounding box of the whole entry
+    uint32_t flags;                 // bits 0..5: T2 = (v[b0], v[b1], v[b2]), two bits each, in T2's own vertex order; bits 6..7: the vertex of T1
+                                    // that T2 does not have; bit 8: there is a T2; bits 9..11 / 12..14: outline edge l of T1 / T2 repeats an edge
+                                    // of an earlier face of the same key (GridEntry::own bits 29..31)
+    uint32_t pad;
+};
+
 struct MapView {
     const GridEntry *entries;
     const int32_t *cell_start;      // nx*ny + 1
     float ox, oy, inv_cell, cell;
     int nx, ny;
     int64_t n_faces;
+    const QuadEntry *qentries;      // the rendering grid with paired faces (null without rendering data): same cells, its own ranges
+    const int32_t *qcell_start;     // nx*ny + 1
 };
 
 // Nearest-face candidate lists of K2b (maps created without rendering data): for every grid cell the faces that can be the nearest one
@@ -111,6 +129,9 @@ struct tds_map {
     tds::MapView view;
     void *d_entries;
     void *d_cell_start;
+    void *d_qentries;           // the rendering grid with paired faces (QuadEntry), null without rendering data
+    void *d_qcell_start;
+    int64_t n_qentries, n_pairs;
     tds::NearView near;         // K2b candidate lists (device pointers; all null when absent)
     int64_t n_cand;
     int device;
