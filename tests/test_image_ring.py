@@ -74,8 +74,8 @@ def test_an_in_between_buffer_that_passes_the_fill_yardstick_loses_to_a_faster_o
 def test_short_launches_stop_after_one_more_candidate_and_say_that_the_yardstick_does_not_apply():
     """B = 256: a 12.9 GB launch (1.85 ms) never beats its fill_ (1.84 ms), whatever the buffer (all four candidates were built
     to then keep the first two).  Three agreeing candidates end the search; the report says why.  At the headline size the same ratios keep searching."""
-    bufs, rep, t = ring([1.85, 1.86, 1.85, 1.85, 1.85], fill=1.84)
-    assert rep['launch_ms'] == [1.85, 1.86, 1.85] and rep['kept'] == [0, 1] and rep['yardstick'] == 'not applicable' and rep['write_bound']
+    bufs, rep, t = ring([1.93, 1.89, 1.91, 1.92, 1.85], fill=1.868)                 # (the figures of a round-5 bench run)
+    assert rep['launch_ms'] == [1.93, 1.89, 1.91] and rep['kept'] == [0, 1] and rep['yardstick'] == 'not applicable' and rep['write_bound']
     assert rep['fast'] == [False, False, False] and not rep['aliased']
     # candidates that do NOT agree (a slower placement class among them) are searched on
     bufs, rep, t = ring([1.85, 1.99, 1.85, 1.85, 1.85], fill=1.84)

@@ -2848,7 +2848,7 @@ namespace {
 constexpr int DEFAULT_CAPS = 512;         // faces per strip list that the recommended workspace provides
 constexpr int LIST_CAPS = 2048;           // faces per camera list of the split bit-plane path that the recommended workspace provides
 // the split form (K3s + K3r) serves resolutions up to these; above, the fused launch hides the scan behind its write stream or its row loops
-constexpr int SPLIT_MAX_RES_F32 = 136, SPLIT_MAX_RES_U8 = 208;      // (round 5 sweep, fused / split ms: float32 128 4.02 / 3.16, 144 4.19 / 4.39, 160 4.31 / 4.22, 176 4.60 / 4.97; uint8 192 4.37 / 4.16, 208 4.77 / 4.81, 224 4.94 / 7.4)
+constexpr int SPLIT_MAX_RES_F32 = 144, SPLIT_MAX_RES_U8 = 208;      // (round 5 sweep, fused / split ms: float32 128 4.02 / 3.16, 144 4.19 / 4.39, 160 4.31 / 4.22, 176 4.60 / 4.97; uint8 192 4.37 / 4.16, 208 4.77 / 4.81, 224 4.94 / 7.4)
 inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
     return n_img * strips * ((int64_t)caps * (int64_t)sizeof(uint4) + (int64_t)sizeof(uint32_t));
 }
@@ -3011,6 +3011,10 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                     // measured at B = 1024 x 64 (fused / split, ms): float32 96 x 96 3.89 / 3.17, 128 3.95 / 3.60, 160 4.33 / 4.79; uint8 128 4.03 / 3.04,
                     // 192 4.53 / 4.34, 256 5.3 / 5.9 -- from there on the fused launch hides the scan behind its write stream or its row loops
                     bool split = !want_slices && nwv == 4 && workspace != nullptr && res <= (f32 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8);
+                    // float32 above 128: only where a column of the output (res x 4 bytes) is a whole number of 64-byte sectors -- K3r is bound by
+                    // its write stream there and pays for columns that straddle sectors (136: 4.47 ms against the fused kernel's 4.19; 144: 3.89
+                    // against 4.21; 120, still below the fused kernel: 3.71 against 128's 3.16)
+                    if (f32 && res > 128 && (res & 15) != 0) split = false;
                     if (TDS_DBG(g_debug) & 8192) split = false;                              // testing: the fused kernel everywhere
                     if (TDS_DBG(g_debug) & 16384) split = !want_slices && nwv == 4 && workspace != nullptr;      // testing: the split form everywhere
                     const size_t off_counts = (((size_t)n_img + 1) * 4 + 255) & ~(size_t)255;
