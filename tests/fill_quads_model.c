@@ -1,18 +1,25 @@
-/* Test infrastructure: a sequential C model of how the K3 bit-plane kernel (torchdrivesim_amd/csrc/raster.hip, process_batch_bits) paints a
- * PAIR of same-key triangles that share an edge (a triangulated quad of the road or lane-marking mesh), checked here against the oracle's
- * restatement of cv::fillConvexPoly (oracle/tds_oracle.c) called once per triangle, as the reference does (rendering/cv2.py:44-59: one
- * cv2.fillConvexPoly per face; equal keys, so the union does not depend on the order).
+/* Test infrastructure: the exact ROW RULE for painting a PAIR of same-key triangles that share an edge (a triangulated quad of the road or
+ * lane-marking mesh) as one, checked against the oracle's restatement of cv::fillConvexPoly (oracle/tds_oracle.c) called once per triangle,
+ * as the reference does (rendering/cv2.py:44-59: one cv2.fillConvexPoly per face; equal keys, so the union does not depend on the order).
+ *
+ * Status (round 5).  The rendering grid pairs such faces (torchdrivesim_amd/csrc/map.hip, tds_common.h: QuadEntry) and the scan kernel of
+ * the split form fetches, projects and trims a pair once.  The RASTERISER still paints triangle by triangle: this rule was built into
+ * process_batch_bits in two organisations ("hull of both triangles' intervals" and the leaner "master + third chain" of model_pair_x
+ * below), was bit-exact against the oracle on every GPU parity test, and LOST on the clock -- the row items of a pair need twice the
+ * cross-lane traffic and the cut rows, which costs more than the halved number of rows gives back (uint8 256 x 256, one box: 5.09 ms
+ * triangle by triangle, 5.75 paired).  The model stays as the proof of the rule for whoever takes it up again.
  *
  * What is being proved.  tests/fill_rows_model.c proves the per-triangle row rule: in every row the painted pixels of a triangle are ONE
- * interval, the hull of the row ends of its active 16.16 edge chains (outline edges inside the image merged into the rows).  The kernel
- * paints the INTERIOR rows of a pair -- the rows strictly between two consecutive vertex rows of the four points -- once, as the hull of
+ * interval, the hull of the row ends of its active 16.16 edge chains (outline edges inside the image merged into the rows).  For a pair,
+ * the INTERIOR rows -- the rows strictly between two consecutive vertex rows of the four points -- can be painted once, as the hull of
  * both triangles' intervals (one ds_or per row instead of two, one work item instead of two).  That is the union of the two fills iff the
  * two intervals overlap or touch in every such row.  They do whenever both triangles contain the row's pixels of the shared edge
  * ("diagonal") d: its chain has the same end points, hence the same slope, class and offsets, in both triangles.  Both triangles are
  * active in an interior row outside d's rows only if both apexes lie strictly above d's top row or both strictly below its bottom row:
- * such a pair ("apexes on one side") is painted triangle by triangle, as before.  What stays per triangle: the exact walk of the edges that
- * are not merged, the vertex rows, and -- new -- a triangle's own interval in the row of the OTHER triangle's apex when that row is interior
- * to it (it is no vertex row of its own, and the pair's items skip all four vertex rows).
+ * such a pair ("apexes on one side") has to be painted triangle by triangle.  What stays per triangle: the exact walk of the edges that
+ * are not merged, the vertex rows, and a triangle's own interval in the row of the OTHER triangle's apex when that row is interior
+ * to it (it is no vertex row of its own, and the pair's items skip all four vertex rows).  "kernel-" modes: the same pixels organised as
+ * two lanes would compute them (model_pair_x).
  *
  * Build + run: see tests/test_fill_quads_model.py.  Exit status 0 = no differing pixel. */
 #include <stdint.h>
@@ -219,7 +226,7 @@ static void model_pair(const int32_t *P, const int *b, int a1) {
         }
 }
 
-/* ---- the same pair as the KERNEL organises it (raster.hip, process_batch_bits): two lanes, one per triangle, each with its own set-up.
+/* ---- the same pair as a KERNEL would organise it (round 5 built it into raster.hip's process_batch_bits): two lanes, one per triangle, each with its own set-up.
  * The lane of T1 is the pair's MASTER: it owns every row strictly inside T1 -- its own two chains plus, where T2 has rows of its own, T2's
  * chain that is not the shared edge (the "third chain"; the shared edge is one of the master's own two there) -- in up to three parts cut at
  * the rows of T1's middle vertex and of T2's apex.  A part that starts at such a row starts WITH it: at the row of T1's middle vertex its own

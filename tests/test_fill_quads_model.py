@@ -1,9 +1,10 @@
 """
-The PAIR rule of the K3 bit-plane kernel -- two same-key triangles that share an edge (a triangulated quad of the road / lane-marking
-mesh) have their interior rows painted once, as the hull of the two triangles' row intervals (raster.hip: process_batch_bits, quad items) --
-as sequential C (tests/fill_quads_model.c), checked pair by pair against the oracle's cv::fillConvexPoly restatement called once per
-triangle (rendering/cv2.py:44-59 of the reference: one cv2.fillConvexPoly per face).  CPU only; the kernel itself is compared with the
-oracle under -m gpu.
+The PAIR rule -- two same-key triangles that share an edge (a triangulated quad of the road / lane-marking mesh) can have their interior rows
+painted once, as the hull of the two triangles' row intervals -- as sequential C (tests/fill_quads_model.c), checked pair by pair against the
+oracle's cv::fillConvexPoly restatement called once per triangle (rendering/cv2.py:44-59 of the reference: one cv2.fillConvexPoly per face).
+Round 5 built the rule into the bit-plane kernel (bit-exact) and took it out again: slower than triangle by triangle.
+The rendering grid still PAIRS the faces (map.hip) and the scan kernel handles a pair at once; the model documents what a paired
+rasteriser has to do.  CPU only.
 """
 import os
 import subprocess
@@ -35,13 +36,16 @@ def test_every_pair_of_a_small_grid(model):
     # apexes on one side of the shared edge), pairs that leave the image
     out = run(model, 'exhaustive', 3, -1, 3)
     assert '7031250 pairs, 0 differ' in out
+    assert '7031250 pairs, 0 differ' in run(model, 'kernel-exhaustive', 3, -1, 3)
 
 
 @pytest.mark.parametrize('res,count,seed', [(64, 200000, 21), (256, 200000, 22), (512, 80000, 23)])
 def test_random_pairs(model, res, count, seed):
+    # (also in the two-lane organisation, 'kernel-' modes)
     # lane-marking slivers and road quads at every rotation, with jitter; across the image border; small quads; degenerate ones; edges beyond the
     # merge limits (walked exactly)
     assert f'{count} pairs, 0 differ' in run(model, 'random', res, count, seed)
+    assert f'{count // 4} pairs, 0 differ' in run(model, 'kernel-random', res, count // 4, seed + 100)
 
 
 @pytest.mark.parametrize('mode', ['always', 'noapex'])

@@ -620,6 +620,37 @@ def test_metrics_on_reserved_cus_beside_the_raster_launch(own_stream):
     torch.cuda.synchronize()
 
 
+def test_reserved_detour_waits_for_the_inputs_built_after_the_fork():
+    """with overlap_infractions = 'reserved' and the caller NOT on the raster stream, the launch moves to the stream that is
+    kept off the reserved CUs.  Its per-launch inputs -- per-camera colour keys (custom_agent_colors), waypoint triangles and their keys -- are
+    built on the caller's stream AFTER the fork event, so the launch has to wait for an event recorded behind them.  Rendered many times with
+    fresh inputs each time and compared bit for bit with the serial order (loop matched: examples/gym_env.py:83-126 of the reference)."""
+    import bench
+    from torchdrivesim_amd.utils import Resolution
+    B, A = 16, 64
+    sim, actions, _ = bench.build_simulator(B, A, torch.device(DEV), seed=21)
+    ref, _, _ = bench.build_simulator(B, A, torch.device(DEV), seed=21)
+    res = Resolution(256, 256)
+    sim.overlap_infractions = 'reserved'
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for i in range(6):
+        sim.step(actions[i % actions.shape[0]])
+        ref.step(actions[i % actions.shape[0]])
+        state = sim.get_state()
+        # fresh per-launch inputs every time: the values the kernel reads are written right before the launch is enqueued
+        cc = torch.rand(B, A, A, 3, device=DEV, generator=gen)
+        wp = state[..., None, :2] + torch.rand(B, A, 3, 2, device=DEV, generator=gen) * 20 - 10
+        wm = torch.rand(B, A, 3, device=DEV, generator=gen) > 0.2
+        kw = dict(res=res, fov=35.0, custom_agent_colors=cc, waypoints=wp, waypoints_rendering_mask=wm)
+        img = sim.render(state[..., :2], state[..., 2:3], **kw)
+        col = sim.compute_collision()
+        assert sim._fork is not None                                   # the detour was taken (float32 256 x 256 is write-bound, the layout verified)
+        exp = ref.render(state[..., :2], state[..., 2:3], **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(img, exp) and torch.equal(col, ref.compute_collision())
+        assert (img.flatten(2).amax(-1) > 0).all()
+
+
 def test_image_ring_is_chosen_among_candidates():
     """rendering.allocate_image_ring on the device: the buffers come from the library's allocator (spread-out physical pages, not torch's
     pool), are distinct, hold a rendered image, and the report carries the yardstick.  The decision logic itself is tested on the CPU with

@@ -2013,33 +2013,17 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, int k, bool acc, unsigned 
     }
 }
 
-// Queue the triangles of the polys of a producer step (at most one poly per lane: one or two triangles, each in its own vertex order) and
-// rasterise the queue whenever it is full.  `flags`: the poly record's (plane index included).  The rasteriser works triangle by triangle:
-// painting the rows of a pair as one was built and measured in round 5 (tests/fill_quads_model.c is the exact rule) and lost -- the third
-// chain and the extra cut rows cost the row items more than the halved row count gives back.
-// BIG: polys outside the packed coordinate range may come along (px, py: their unpacked vertices): they take the exact sequential path,
-// triangle by triangle, on the spot; the list kernel never sees one.
-template <bool BIG = true>
-__device__ __forceinline__ void drain_poly(BitCtx &w, bool acc, uint32_t flags, const uint32_t (&P)[4], bool big, const int (&px)[4], const int (&py)[4], bool more) {
+// Queue the triangles of the poly records K3r reads from its camera's list (at most one poly per lane: one or two triangles, each in its own
+// vertex order; acc1 / acc2: which of them still have to be rasterised) and rasterise the queue whenever it is full.  `flags`: the poly
+// record's.  The rasteriser works triangle by triangle: painting the rows of a pair as one was built and measured in round 5
+// (tests/fill_quads_model.c is the exact rule) and lost -- the third chain and the extra cut rows cost the row items more than the halved
+// row count gives back.
+__device__ __forceinline__ void drain_poly(BitCtx &w, bool acc1, bool acc2, uint32_t flags, const uint32_t (&P)[4], bool more) {
     const uint32_t b0 = (flags >> 10) & 3u, b1 = (flags >> 12) & 3u, b2 = (flags >> 14) & 3u;
-    if constexpr (BIG) {
-        big = big && acc;
-        if (__builtin_expect(__ballot(big) != 0, 0)) {
-            if (big) {
-                uint32_t *pl = w.planes + (size_t)(flags & 15u) * w.H * w.wpr;
-                fill_generic_bits(pl, w.H, w.W, w.X0, w.TWp, w.wpr, px[0], py[0], px[1], py[1], px[2], py[2]);
-                if (flags & PF_HAS2)
-                    fill_generic_bits(pl, w.H, w.W, w.X0, w.TWp, w.wpr, (int)sel4(px[0], px[1], px[2], px[3], b0), (int)sel4(py[0], py[1], py[2], py[3], b0),
-                                      (int)sel4(px[0], px[1], px[2], px[3], b1), (int)sel4(py[0], py[1], py[2], py[3], b1),
-                                      (int)sel4(px[0], px[1], px[2], px[3], b2), (int)sel4(py[0], py[1], py[2], py[3], b2));
-            }
-            acc = acc && !big;
-        }
-    }
     // two rounds: the first triangles of all polys, then the second ones (a triangle of the queue is plane | outline edges << 4 + three vertices)
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-        const bool mine = acc && (h == 0 || (flags & PF_HAS2));
+        const bool mine = h == 0 ? acc1 : acc2;
         const bool last = more ? false : (h == 1);
         if (h == 1 && __ballot(mine) == 0) { if (!more) { process_batch_bits(w, w.qlen, true); w.qlen = 0; } break; }
         const uint32_t q0 = (flags & 15u) | (((flags >> (h ? 7 : 4)) & 7u) << 4);
@@ -2623,31 +2607,31 @@ __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArg
             chunk = __builtin_amdgcn_readfirstlane((int)nxt);
         }
         const uint32_t P[4] = {e.y, e.z, e.w, e3};
-        const int px[4] = {unpack_x(e.y), unpack_x(e.z), unpack_x(e.w), unpack_x(e3)}, py[4] = {unpack_y(e.y), unpack_y(e.z), unpack_y(e.w), unpack_y(e3)};
-        const int xmin = min(min(px[0], px[1]), min(px[2], px[3])), xmax = max(max(px[0], px[1]), max(px[2], px[3]));
-        if (c.strips > 1) acc = acc && !(xmax < X0 || xmin > Xhi);      // polys that miss this strip are not queued
-        // SMALL polys -- every vertex inside the image, in one row or in two adjacent rows (up to four from SMALL_TALL_RES on): two thirds of
-        // the faces of a 64 x 64 view, a third at 128 x 128 -- are painted on the spot by their lane, triangle by triangle
-        // (process_small_bits: nothing to scan-convert, no edge to clip or walk); only the others go through the queue and the full set-up
-        if (!(TDS_DBG(c.debug) & 32768)) {
-            const int ymin = min(min(py[0], py[1]), min(py[2], py[3])), ymax = max(max(py[0], py[1]), max(py[2], py[3]));
-            const bool inside = acc && xmin >= 0 && xmax < W && ymin >= 0 && ymax < H;
-            const bool has2 = (e.x & PF_HAS2) != 0u;
-            const uint32_t b0 = (e.x >> 10) & 3u, b1 = (e.x >> 12) & 3u, b2 = (e.x >> 14) & 3u;
-            const uint32_t t0 = sel4(P[0], P[1], P[2], P[3], b0), t1 = sel4(P[0], P[1], P[2], P[3], b1), t2 = sel4(P[0], P[1], P[2], P[3], b2);
-            bool small;
-            if (res >= SMALL_TALL_RES) {                                  // wave-uniform choice
-                small = inside && ymax - ymin <= 3;
-                process_small_bits<true>(w, small, e.x, P[0], P[1], P[2]);
-                process_small_bits<true>(w, small && has2, e.x, t0, t1, t2);
-            } else {
-                small = inside && ymax - ymin <= 1;
-                process_small_bits<false>(w, small, e.x, P[0], P[1], P[2]);
-                process_small_bits<false>(w, small && has2, e.x, t0, t1, t2);
-            }
-            acc = acc && !small;
+        const bool has2 = (e.x & PF_HAS2) != 0u;
+        const uint32_t b0 = (e.x >> 10) & 3u, b1 = (e.x >> 12) & 3u, b2 = (e.x >> 14) & 3u;
+        const uint32_t T[3] = {sel4(P[0], P[1], P[2], P[3], b0), sel4(P[0], P[1], P[2], P[3], b1), sel4(P[0], P[1], P[2], P[3], b2)};     // the second triangle
+        // per triangle: does it touch this strip, and is it SMALL -- its three vertices inside the image, in one row or in two adjacent rows
+        // (up to four from SMALL_TALL_RES on): two thirds of the faces of a 64 x 64 view, a third at 128 x 128.  Small triangles are painted on
+        // the spot by their lane (process_small_bits: nothing to scan-convert, no edge to clip or walk); only the others go through the queue
+        // and the full set-up.
+        const int span = res >= SMALL_TALL_RES ? 3 : 1;                    // wave-uniform
+        auto classify = [&](uint32_t v0, uint32_t v1, uint32_t v2, bool on, bool &small) {
+            const int x0 = unpack_x(v0), x1 = unpack_x(v1), x2 = unpack_x(v2), y0 = unpack_y(v0), y1 = unpack_y(v1), y2 = unpack_y(v2);
+            const int xmin = min(x0, min(x1, x2)), xmax = max(x0, max(x1, x2)), ymin = min(y0, min(y1, y2)), ymax = max(y0, max(y1, y2));
+            if (c.strips > 1) on = on && !(xmax < X0 || xmin > Xhi);       // triangles that miss this strip are not queued
+            small = on && !(TDS_DBG(c.debug) & 32768) && xmin >= 0 && xmax < W && ymin >= 0 && ymax < H && ymax - ymin <= span;
+            return on;
+        };
+        bool small1, small2;
+        const bool on1 = classify(P[0], P[1], P[2], acc, small1), on2 = classify(T[0], T[1], T[2], acc && has2, small2);
+        if (res >= SMALL_TALL_RES) {
+            process_small_bits<true>(w, small1, e.x, P[0], P[1], P[2]);
+            process_small_bits<true>(w, small2, e.x, T[0], T[1], T[2]);
+        } else {
+            process_small_bits<false>(w, small1, e.x, P[0], P[1], P[2]);
+            process_small_bits<false>(w, small2, e.x, T[0], T[1], T[2]);
         }
-        drain_poly<false>(w, acc, e.x, P, false, px, py, more);
+        drain_poly(w, on1 && !small1, on2 && !small2, e.x, P, more);
         if (!more) break;
     }
     __syncthreads();
