@@ -3015,7 +3015,11 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                         int lw = g_list_waves;
                         int tws = (res + 31) & ~31;
                         // (ms at B = 1024 x 64 with 1 / 2 / 4 waves: 32 x 32 2.30 / 2.33 / 2.45, 64 x 64 2.53 / 2.45 / 2.59, 96 x 96 3.32 / 2.89 / 3.03, 128 x 128 4.75 / 3.80 / 3.57)
-                        if (lw == 0) lw = (int64_t)res * tws <= 104 * 104 ? 2 : 4;
+                        // (round 5, poly records: uint8 112 x 112 2.71 / 3.04, 128 2.84 / 3.08, 144 3.34 / 3.29, 160 3.62 / 3.39; float32 112 3.11 / 3.14, 128 3.23 / 3.15.
+                        //  Tried on the record loop of K3r and dropped: a chunk of 32 records with a lane per TRIANGLE instead of 64 records with a lane per
+                        //  record (64 x 64 2.27 -> 2.44 ms, 128 x 128 3.38 -> 3.65: two triangles per lane interleave, one per lane waits); the records of
+                        //  the next chunk requested one iteration ahead (2.17 -> 2.26, 3.09 -> 3.28: the pre-claimed chunk unbalances the waves' tails))
+                        if (lw == 0) lw = (int64_t)res * tws <= (f32 ? 104 * 104 : 128 * 128) ? 2 : 4;
                         while (tws > 32 && bits_lds_bytes(kt.n, res, tws, lw, out_mode) > (size_t)g_list_lds_kb * 1024) tws -= 32;
                         const size_t lds_s = bits_lds_bytes(kt.n, res, tws, lw, out_mode);
                         if (lds_s <= 150 * 1024) {
