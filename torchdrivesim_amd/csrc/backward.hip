@@ -377,39 +377,87 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
     return best;
 }
 
+// the same arg-min by the ordered descent of the hierarchy over the faces (see nearest_face_d2_bvh in map.hip); one lane per point, its stack
+// in private memory
+__device__ float nearest_face_d2_grad_bvh(const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop) {
+    constexpr int CAP = 32;
+    int stk[CAP];
+    float slb[CAP];
+    float best = __builtin_inff();
+    int best_f = 0x7fffffff;                 // among faces at the same distance the one of lowest index gives the gradient (torch.min's choice)
+    gx = gy = 0.0f;
+    auto box_lb = [&](float x0, float y0, float x1, float y1) {
+        const float ex = fmaxf(fmaxf(x0 - px, px - x1), 0.0f), ey = fmaxf(fmaxf(y0 - py, py - y1), 0.0f);
+        return (ex * ex + ey * ey) * 0.998f - 1e-3f;
+    };
+    int sp = 0, cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const tds::BvhNode nd = nv.bvh[cur];
+            const float ll = box_lb(nd.lx0, nd.ly0, nd.lx1, nd.ly1), lr = box_lb(nd.rx0, nd.ry0, nd.rx1, nd.ry1);
+            const bool left_first = ll <= lr;
+            const int nearc = left_first ? nd.left : nd.right, farc = left_first ? nd.right : nd.left;
+            const float nlb = left_first ? ll : lr, flb = left_first ? lr : ll;
+            if (flb <= best && sp < CAP) { stk[sp] = farc; slb[sp] = flb; ++sp; }
+            if (nlb <= best) { cur = nearc; continue; }
+        } else {
+            const int code = -1 - cur, first = code >> 4, cnt = code & 15;
+            for (int j = 0; j < cnt; ++j) {
+                const int f = nv.bvh_idx[first + j];
+                const GridEntry ge = nv.faces[f];
+                const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
+                const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
+                if (box_lb(fx0, fy0, fx1, fy1) > best) continue;                     // (a box AT the minimum may hold a face that ties it)
+                float tgx, tgy;
+                const float d = tri_d2_grad(px, py, ge, tgx, tgy);
+                if (d < best || (d == best && f < best_f)) { best = d; best_f = f; gx = tgx; gy = tgy; }
+            }
+        }
+        float lb;
+        do {
+            if (sp == 0 || best <= stop) return best;
+            --sp;
+            cur = stk[sp]; lb = slb[sp];
+        } while (lb > best);
+    }
+}
+
 // the same arg-min from the candidate list of the point's cell (tds::NearView, see nearest_face_d2_lists in map.hip)
 __device__ float nearest_face_d2_grad_lists(const MapView &m, const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop) {
     if (nv.cand == nullptr || m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py))
         return nearest_face_d2_grad(m, px, py, gx, gy, stop);
+    // beyond the lists' grid: the hierarchy over the faces where the map has one, else the walk over grid rings
+    auto beyond = [&]() { return nv.bvh != nullptr ? nearest_face_d2_grad_bvh(nv, px, py, gx, gy, stop) : nearest_face_d2_grad(m, px, py, gx, gy, stop); };
     const float fx = (px - nv.ox) * m.inv_cell, fy = (py - nv.oy) * m.inv_cell;
-    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny)) return nearest_face_d2_grad(m, px, py, gx, gy, stop);
+    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny)) return beyond();
     const int cx = tds::cell_coord(px, nv.ox, m.inv_cell), cy = tds::cell_coord(py, nv.oy, m.inv_cell);
-    if (cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny) return nearest_face_d2_grad(m, px, py, gx, gy, stop);
+    if (cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny) return beyond();
     const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
     float best = __builtin_inff();
+    int best_f = 0x7fffffff;                 // among faces at the same distance the one of lowest index gives the gradient (torch.min's choice)
     gx = gy = 0.0f;
     // as the forward walk (map.hip: nearest_face_d2_lists): four candidates in flight, a face whose bounding box is already farther than
     // the running minimum is not evaluated
     auto consider = [&](const tds::NearCand &c, const GridEntry &ge) {
-        if (c.lb >= best) return;
+        if (c.lb > best) return;
         const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
         const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
         const float ex = fmaxf(fmaxf(fx0 - px, px - fx1), 0.0f), ey = fmaxf(fmaxf(fy0 - py, py - fy1), 0.0f);
-        if ((ex * ex + ey * ey) * 0.998f - 1e-3f >= best) return;
+        if ((ex * ex + ey * ey) * 0.998f - 1e-3f > best) return;
         float tgx, tgy;
         const float d = tri_d2_grad(px, py, ge, tgx, tgy);
-        if (d < best) { best = d; gx = tgx; gy = tgy; }
+        if (d < best || (d == best && c.face < best_f)) { best = d; best_f = c.face; gx = tgx; gy = tgy; }
     };
     int i = s;
     for (; i + 4 <= e && best > stop; i += 4) {
         const tds::NearCand c0 = nv.cand[i], c1 = nv.cand[i + 1], c2 = nv.cand[i + 2], c3 = nv.cand[i + 3];
-        if (c0.lb >= best) return best;                         // sorted by lb: nothing further can be nearer
+        if (c0.lb > best) return best;                          // sorted by lb: nothing further can be as near
         const GridEntry g0 = nv.faces[c0.face], g1 = nv.faces[c1.face], g2 = nv.faces[c2.face], g3 = nv.faces[c3.face];
         consider(c0, g0); consider(c1, g1); consider(c2, g2); consider(c3, g3);
     }
     for (; i < e && best > stop; ++i) {
         const tds::NearCand c0 = nv.cand[i];
-        if (c0.lb >= best) break;
+        if (c0.lb > best) break;
         consider(c0, nv.faces[c0.face]);
     }
     return best;
@@ -512,7 +560,7 @@ TDS_EXPORT int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t 
     TDS_CHECK_ARG(state && lenwid && sc && grad_out, "tds_offroad_multi_bwd_f32: null pointer");
     int64_t threads = n_agents * 4;
     hipLaunchKernelGGL(offroad_bwd_kernel, dim3((unsigned)((threads + GBLOCK - 1) / GBLOCK)), dim3(GBLOCK), 0, (hipStream_t)stream, tds::MapView{},
-                       tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present,
+                       tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0, nullptr, nullptr}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present,
                        grad_out, (float4 *)grad_state, (float2 *)grad_lenwid, (float2 *)grad_sc, n_agents, threshold, (const MapView *)set->d_views,
                        (const tds::NearView *)set->d_near, scene_map, (int)agents_per_scene);
     TDS_LAUNCH_CHECK("offroad_bwd_kernel");

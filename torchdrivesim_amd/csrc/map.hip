@@ -19,12 +19,14 @@ using tds::MapView;
 #ifdef TDS_TESTING
 static int g_near_lists = 1;
 #define TDS_NEAR_LISTS_ENABLED (g_near_lists != 0)
+#define TDS_BVH_BUILD (g_near_lists != 2)          // 2: candidate lists but no hierarchy (points beyond the lists walk grid rings, as before round 5)
 TDS_EXPORT int tds_testing_set_near_lists(int enabled) {
     g_near_lists = enabled;
     return TDS_OK;
 }
 #else
 #define TDS_NEAR_LISTS_ENABLED true
+#define TDS_BVH_BUILD true
 #endif
 
 
@@ -136,6 +138,66 @@ void build_near_lists(const float *verts, const int32_t *faces, int64_t F, float
             }
             cand_start[(size_t)c + 1] = (int32_t)cand.size();
         }
+}
+// Host: the hierarchy over the faces with finite vertices (tds::BvhNode).  Median splits along the longer axis of the centroids' box, leaves
+// of at most 8 faces (one per lane of a group of the off-road kernel): the depth stays below 24 for any mesh tds_map_create accepts.
+void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<tds::BvhNode> &nodes, std::vector<int32_t> &idx) {
+    struct Box { float x0, y0, x1, y1; };
+    std::vector<Box> fb((size_t)F);
+    std::vector<float> cx((size_t)F), cy((size_t)F);
+    idx.clear(); nodes.clear();
+    for (int64_t f = 0; f < F; ++f) {
+        const float *p0 = verts + 2 * faces[3 * f], *p1 = verts + 2 * faces[3 * f + 1], *p2 = verts + 2 * faces[3 * f + 2];
+        if (!(std::isfinite(p0[0]) && std::isfinite(p0[1]) && std::isfinite(p1[0]) && std::isfinite(p1[1]) && std::isfinite(p2[0]) && std::isfinite(p2[1]))) continue;
+        Box &b = fb[(size_t)f];
+        b.x0 = std::min(p0[0], std::min(p1[0], p2[0])); b.x1 = std::max(p0[0], std::max(p1[0], p2[0]));
+        b.y0 = std::min(p0[1], std::min(p1[1], p2[1])); b.y1 = std::max(p0[1], std::max(p1[1], p2[1]));
+        cx[(size_t)f] = 0.5f * (b.x0 + b.x1); cy[(size_t)f] = 0.5f * (b.y0 + b.y1);
+        idx.push_back((int32_t)f);
+    }
+    if (idx.empty()) return;
+    const Box none = {INFINITY, INFINITY, -INFINITY, -INFINITY};
+    auto box_of = [&](int lo, int hi) {
+        Box b = none;
+        for (int i = lo; i < hi; ++i) {
+            const Box &q = fb[(size_t)idx[(size_t)i]];
+            b.x0 = std::min(b.x0, q.x0); b.y0 = std::min(b.y0, q.y0); b.x1 = std::max(b.x1, q.x1); b.y1 = std::max(b.y1, q.y1);
+        }
+        return b;
+    };
+    // child of a node over idx[lo, hi): a leaf code, or a new inner node (filled by the work list below)
+    struct Work { int lo, hi, node; };
+    std::vector<Work> work;
+    auto child = [&](int lo, int hi) -> int32_t {
+        if (hi - lo <= 8) return -1 - ((lo << 4) | (hi - lo));
+        nodes.push_back(tds::BvhNode{});
+        work.push_back(Work{lo, hi, (int)nodes.size() - 1});
+        return (int32_t)nodes.size() - 1;
+    };
+    nodes.push_back(tds::BvhNode{});
+    work.push_back(Work{0, (int)idx.size(), 0});
+    while (!work.empty()) {
+        const Work w = work.back();
+        work.pop_back();
+        int mid = w.lo;
+        if (w.hi - w.lo > 8) {
+            float mx0 = INFINITY, mx1 = -INFINITY, my0 = INFINITY, my1 = -INFINITY;
+            for (int i = w.lo; i < w.hi; ++i) {
+                mx0 = std::min(mx0, cx[(size_t)idx[(size_t)i]]); mx1 = std::max(mx1, cx[(size_t)idx[(size_t)i]]);
+                my0 = std::min(my0, cy[(size_t)idx[(size_t)i]]); my1 = std::max(my1, cy[(size_t)idx[(size_t)i]]);
+            }
+            const std::vector<float> &key = (mx1 - mx0 >= my1 - my0) ? cx : cy;
+            mid = w.lo + (w.hi - w.lo) / 2;
+            std::nth_element(idx.begin() + w.lo, idx.begin() + mid, idx.begin() + w.hi, [&](int32_t a, int32_t b) { return key[(size_t)a] < key[(size_t)b] || (key[(size_t)a] == key[(size_t)b] && a < b); });
+        } else {
+            mid = w.hi;                  // (the root of a mesh of at most 8 faces: everything in the left leaf, an empty right one)
+        }
+        const Box bl = box_of(w.lo, mid), br = mid < w.hi ? box_of(mid, w.hi) : none;
+        const int32_t l = child(w.lo, mid), r = mid < w.hi ? child(mid, w.hi) : (-1 - ((mid << 4) | 0));
+        tds::BvhNode &n = nodes[(size_t)w.node];
+        n.lx0 = bl.x0; n.ly0 = bl.y0; n.lx1 = bl.x1; n.ly1 = bl.y1; n.rx0 = br.x0; n.ry0 = br.y0; n.rx1 = br.x1; n.ry1 = br.y1;
+        n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
+    }
 }
 }  // namespace
 
@@ -386,7 +448,7 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
     }
     m->V = V; m->F = F; m->n_entries = (int64_t)entries.size(); m->n_levels = face_z ? n_levels : 0;
     m->d_entries = nullptr; m->d_cell_start = nullptr;
-    m->near = tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}; m->n_cand = 0;
+    m->near = tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0, nullptr, nullptr}; m->n_cand = 0;
     // geometry-only maps are the ones K2b queries: give them nearest-face candidate lists
     std::vector<int32_t> cand_start;
     std::vector<tds::NearCand> cand;
@@ -398,6 +460,9 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         build_near_lists(verts, faces, F, ox, oy, cell, nx, ny, cand_start, cand, face_entries, near_ox, near_oy, near_nx, near_ny);
         if (cand.size() > ((size_t)1 << 28)) { cand.clear(); cand_start.clear(); }
     }
+    std::vector<tds::BvhNode> bvh_nodes;
+    std::vector<int32_t> bvh_idx;
+    if (with_near && !cand.empty() && TDS_BVH_BUILD) build_bvh(verts, faces, F, bvh_nodes, bvh_idx);
     hipError_t e = hipGetDevice(&m->device);
     size_t be = std::max<size_t>(entries.size(), 1) * sizeof(GridEntry), bc = cell_start.size() * sizeof(int32_t);
     if (e == hipSuccess) e = hipMalloc(&m->d_entries, be);
@@ -425,9 +490,19 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         if (e == hipSuccess) e = hipMemcpy(dc, cand.data(), b1, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(ds, cand_start.data(), b2, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(df, face_entries.data(), b3, hipMemcpyHostToDevice);
-        m->near = tds::NearView{(const tds::NearCand *)dc, (const int32_t *)ds, (const GridEntry *)df, near_ox, near_oy, near_nx, near_ny};
+        m->near = tds::NearView{(const tds::NearCand *)dc, (const int32_t *)ds, (const GridEntry *)df, near_ox, near_oy, near_nx, near_ny, nullptr, nullptr};
         m->n_cand = (int64_t)cand.size();
         bn = b1 + b2 + b3;
+        if (e == hipSuccess && !bvh_nodes.empty()) {
+            void *dn = nullptr, *di = nullptr;
+            const size_t b4 = bvh_nodes.size() * sizeof(tds::BvhNode), b5 = bvh_idx.size() * sizeof(int32_t);
+            e = hipMalloc(&dn, b4);
+            if (e == hipSuccess) e = hipMalloc(&di, b5);
+            if (e == hipSuccess) e = hipMemcpy(dn, bvh_nodes.data(), b4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(di, bvh_idx.data(), b5, hipMemcpyHostToDevice);
+            m->near.bvh = (const tds::BvhNode *)dn; m->near.bvh_idx = (const int32_t *)di;
+            bn += b4 + b5;
+        }
     }
     if (e != hipSuccess) {
         tds::set_error("tds_map_create: %s", hipGetErrorString(e));
@@ -438,6 +513,8 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
         if (m->near.cand) (void)hipFree((void *)m->near.cand);
         if (m->near.cand_start) (void)hipFree((void *)m->near.cand_start);
         if (m->near.faces) (void)hipFree((void *)m->near.faces);
+        if (m->near.bvh) (void)hipFree((void *)m->near.bvh);
+        if (m->near.bvh_idx) (void)hipFree((void *)m->near.bvh_idx);
         delete m;
         return e == hipErrorOutOfMemory ? TDS_ENOMEM : TDS_EHIP;
     }
@@ -471,6 +548,8 @@ TDS_EXPORT int tds_map_destroy(tds_map_t *map) {
     if (map->near.cand) (void)hipFree((void *)map->near.cand);
     if (map->near.cand_start) (void)hipFree((void *)map->near.cand_start);
     if (map->near.faces) (void)hipFree((void *)map->near.faces);
+    if (map->near.bvh) (void)hipFree((void *)map->near.bvh);
+    if (map->near.bvh_idx) (void)hipFree((void *)map->near.bvh_idx);
     if (cur != map->device) (void)hipSetDevice(cur);
     delete map;
     if (e1 != hipSuccess || e2 != hipSuccess) { tds::set_error("tds_map_destroy: hipFree failed"); return TDS_EHIP; }
@@ -602,6 +681,54 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
     return best;
 }
 
+// The same minimum by an ordered descent of the hierarchy over the faces (tds::BvhNode): for the points the candidate lists do not cover.
+// The group's lanes hold the same point and take every decision together: at an inner node the nearer child first, the farther one on
+// the group's stack (in LDS) when its box can still beat the minimum; at a leaf a face per lane.  Boxes are shrunk like everywhere in
+// K2b (x 0.998 - 1e-3): a subtree is left out only if every face in it is certainly farther than the minimum so far, so the result is
+// the minimum over ALL faces, bit for bit, and `stop` ends the descent as in the other walks.
+constexpr int BVH_STACK = 32;           // (the depth of the hierarchy is below 24: tds_map_create takes fewer than 2^24 faces, leaves hold 8)
+__device__ __forceinline__ float box_lb(float px, float py, float x0, float y0, float x1, float y1) {
+    const float ex = fmaxf(fmaxf(x0 - px, px - x1), 0.0f), ey = fmaxf(fmaxf(y0 - py, py - y1), 0.0f);
+    return (ex * ex + ey * ey) * 0.998f - 1e-3f;
+}
+__device__ float nearest_face_d2_bvh(const tds::NearView &nv, float px, float py, float stop, int sub) {
+    __shared__ int2 stacks[OBLOCK / OL][BVH_STACK];
+    int2 *st = stacks[threadIdx.x / OL];
+    const float inf = __builtin_inff();
+    float best = inf;
+    int sp = 0, cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const tds::BvhNode nd = nv.bvh[cur];
+            const float ll = box_lb(px, py, nd.lx0, nd.ly0, nd.lx1, nd.ly1), lr = box_lb(px, py, nd.rx0, nd.ry0, nd.rx1, nd.ry1);
+            const bool left_first = ll <= lr;
+            const int nearc = left_first ? nd.left : nd.right, farc = left_first ? nd.right : nd.left;
+            const float nlb = left_first ? ll : lr, flb = left_first ? lr : ll;
+            if (flb < best && sp < BVH_STACK) st[sp++] = make_int2(farc, __float_as_int(flb));
+            if (nlb < best) { cur = nearc; continue; }
+        } else {
+            const int code = -1 - cur, first = code >> 4, cnt = code & 15;
+            float d = inf;
+            for (int j = sub; j < cnt; j += OL) {
+                const GridEntry ge = nv.faces[nv.bvh_idx[first + j]];
+                const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
+                const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
+                if (box_lb(px, py, fx0, fy0, fx1, fy1) >= fminf(best, d)) continue;
+                const float t = tri_d2(px, py, ge);
+                d = (t < d) ? t : d;                                                  // a NaN distance never becomes the minimum
+            }
+            best = fminf(best, group_min(d));
+        }
+        // the next subtree that can still hold a nearer face
+        float lb;
+        do {
+            if (sp == 0 || best <= stop) return best;
+            --sp;
+            cur = st[sp].x; lb = __int_as_float(st[sp].y);
+        } while (lb >= best);
+    }
+}
+
 // The same minimum from the candidate list of the point's cell (tds::NearView), walked by OL lanes together: candidate i + lane of every
 // round, the group's running minimum by three xor-shuffles, ended by the first round whose first candidate has a lower bound that is not
 // below it (the list is sorted by lower bound) or as soon as the minimum is <= stop.  The minimum over faces does not depend on the order
@@ -620,7 +747,11 @@ __device__ __forceinline__ float nearest_face_d2_lists(const MapView &m, const t
             ring = cx < 0 || cy < 0 || cx >= nv.nx || cy >= nv.ny;
         }
     }
-    if (ring) return nearest_face_d2(m, px, py, stop, sub);                              // (uniform within the group: all its lanes hold the same point)
+    if (ring) {                                                                         // (uniform within the group: all its lanes hold the same point)
+        // beyond the lists' grid: the hierarchy over the faces where the map has one, else the walk over grid rings
+        if (nv.bvh != nullptr && px == px && py == py && !__builtin_isinf(px) && !__builtin_isinf(py)) return nearest_face_d2_bvh(nv, px, py, stop, sub);
+        return nearest_face_d2(m, px, py, stop, sub);
+    }
     const int s = nv.cand_start[cy * nv.nx + cx], e = nv.cand_start[cy * nv.nx + cx + 1];
     float best = inf;                                                                 // the group's minimum so far, the same in all its lanes
     for (int i = s; i < e && best > stop; i += OL) {
@@ -706,7 +837,7 @@ TDS_EXPORT int tds_offroad_multi_f32(const tds_mapset_t *set, const int32_t *sce
     TDS_CHECK_ARG(state && lenwid && sc && out, "tds_offroad_multi_f32: null pointer");
     int64_t threads = n_agents * 4 * OL;
     hipLaunchKernelGGL(offroad_kernel, dim3((unsigned)((threads + OBLOCK - 1) / OBLOCK)), dim3(OBLOCK), 0, (hipStream_t)stream, MapView{},
-                       tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents,
+                       tds::NearView{nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 0, nullptr, nullptr}, (const float4 *)state, (const float2 *)lenwid, (const float2 *)sc, present, out, n_agents,
                        threshold, (const MapView *)set->d_views, (const tds::NearView *)set->d_near, scene_map, (int)agents_per_scene);
     TDS_LAUNCH_CHECK("offroad_kernel");
     return TDS_OK;
