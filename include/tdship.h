@@ -127,7 +127,7 @@ typedef struct tds_map tds_map_t;
  * quantised as cv2.py:50: 0x00RRGGBB), levels: n_levels distinct rendering levels sorted DESCENDING that contain every
  * face_z and every actor level that will be rendered with this map (<= 255).  face_z / face_rgb / levels may be NULL
  * for a map that is only used by tds_offroad_f32; such a map also gets per-cell nearest-face candidate lists (exact),
- * which make the off-road query one short linear walk.  cell_size <= 0 selects the default (8 m).
+ * which make the off-road query one short linear walk, and a bounding-volume hierarchy over its faces for points beyond the lists' grid.  cell_size <= 0 selects the default (8 m).
  * The handle lives on the CURRENT HIP device. */
 int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
                    int64_t F, const float *levels, int n_levels, float cell_size, tds_map_t **out);
