@@ -694,7 +694,9 @@ class Simulator:
 
     def _beside_render(self, fn, key=None):
         """fn() -> Tensor: the result computed ahead of the raster launch when `key` was foreseen, else fn() on the side stream when a
-        render of exactly this state is in flight on the current stream, else in place"""
+        render of exactly this state is in flight on the current stream, else in place.
+        With overlap_infractions on, asking for the same metric twice between two renders returns the SAME tensor object (the result is
+        computed once per state): treat the returned tensors as read-only, or clone them before an in-place edit."""
         fork = self._fork
         if fork is None or not self.overlap_infractions:
             return fn()
