@@ -86,3 +86,33 @@ def test_collision_gradient_finite_differences():
                     fm = (_ops.collision(bm, present, metric=metric) * wgt).sum().item()
                     num[bi, ni, k] = (fp - fm) / (2 * eps)
         np.testing.assert_allclose(an, num, rtol=0.05, atol=0.02 * max(1.0, np.abs(num).max()))
+
+
+@pytest.mark.parametrize('metric', ['iou', 'discs'])
+def test_collision_gradient_of_a_large_scene_equals_that_of_its_far_apart_halves(metric):
+    """Scenes of up to 4096 pairs take the whole-scene backward kernel, larger ones one wavefront per row: a scene of 96 agents in two
+    clusters a kilometre apart (row kernel) must give each cluster the gradients it gets as a scene of its own (scene kernel)."""
+    from torchdrivesim_amd import _ops
+    gen = torch.Generator().manual_seed(11)
+    B, H = 3, 48
+    def cluster():
+        xy = (torch.rand(B, H, 2, generator=gen) - 0.5) * 40
+        return torch.cat([xy, 4 + torch.rand(B, H, 1, generator=gen), 1.8 + 0.4 * torch.rand(B, H, 1, generator=gen),
+                          (torch.rand(B, H, 1, generator=gen) - 0.5) * 6], -1)
+    c1, c2 = cluster(), cluster()
+    c2[..., 0] += 1000.0
+    present = torch.rand(B, 2 * H, generator=gen) > 0.1
+    wgt = torch.rand(B, 2 * H, generator=gen)
+    wgt[:, ::7] = 0.0                                   # rows without a gradient are skipped by both kernels
+    whole = torch.cat([c1, c2], 1).to(DEV).requires_grad_(True)
+    out = _ops.collision(whole, present.to(DEV), metric=metric)
+    (out * wgt.to(DEV)).sum().backward()
+    assert (out > 0).sum().item() > 20
+    for k, c in enumerate((c1, c2)):
+        part = c.to(DEV).requires_grad_(True)
+        sl = slice(k * H, (k + 1) * H)
+        o = _ops.collision(part, present[:, sl].to(DEV), metric=metric)
+        torch.testing.assert_close(o, out[:, sl].detach(), rtol=0, atol=0)
+        (o * wgt[:, sl].to(DEV)).sum().backward()
+        assert part.grad.abs().max().item() > 0
+        torch.testing.assert_close(whole.grad[:, sl], part.grad, rtol=1e-5, atol=1e-6 * part.grad.abs().max().item())
