@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(GBLOCK) collision_bwd_kernel(const float *__re
 // row for the handful of lanes whose partner is near (0.22 ms at B = 256 x 64 x 64 against 0.026 ms for the forward).  Here the near
 // pairs of the scene's rows that carry a gradient are gathered into an LDS list first and evaluated on full waves: overlaps ->
 // arg-max per row (first index on ties) -> gradients of every near pair but the row's maximum, accumulated per box in LDS (the
-// scene's boxes belong to this workgroup alone: no global atomics) and stored once.  Same pair functions, same rules as
+// scene's boxes belong to this workgroup alone: no global atomics, no zeroing beforehand) and stored once.  Same pair functions, same rules as
 // collision_bwd_kernel; only the order in which a box's contributions are added differs (it was not fixed there either).
 // LDS: boxes N x 6, sums N x 6, gout / arg-max A, overlaps A x N (float), the pair list A x N (uint16).
 template <int METRIC>
@@ -379,9 +379,9 @@ __global__ void __launch_bounds__(GBLOCK) collision_scene_bwd_kernel(const float
         if (gj.c != 0.0f) atomicAdd(aj + 5, gj.c);
     }
     __syncthreads();
-    for (int j = tid; j < N; j += GBLOCK) {                  // (the host wrapper zeroed both outputs; column 4 of grad_boxes stays zero)
+    for (int j = tid; j < N; j += GBLOCK) {                  // every element of both outputs (the heading's gradient flows through grad_sc)
         float *gb = gboxes + (b * N + j) * 5, *gs = gsc + (b * N + j) * 2;
-        gb[0] = acc[6 * j]; gb[1] = acc[6 * j + 1]; gb[2] = acc[6 * j + 2]; gb[3] = acc[6 * j + 3];
+        gb[0] = acc[6 * j]; gb[1] = acc[6 * j + 1]; gb[2] = acc[6 * j + 2]; gb[3] = acc[6 * j + 3]; gb[4] = 0.0f;
         gs[0] = acc[6 * j + 4]; gs[1] = acc[6 * j + 5];
     }
 }
@@ -623,9 +623,12 @@ TDS_EXPORT int tds_collision_bwd_f32(const float *boxes, const float *sc, const 
     TDS_CHECK_ARG(metric == TDS_METRIC_IOU || metric == TDS_METRIC_DISCS, "tds_collision_bwd_f32: unknown metric %d", metric);
     TDS_CHECK_ARG(grad_boxes && grad_sc, "tds_collision_bwd_f32: null gradient outputs");
     if (B == 0 || N == 0) return TDS_OK;
-    TDS_HIP(tds::zero_async(grad_boxes, (size_t)B * N * 5 * sizeof(float), (hipStream_t)stream));
-    TDS_HIP(tds::zero_async(grad_sc, (size_t)B * N * 2 * sizeof(float), (hipStream_t)stream));
-    if (A == 0) return TDS_OK;
+    auto zero_outputs = [&]() -> int {
+        TDS_HIP(tds::zero_async(grad_boxes, (size_t)B * N * 5 * sizeof(float), (hipStream_t)stream));
+        TDS_HIP(tds::zero_async(grad_sc, (size_t)B * N * 2 * sizeof(float), (hipStream_t)stream));
+        return TDS_OK;
+    };
+    if (A == 0) return zero_outputs();
     TDS_CHECK_ARG(boxes && sc && present && grad_out, "tds_collision_bwd_f32: null pointer");
     // whole scene per workgroup where its tables fit (see collision_scene_bwd_kernel); one wavefront per (scene, agent) otherwise
     const size_t lds_scene = ((size_t)N * 12 + 2 * (size_t)A + (size_t)A * N) * sizeof(float) + (size_t)A * N * sizeof(uint16_t);
@@ -637,8 +640,9 @@ TDS_EXPORT int tds_collision_bwd_f32(const float *boxes, const float *sc, const 
             hipLaunchKernelGGL(collision_scene_bwd_kernel<TDS_METRIC_DISCS>, dim3((unsigned)B), dim3(GBLOCK), lds_scene, (hipStream_t)stream, boxes, sc,
                                present, grad_out, grad_boxes, grad_sc, (int)A, (int)N);
         TDS_LAUNCH_CHECK("collision_scene_bwd_kernel");
-        return TDS_OK;
+        return TDS_OK;                                                         // (that kernel writes every element of both outputs)
     }
+    if (int rc = zero_outputs()) return rc;                                    // the row kernel adds into them
     dim3 grid((unsigned)((B * A * 64 + GBLOCK - 1) / GBLOCK));
     if (metric == TDS_METRIC_IOU)
         hipLaunchKernelGGL(collision_bwd_kernel<TDS_METRIC_IOU>, grid, dim3(GBLOCK), 0, (hipStream_t)stream, boxes, sc, present, grad_out,
