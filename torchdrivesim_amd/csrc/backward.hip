@@ -469,13 +469,18 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
     return best;
 }
 
-// the same arg-min by the ordered descent of the hierarchy over the faces (see nearest_face_d2_bvh in map.hip); one lane per point, its stack
-// in private memory
-__device__ float nearest_face_d2_grad_bvh(const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop) {
-    constexpr int CAP = 32;
-    int stk[CAP];
-    float slb[CAP];
-    float best = __builtin_inff();
+// the same arg-min by the ordered descent of the hierarchy over the faces (see nearest_face_d2_bvh in map.hip): the group's BL lanes hold the
+// same point, weigh a child each at an inner node and a face each at a leaf; boxes AT the running minimum are still opened (a face in them may
+// tie it, and the lowest face index among ties gives the gradient); the gradient is taken once, from the winning face
+constexpr int BL = 8;             // lanes per corner (a power of two, <= 16: a wavefront holds whole agents)
+constexpr int BVH_STACK = 64;     // (the depth of the hierarchy is below 8, a visit leaves at most 7 entries behind)
+__device__ float nearest_face_d2_grad_bvh(const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop, int sub) {
+    static_assert(BL == 8, "nearest_face_d2_grad_bvh: a lane per child of a node");
+    __shared__ int2 stacks[GBLOCK / BL][BVH_STACK];
+    int2 *st = stacks[threadIdx.x / BL];
+    const float inf = __builtin_inff();
+    const int shift = (int)(threadIdx.x & 63 & ~(BL - 1));                              // the group's first lane within the wavefront
+    float best = inf;
     int best_f = 0x7fffffff;                 // among faces at the same distance the one of lowest index gives the gradient (torch.min's choice)
     gx = gy = 0.0f;
     auto box_lb = [&](float x0, float y0, float x1, float y1) {
@@ -485,46 +490,71 @@ __device__ float nearest_face_d2_grad_bvh(const tds::NearView &nv, float px, flo
     int sp = 0, cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const tds::BvhNode nd = nv.bvh[cur];
-            const float ll = box_lb(nd.lx0, nd.ly0, nd.lx1, nd.ly1), lr = box_lb(nd.rx0, nd.ry0, nd.rx1, nd.ry1);
-            const bool left_first = ll <= lr;
-            const int nearc = left_first ? nd.left : nd.right, farc = left_first ? nd.right : nd.left;
-            const float nlb = left_first ? ll : lr, flb = left_first ? lr : ll;
-            if (flb <= best && sp < CAP) { stk[sp] = farc; slb[sp] = flb; ++sp; }
-            if (nlb <= best) { cur = nearc; continue; }
+            const float4 bx = nv.bvh[cur].box[sub];
+            const int ch = nv.bvh[cur].child[sub];
+            const float lb = box_lb(bx.x, bx.y, bx.z, bx.w);
+            const bool open = lb <= best && lb < inf;
+            const float key = open ? lb : inf;
+            int above = 0;                                                             // open children that will lie above this lane's on the stack
+#pragma unroll
+            for (int k = 1; k < BL; ++k) {
+                const float o = __shfl_xor(key, k);
+                above += (o < key || (o == key && (sub ^ k) < sub)) ? 1 : 0;
+            }
+            const int nopen = __popc((unsigned)(__ballot(open) >> shift) & 0xffu);
+            const int slot = sp + nopen - 1 - above;
+            if (open && slot < BVH_STACK) st[slot] = make_int2(ch, __float_as_int(lb));
+            sp = min(sp + nopen, BVH_STACK);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             const int code = -1 - cur, first = code >> 4, cnt = code & 15;
-            for (int j = 0; j < cnt; ++j) {
-                const int f = nv.bvh_idx[first + j];
-                const GridEntry ge = nv.faces[f];
+            float d = inf;
+            int f = 0x7fffffff;
+            if (sub < cnt) {
+                const int fi = nv.bvh_idx[first + sub];
+                const GridEntry ge = nv.faces[fi];
                 const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
                 const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
-                if (box_lb(fx0, fy0, fx1, fy1) > best) continue;                     // (a box AT the minimum may hold a face that ties it)
-                float tgx, tgy;
-                const float d = tri_d2_grad(px, py, ge, tgx, tgy);
-                if (d < best || (d == best && f < best_f)) { best = d; best_f = f; gx = tgx; gy = tgy; }
+                if (!(box_lb(fx0, fy0, fx1, fy1) > best)) {                             // (a box AT the minimum may hold a face that ties it)
+                    float tgx, tgy;
+                    const float t = tri_d2_grad(px, py, ge, tgx, tgy);                // (the distance alone: the gradient is taken below)
+                    if (t < inf) { d = t; f = fi; }                                   // a NaN distance never becomes the minimum
+                }
             }
+#pragma unroll
+            for (int k = 1; k < BL; k <<= 1) {
+                const float od = __shfl_xor(d, k);
+                const int of = __shfl_xor(f, k);
+                if (od < d || (od == d && of < f)) { d = od; f = of; }
+            }
+            if (d < best || (d == best && f < best_f)) { best = d; best_f = f; }
         }
-        float lb;
+        // the next subtree that can still hold a face as near
+        float lb = inf;
+        bool done = false;
         do {
-            if (sp == 0 || best <= stop) return best;
+            if (sp == 0 || best <= stop) { done = true; break; }
             --sp;
-            cur = stk[sp]; lb = slb[sp];
+            cur = st[sp].x; lb = __int_as_float(st[sp].y);
         } while (lb > best);
+        if (done) break;
     }
+    if (best_f != 0x7fffffff) best = tri_d2_grad(px, py, nv.faces[best_f], gx, gy);
+    return best;
 }
 
 // the same arg-min from the candidate list of the point's cell (tds::NearView, see nearest_face_d2_lists in map.hip).  As in the forward
 // kernel a point is served by a GROUP of BL consecutive lanes that all hold it; `sub` is the lane's place in its group: a round evaluates BL
 // candidates' DISTANCES side by side (one lane per point walked the list four at a time, gradients and all: 0.12 ms at 16 384 agents against the
 // forward's 0.04), the group agrees on (minimum, lowest face index), and the gradient is taken once, from the winning face.
-constexpr int BL = 8;             // lanes per corner (a power of two, <= 16: a wavefront holds whole agents)
 __device__ float nearest_face_d2_grad_lists(const MapView &m, const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop, int sub) {
     if (nv.cand == nullptr || m.nx <= 0 || !(px == px) || !(py == py) || __builtin_isinf(px) || __builtin_isinf(py))
         return nearest_face_d2_grad(m, px, py, gx, gy, stop);
-    // beyond the lists' grid: the hierarchy over the faces where the map has one, else the walk over grid rings (every lane of the group walks
-    // it for itself: the same point, the same answer)
-    auto beyond = [&]() { return nv.bvh != nullptr ? nearest_face_d2_grad_bvh(nv, px, py, gx, gy, stop) : nearest_face_d2_grad(m, px, py, gx, gy, stop); };
+    // beyond the lists' grid: the hierarchy over the faces where the map has one (walked by the group together), else the walk over grid rings
+    // (every lane of the group for itself: the same point, the same answer)
+    auto beyond = [&]() { return nv.bvh != nullptr ? nearest_face_d2_grad_bvh(nv, px, py, gx, gy, stop, sub) : nearest_face_d2_grad(m, px, py, gx, gy, stop); };
     const float fx = (px - nv.ox) * m.inv_cell, fy = (py - nv.oy) * m.inv_cell;
     if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)nv.nx && fy < (float)nv.ny)) return beyond();
     const int cx = tds::cell_coord(px, nv.ox, m.inv_cell), cy = tds::cell_coord(py, nv.oy, m.inv_cell);

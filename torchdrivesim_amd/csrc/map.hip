@@ -139,8 +139,9 @@ void build_near_lists(const float *verts, const int32_t *faces, int64_t F, float
             cand_start[(size_t)c + 1] = (int32_t)cand.size();
         }
 }
-// Host: the hierarchy over the faces with finite vertices (tds::BvhNode).  Median splits along the longer axis of the centroids' box, leaves
-// of at most 8 faces (one per lane of a group of the off-road kernel): the depth stays below 24 for any mesh tds_map_create accepts.
+// Host: the hierarchy over the faces with finite vertices (tds::BvhNode).  A node's faces are cut into up to eight parts by three rounds of
+// median splits, each along the longer axis of the part's centroids; parts of at most 8 faces are leaves (one face per lane of a group of the
+// off-road kernels), larger ones nodes of their own: the depth stays below 8 for any mesh tds_map_create accepts (fewer than 2^24 faces).
 void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<tds::BvhNode> &nodes, std::vector<int32_t> &idx) {
     struct Box { float x0, y0, x1, y1; };
     std::vector<Box> fb((size_t)F);
@@ -165,38 +166,54 @@ void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<
         }
         return b;
     };
-    // child of a node over idx[lo, hi): a leaf code, or a new inner node (filled by the work list below)
+    // idx[lo, hi) cut in two at the median of the longer axis of its centroids' box (ties by face index: the build is deterministic)
+    auto split = [&](int lo, int hi) {
+        float mx0 = INFINITY, mx1 = -INFINITY, my0 = INFINITY, my1 = -INFINITY;
+        for (int i = lo; i < hi; ++i) {
+            mx0 = std::min(mx0, cx[(size_t)idx[(size_t)i]]); mx1 = std::max(mx1, cx[(size_t)idx[(size_t)i]]);
+            my0 = std::min(my0, cy[(size_t)idx[(size_t)i]]); my1 = std::max(my1, cy[(size_t)idx[(size_t)i]]);
+        }
+        const std::vector<float> &key = (mx1 - mx0 >= my1 - my0) ? cx : cy;
+        const int mid = lo + (hi - lo) / 2;
+        std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int32_t a, int32_t b) { return key[(size_t)a] < key[(size_t)b] || (key[(size_t)a] == key[(size_t)b] && a < b); });
+        return mid;
+    };
     struct Work { int lo, hi, node; };
     std::vector<Work> work;
-    auto child = [&](int lo, int hi) -> int32_t {
-        if (hi - lo <= 8) return -1 - ((lo << 4) | (hi - lo));
-        nodes.push_back(tds::BvhNode{});
-        work.push_back(Work{lo, hi, (int)nodes.size() - 1});
-        return (int32_t)nodes.size() - 1;
-    };
     nodes.push_back(tds::BvhNode{});
     work.push_back(Work{0, (int)idx.size(), 0});
     while (!work.empty()) {
         const Work w = work.back();
         work.pop_back();
-        int mid = w.lo;
-        if (w.hi - w.lo > 8) {
-            float mx0 = INFINITY, mx1 = -INFINITY, my0 = INFINITY, my1 = -INFINITY;
-            for (int i = w.lo; i < w.hi; ++i) {
-                mx0 = std::min(mx0, cx[(size_t)idx[(size_t)i]]); mx1 = std::max(mx1, cx[(size_t)idx[(size_t)i]]);
-                my0 = std::min(my0, cy[(size_t)idx[(size_t)i]]); my1 = std::max(my1, cy[(size_t)idx[(size_t)i]]);
+        // the parts of this node: three rounds, each cutting every part of more than 8 faces in two
+        int cut[9] = {w.lo, w.hi, 0, 0, 0, 0, 0, 0, 0}, nparts = 1;
+        for (int round = 0; round < 3; ++round) {
+            int next[9], nn = 0;
+            for (int p = 0; p < nparts; ++p) {
+                next[nn++] = cut[p];
+                if (cut[p + 1] - cut[p] > 8) next[nn++] = split(cut[p], cut[p + 1]);
             }
-            const std::vector<float> &key = (mx1 - mx0 >= my1 - my0) ? cx : cy;
-            mid = w.lo + (w.hi - w.lo) / 2;
-            std::nth_element(idx.begin() + w.lo, idx.begin() + mid, idx.begin() + w.hi, [&](int32_t a, int32_t b) { return key[(size_t)a] < key[(size_t)b] || (key[(size_t)a] == key[(size_t)b] && a < b); });
-        } else {
-            mid = w.hi;                  // (the root of a mesh of at most 8 faces: everything in the left leaf, an empty right one)
+            next[nn] = cut[nparts];
+            for (int p = 0; p <= nn; ++p) cut[p] = next[p];
+            nparts = nn;
         }
-        const Box bl = box_of(w.lo, mid), br = mid < w.hi ? box_of(mid, w.hi) : none;
-        const int32_t l = child(w.lo, mid), r = mid < w.hi ? child(mid, w.hi) : (-1 - ((mid << 4) | 0));
-        tds::BvhNode &n = nodes[(size_t)w.node];
-        n.lx0 = bl.x0; n.ly0 = bl.y0; n.lx1 = bl.x1; n.ly1 = bl.y1; n.rx0 = br.x0; n.ry0 = br.y0; n.rx1 = br.x1; n.ry1 = br.y1;
-        n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
+        tds::BvhNode n;
+        for (int k = 0; k < 8; ++k) {
+            n.box[k] = make_float4(none.x0, none.y0, none.x1, none.y1);
+            n.child[k] = -1;                                   // a leaf without faces
+            if (k >= nparts) continue;
+            const int lo = cut[k], hi = cut[k + 1];
+            const Box b = box_of(lo, hi);
+            n.box[k] = make_float4(b.x0, b.y0, b.x1, b.y1);
+            if (hi - lo <= 8) {
+                n.child[k] = -1 - ((lo << 4) | (hi - lo));
+            } else {
+                nodes.push_back(tds::BvhNode{});
+                work.push_back(Work{lo, hi, (int)nodes.size() - 1});
+                n.child[k] = (int32_t)nodes.size() - 1;
+            }
+        }
+        nodes[(size_t)w.node] = n;
     }
 }
 }  // namespace
@@ -682,11 +699,14 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
 }
 
 // The same minimum by an ordered descent of the hierarchy over the faces (tds::BvhNode): for the points the candidate lists do not cover.
-// The group's lanes hold the same point and take every decision together: at an inner node the nearer child first, the farther one on
-// the group's stack (in LDS) when its box can still beat the minimum; at a leaf a face per lane.  Boxes are shrunk like everywhere in
-// K2b (x 0.998 - 1e-3): a subtree is left out only if every face in it is certainly farther than the minimum so far, so the result is
-// the minimum over ALL faces, bit for bit, and `stop` ends the descent as in the other walks.
-constexpr int BVH_STACK = 32;           // (the depth of the hierarchy is below 24: tds_map_create takes fewer than 2^24 faces, leaves hold 8)
+// The group's lanes hold the same point.  At an inner node every lane weighs ONE of the eight children (a 16-byte box each: one 128-byte
+// line for the group); the children whose box can still beat the minimum go onto the group's stack (in LDS) farthest first -- a lane finds
+// its place by comparing its bound with the other seven -- and the nearest is taken up at once; at a leaf a face per lane.  Boxes are
+// shrunk like everywhere in K2b (x 0.998 - 1e-3): a subtree is left out only if every face in it is certainly farther than the minimum so
+// far, so the result is the minimum over ALL faces, bit for bit, and `stop` ends the descent as in the other walks.  (Round 5 began with
+// two children per node, both weighed by every lane: three times the depth, 0.60 ms for 65 536 strayed agents.)
+static_assert(OL == 8, "nearest_face_d2_bvh: a lane per child of a node");
+constexpr int BVH_STACK = 64;           // (the depth of the hierarchy is below 8, a visit leaves at most 7 entries behind)
 __device__ __forceinline__ float box_lb(float px, float py, float x0, float y0, float x1, float y1) {
     const float ex = fmaxf(fmaxf(x0 - px, px - x1), 0.0f), ey = fmaxf(fmaxf(y0 - py, py - y1), 0.0f);
     return (ex * ex + ey * ey) * 0.998f - 1e-3f;
@@ -695,27 +715,40 @@ __device__ float nearest_face_d2_bvh(const tds::NearView &nv, float px, float py
     __shared__ int2 stacks[OBLOCK / OL][BVH_STACK];
     int2 *st = stacks[threadIdx.x / OL];
     const float inf = __builtin_inff();
+    const int shift = (int)(threadIdx.x & 63 & ~(OL - 1));                              // the group's first lane within the wavefront
     float best = inf;
     int sp = 0, cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const tds::BvhNode nd = nv.bvh[cur];
-            const float ll = box_lb(px, py, nd.lx0, nd.ly0, nd.lx1, nd.ly1), lr = box_lb(px, py, nd.rx0, nd.ry0, nd.rx1, nd.ry1);
-            const bool left_first = ll <= lr;
-            const int nearc = left_first ? nd.left : nd.right, farc = left_first ? nd.right : nd.left;
-            const float nlb = left_first ? ll : lr, flb = left_first ? lr : ll;
-            if (flb < best && sp < BVH_STACK) st[sp++] = make_int2(farc, __float_as_int(flb));
-            if (nlb < best) { cur = nearc; continue; }
+            const float4 bx = nv.bvh[cur].box[sub];
+            const int ch = nv.bvh[cur].child[sub];
+            const float lb = box_lb(px, py, bx.x, bx.y, bx.z, bx.w);
+            const bool open = lb < best;
+            const float key = open ? lb : inf;
+            int above = 0;                                                             // open children that will lie above this lane's on the stack
+#pragma unroll
+            for (int k = 1; k < OL; ++k) {
+                const float o = __shfl_xor(key, k);
+                above += (o < key || (o == key && (sub ^ k) < sub)) ? 1 : 0;
+            }
+            const int nopen = __popc((unsigned)(__ballot(open) >> shift) & 0xffu);
+            const int slot = sp + nopen - 1 - above;
+            if (open && slot < BVH_STACK) st[slot] = make_int2(ch, __float_as_int(lb));
+            sp = min(sp + nopen, BVH_STACK);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             const int code = -1 - cur, first = code >> 4, cnt = code & 15;
             float d = inf;
-            for (int j = sub; j < cnt; j += OL) {
-                const GridEntry ge = nv.faces[nv.bvh_idx[first + j]];
+            if (sub < cnt) {
+                const GridEntry ge = nv.faces[nv.bvh_idx[first + sub]];
                 const float fx0 = fminf(ge.x0, fminf(ge.x1, ge.x2)), fx1 = fmaxf(ge.x0, fmaxf(ge.x1, ge.x2));
                 const float fy0 = fminf(ge.y0, fminf(ge.y1, ge.y2)), fy1 = fmaxf(ge.y0, fmaxf(ge.y1, ge.y2));
-                if (box_lb(px, py, fx0, fy0, fx1, fy1) >= fminf(best, d)) continue;
-                const float t = tri_d2(px, py, ge);
-                d = (t < d) ? t : d;                                                  // a NaN distance never becomes the minimum
+                if (!(box_lb(px, py, fx0, fy0, fx1, fy1) >= best)) {
+                    const float t = tri_d2(px, py, ge);
+                    d = (t < inf) ? t : inf;                                          // a NaN distance never becomes the minimum
+                }
             }
             best = fminf(best, group_min(d));
         }

@@ -102,12 +102,11 @@ struct NearCand {
 };
 // ... and a bounding-volume hierarchy over the same faces for the points the lists do not serve (agents that strayed more than the margin
 // beyond the mesh): an ordered nearest-neighbour descent, pruned by the same conservative box bounds as every other walk of K2b, is the
-// exact minimum over all faces in a few dozen steps wherever the point lies (the walk over grid rings took 2.5 ms once random steps had
+// exact minimum over all faces in a dozen steps wherever the point lies (the walk over grid rings took 2.5 ms once random steps had
 // scattered the agents and 124 ms with every agent a thousand kilometres away).
-struct BvhNode {                // 48 bytes: the boxes of the two children and where they are
-    float lx0, ly0, lx1, ly1, rx0, ry0, rx1, ry1;
-    int32_t left, right;        // >= 0: an inner node; < 0: a leaf, -1 - (first << 4 | count): `count` (<= 8) faces from bvh_idx[first]
-    int32_t pad0, pad1;
+struct BvhNode {                // 160 bytes, eight children: a lane of the off-road kernels' groups of eight weighs one child each
+    float4 box[8];              // (x0, y0, x1, y1) of child k; an empty slot holds (+inf, +inf, -inf, -inf): infinitely far from every point
+    int32_t child[8];           // >= 0: an inner node; < 0: a leaf, -1 - (first << 4 | count): `count` (<= 8) faces from bvh_idx[first]
 };
 struct NearView {
     const NearCand *cand;       // null: no lists (maps with rendering data, empty maps)
