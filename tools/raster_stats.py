@@ -18,7 +18,8 @@ for i in range(5):
 buf = (ctypes.c_ulonglong * 16)()
 sim.render_egocentric(res=Resolution(RES, RES), fov=35.0); torch.cuda.synchronize()
 L.tds_raster_get_stats(buf)
-L.tds_raster_set_debug(128 | 8192)          # the counters are the fused kernel's: force it at every resolution
+SPLIT = len(sys.argv) > 3 and sys.argv[3] == 'split'   # 'split': whatever form the library chooses at this resolution (K3s + K3r below 144 / 208 pixels)
+L.tds_raster_set_debug(128 if SPLIT else 128 | 8192)          # default: the fused kernel at every resolution
 sim.render_egocentric(res=Resolution(RES, RES), fov=35.0); torch.cuda.synchronize()
 L.tds_raster_set_debug(0)
 L.tds_raster_get_stats(buf)

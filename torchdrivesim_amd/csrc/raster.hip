@@ -1753,7 +1753,8 @@ __device__ __forceinline__ void process_batch_bits(BitCtx &w, int n, bool flush)
     // ---- outline edges that are walked exactly ----
     // They go through a per-wave ring of EQCAP entries (two packed end points + plane index) that lives across batches: 64 of them are
     // taken at a time, so that the per-edge set-up and the row items below run on full waves.
-    if (!(TDS_DBG(w.debug) & 8)) {
+    // (ablations of the testing build: 8 = no edge classes and no walk -- every edge unmerged, nothing walked --, 256 = the classes stay, only the walk goes)
+    if (!(TDS_DBG(w.debug) & (8 | 256))) {
         TDS_STAT_LANES(w, 5, __popc(((unsigned)flags >> 13) & 7u));
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
