@@ -2548,6 +2548,8 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
 // the loop over the items costs 30 VGPRs -- 111 instead of 75 -- and with them a fifth of the waves: 64 x 64 2.8 -> 3.2 ms)
 // BWAVES: wavefronts per workgroup.  A 64 x 64 camera holds five chunks of faces per wave of four: too little to keep four waves in step
 // between the barriers of a workgroup (SQ_WAIT_ANY 40 % of the wave cycles) -- small images get fewer waves per workgroup and more workgroups.
+// (Round 5: registers cut for seven / eight waves per SIMD -- 72 / 64 VGPRs instead of 77 - 82, a few spills --: 64 x 64 2.25 -> 2.22 / 2.22 ms, 128 x 128 3.12 -> 3.07 / 3.38,
+//  uint8 192 x 192 4.12 -> 4.16 / 4.31: within the noise or worse, not taken.)
 template <int NB, typename OutT, int BWAVES>
 __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
                                                                       const uint4 *__restrict__ lists, const uint32_t *__restrict__ lists3, int caps) {
