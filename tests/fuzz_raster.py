@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large randomised parity run of the K3 scene rasteriser against the oracle (a script, not collected by pytest: minutes of CPU time).
-   python tests/fuzz_raster.py [--seeds 8] [--batch 8] [--agents 24] [--res 256] [--map town01|town02] [--u8]
+   python tests/fuzz_raster.py [--seeds 8] [--seed0 0] [--batch 8] [--agents 24] [--res 256] [--map town01|town02] [--u8]
    --res 0: a third family -- every seed draws its own resolution from 4 .. 60 (multiples of 4 or not: the one-pixel-per-thread
    write-out) and its own field of view from 5 .. 200 m."""
 import argparse, os, sys, time
@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--seeds', type=int, default=8); ap.add_argument('--batch', type=int, default=8); ap.add_argument('--agents', type=int, default=24)
 ap.add_argument('--res', type=int, default=256); ap.add_argument('--fov', type=float, default=35.0)
 ap.add_argument('--map', default='town01'); ap.add_argument('--u8', action='store_true')
+ap.add_argument('--seed0', type=int, default=0, help='first seed (a second run with other scenes)')
 a = ap.parse_args()
 t = np.load(os.path.join(ROOT, 'tests', 'golden', f'{a.map}_mesh.npz'))
 town = dict(verts=t['verts'], faces=t['faces'], vert_category=t['vert_category'], categories=[str(c) for c in t['categories']])
@@ -25,7 +26,7 @@ road = town['verts'][town['vert_category'] == town['categories'].index('road')]
 bad_total = n_img = 0
 t0 = time.time()
 for seed in range(a.seeds):
-    gen = np.random.default_rng(1000 + seed)
+    gen = np.random.default_rng(1000 + a.seed0 + seed)
     B, A = a.batch, a.agents
     anchor = road[gen.integers(0, len(road), (B, 1))]
     xy = anchor + gen.uniform(-25, 25, (B, A, 2))

@@ -7,6 +7,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/${1:-r05_fuzz_raster}.log
 SC=${2:-1}
+S0=${3:-0}          # first seed of every family (a second run with other scenes)
 : > $OUT
 for cfg in "--seeds $((200*SC)) --batch 8 --agents 64 --res 64 --fov 35" "--seeds $((100*SC)) --batch 8 --agents 64 --res 64 --fov 50 --u8 --map town02" \
            "--seeds $((100*SC)) --batch 8 --agents 64 --res 64 --fov 120" "--seeds $((60*SC)) --batch 8 --agents 64 --res 32 --fov 35 --u8" \
@@ -16,7 +17,7 @@ for cfg in "--seeds $((200*SC)) --batch 8 --agents 64 --res 64 --fov 35" "--seed
            "--seeds $((60*SC)) --batch 8 --agents 64 --res 256 --fov 35" "--seeds $((40*SC)) --batch 8 --agents 64 --res 104 --fov 35" "--seeds $((40*SC)) --batch 8 --agents 64 --res 120 --fov 50 --map town02" "--seeds $((40*SC)) --batch 8 --agents 64 --res 136 --fov 35" "--seeds $((40*SC)) --batch 8 --agents 64 --res 160 --fov 70 --u8" "--seeds $((30*SC)) --batch 8 --agents 64 --res 256 --fov 20 --u8" \
            "--seeds $((300*SC)) --batch 8 --agents 64 --res 0 --map town02" "--seeds $((150*SC)) --batch 8 --agents 64 --res 0 --map town02 --u8" "--seeds $((150*SC)) --batch 8 --agents 64 --res 0"; do
   echo "# tests/fuzz_raster.py $cfg" >> $OUT
-  python tests/fuzz_raster.py $cfg 2>&1 | tail -2 >> $OUT
+  python tests/fuzz_raster.py $cfg --seed0 $S0 2>&1 | tail -2 >> $OUT
 done
 python tests/fuzz_raster_modes.py --seeds 12 --batch 4 --agents 24 2>&1 | tail -3 >> $OUT
 cat $OUT
