@@ -52,16 +52,32 @@ def synth_agents(B, A, road_verts, seed):
     return state, size, present, actions
 
 
-def build_simulator(B, A, device, seed, metric='iou', lanelet_map=None):
+def load_town02():
+    t = np.load(os.path.join(ROOT, 'tests', 'golden', 'town02_mesh.npz'))
+    return t['verts'], t['faces'], t['vert_category'], [str(c) for c in t['categories']]
+
+
+def build_simulator(B, A, device, seed, metric='iou', lanelet_map=None, mixed=False):
+    """`mixed`: the batch is collated from Town01 and Town02 (mesh.py:232-245 of the reference: padded to the larger mesh), even scenes on
+    Town01, odd scenes on Town02, every scene's agents on its own town's roads."""
     from torchdrivesim_amd.kinematic import KinematicBicycle
     from torchdrivesim_amd.mesh import BirdviewMesh
     from torchdrivesim_amd.rendering import HipRendererConfig, renderer_from_config
     from torchdrivesim_amd.simulator import Simulator, TorchDriveConfig, CollisionMetric
     from torchdrivesim_amd.utils import Resolution
     verts, faces, vcat, cats = load_town01()
-    road = BirdviewMesh(verts=torch.from_numpy(verts)[None], faces=torch.from_numpy(faces.astype(np.int64))[None], categories=cats,
-                        colors={}, zs={}, vert_category=torch.from_numpy(vcat.astype(np.int64))[None]).expand(B).to(device)
-    state, size, present, actions = synth_agents(B, A, verts[vcat == cats.index('road')], seed)
+    town = lambda v, f, vc, c: BirdviewMesh(verts=torch.from_numpy(v)[None], faces=torch.from_numpy(f.astype(np.int64))[None], categories=c,
+                                            colors={}, zs={}, vert_category=torch.from_numpy(vc.astype(np.int64))[None])
+    if not mixed:
+        road = town(verts, faces, vcat, cats).expand(B).to(device)
+        state, size, present, actions = synth_agents(B, A, verts[vcat == cats.index('road')], seed)
+    else:
+        v2, f2, vc2, c2 = load_town02()
+        which = np.arange(B) % 2
+        road = BirdviewMesh.collate([town(verts, faces, vcat, cats), town(v2, f2, vc2, c2)]).to(device)[which.tolist()]       # B padded rows, a real (not expanded) batch
+        state, size, present, actions = synth_agents(B, A, verts[vcat == cats.index('road')], seed)
+        s2 = synth_agents(B, A, v2[vc2 == c2.index('road')], seed + 1)[0]
+        state[which == 1] = s2[which == 1]
     km = KinematicBicycle()
     km.set_params(lr=torch.full((B, A), 1.5, device=device))
     km.set_state(torch.from_numpy(state).to(device))
@@ -391,6 +407,98 @@ def low_res_mode(device, steps, warmup, B, A, res=128):
                 kernel='scan_faces_kernel + raster_list_bits_kernel (the split form of the bit-plane path)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
 
 
+def mixed_maps_mode(device, steps, warmup, B, A, overlap, headline_ms, ring):
+    """The headline loop on a batch collated from TWO towns (even scenes Town01, odd scenes Town02: the reference's collated, padded mesh batch,
+    mesh.py:232-245): one device map per DISTINCT mesh (two rendering maps, two off-road maps; `_ops.group_rows` finds them by content on the
+    device), served by the same launches through a map set.  Reports the set-up (grouping + map builds, until the first image exists) and the
+    step beside the single-map headline of this run.  `ring`: the headline's own two output buffers -- the same physical pages under both
+    measurements (what a write stream reaches depends on them), so that the difference is the maps'."""
+    from torchdrivesim_amd import _ops
+    from torchdrivesim_amd.utils import Resolution
+    res = Resolution(RES, RES)
+    _ops.map_cache.clear()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    sim, actions, _ = build_simulator(B, A, device, seed=4321, mixed=True)
+    torch.cuda.synchronize(device)
+    t_build = time.perf_counter() - t0
+    n0, t0 = _ops.map_creations, time.perf_counter()
+    sim._scene()
+    torch.cuda.synchronize(device)
+    t_render_maps = time.perf_counter() - t0
+    n1, t0 = _ops.map_creations, time.perf_counter()
+    sim.compute_offroad()
+    torch.cuda.synchronize(device)
+    t_off_maps = time.perf_counter() - t0
+    n2 = _ops.map_creations
+    # a batch operation afterwards: the handles come from the cache
+    t0 = time.perf_counter()
+    half = sim.select_batch_elements(list(range(0, B, 2)) + list(range(1, B, 4)), in_place=False)
+    half._scene()
+    torch.cuda.synchronize(device)
+    t_select = time.perf_counter() - t0
+    n3 = _ops.map_creations
+    del half
+    sink = {}
+    if overlap == 'reserved':
+        sim.overlap_infractions = 'reserved'
+        torch.cuda.synchronize(device)
+        torch.cuda.set_stream(sim.raster_stream())
+
+    def step(i):
+        sim.step(actions[i % actions.shape[0]])
+        sink['img'] = sim.render_egocentric(res=res, fov=FOV, out=ring[i % 2])
+        sink['col'] = sim.compute_collision()
+        sink['off'] = sim.compute_offroad()
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    _ops.raster_events = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    k = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events]))
+    _ops.raster_events = None
+    frac_lit = float((sink['img'][:8] != 0).float().mean())
+    torch.cuda.set_stream(torch.cuda.default_stream(device))
+    del sim
+    sink.clear()
+    return dict(what=f'the headline loop at B={B}xA={A}, {RES}x{RES} float32, on a batch collated from Town01 (even scenes) and Town02 (odd scenes), '
+                     'rendered into the headline\'s own two output buffers',
+                ms_per_step=1e3 * dt, agent_steps_per_s=B * A / dt, vs_single_map_headline=None if not headline_ms else 1e3 * dt / headline_ms,
+                dominant_kernel='raster_scene_bits_kernel', dominant_kernel_ms=k,
+                dominant_kernel_frac_of_hbm_peak=B * A * ALGO_BYTES_PER_IMAGE / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                map_creations=dict(rendering=n1 - n0, offroad=n2 - n1, after_select_batch_elements=n3 - n2),
+                setup_s=dict(build_simulator_incl_collate_and_upload=t_build, group_scenes_and_build_rendering_maps=t_render_maps,
+                             group_scenes_and_build_offroad_maps_incl_first_query=t_off_maps, select_batch_elements_and_regroup=t_select),
+                nonzero_pixel_share_first_scenes=frac_lit,
+                overlap=overlap)
+
+
+def device_identity(device, reserved_usable=None):
+    """Which physical GPU this rank ran on (a SCALE record must be able to show that N ranks sat on N distinct GPUs):
+    uuid and PCI address from the device properties, architecture, CU count, and whether the 'reserved' CU layout was usable there."""
+    if torch.device(device).type != 'cuda':
+        return dict(device=str(device), uuid=None, pci=None, arch=None, compute_units=None, reserved_usable=None, visible=os.environ.get('HIP_VISIBLE_DEVICES'))
+    p = torch.cuda.get_device_properties(device)
+    pci = None
+    if all(hasattr(p, k) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')):
+        pci = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}'
+    return dict(device=str(device), name=p.name, uuid=str(getattr(p, 'uuid', None)), pci=pci, arch=getattr(p, 'gcnArchName', None),
+                compute_units=p.multi_processor_count, total_memory_gb=round(p.total_memory / 2 ** 30, 1), reserved_usable=reserved_usable,
+                visible=os.environ.get('HIP_VISIBLE_DEVICES'))
+
+
+def distinct_devices(reports):
+    """number of distinct physical devices among the ranks' reports (by uuid, else PCI address; None when no rank could tell)"""
+    ids = [(r.get('device_identity') or {}).get('uuid') or (r.get('device_identity') or {}).get('pci') for r in reports]
+    ids = [i for i in ids if i and i != 'None']
+    return len(set(ids)) if ids else None
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -598,7 +706,10 @@ def main():
         raster_ms = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events])) if _ops.raster_events else None
         _ops.raster_events = None
     # every rank's own figures (a rank on slow memory would otherwise show only as a low rate): reporting only, over gloo
-    mine_report = dict(rank=rank, seconds=mine, agent_steps_per_s=B * A * args.steps / mine, avg_launch_ms=raster_ms,
+    reserved_ok = None
+    if not args.dry_run and args.overlap == 'reserved':
+        reserved_ok = bool(sim._reserved_usable(device))
+    mine_report = dict(rank=rank, seconds=mine, agent_steps_per_s=B * A * args.steps / mine, avg_launch_ms=raster_ms, device_identity=device_identity(device, reserved_ok),
                        ring_probe=None if args.dry_run else dict(launch_ms=ring_probe['launch_ms'], fill_ms=ring_probe['fill_ms'], fast=ring_probe['fast'],
                                                                 kept=ring_probe['kept'], aliased=ring_probe['aliased']))
     all_reports = parallel.gather_objects_over_ranks(mine_report)
@@ -631,6 +742,9 @@ def main():
                                               'stream confined to those 32 CUs, beside the launch (Simulator.overlap_infractions = \'reserved\'; --overlap off: behind it)',
                                   'stream': 'the metric kernels on a plain second stream', 'off': 'the metric kernels behind the raster launch on the same stream'}[args.overlap])
         line['overlap'] = args.overlap
+        line['distinct_devices'] = distinct_devices(all_reports)          # N ranks on N GPUs <=> distinct_devices == n_gpus
+        if world == 1:
+            line['device_identity'] = all_reports[0]['device_identity']
         if world > 1:
             line['per_rank_agent_steps_per_s'] = [B * A * args.steps / t for t in per_rank]
             line['per_rank'] = all_reports
@@ -640,6 +754,9 @@ def main():
             line['dry_run'] = True
             line['data'] = 'none (dry run: no kernels were launched, the value is meaningless)'
         if world == 1 and not args.dry_run:
+            if not args.no_configs:
+                line['mixed_maps'] = mixed_maps_mode(device, args.steps, args.warmup, B, A, args.overlap, line['ms_per_step'], bufs)
+                torch.cuda.set_stream(loop_stream)
             if not args.no_default_path:
                 # the reference-shaped call: no `out=`, a fresh image tensor per step (rendering/cv2.py:52 allocates per call); the previous
                 # image is still held when the next one is allocated, as a consumer would

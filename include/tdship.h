@@ -132,9 +132,13 @@ typedef struct tds_map tds_map_t;
 int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
                    int64_t F, const float *levels, int n_levels, float cell_size, tds_map_t **out);
 int tds_map_destroy(tds_map_t *map);
-/* info[0..9] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, number of nearest-face candidates,
- * entries of the rendering grid (lone faces + pairs, tds_common.h: QuadEntry), pairs of same-key faces that share an edge */
+/* info[0..7] = V, F, grid nx, grid ny, number of grid entries, device bytes held, n_levels, number of nearest-face candidates
+ * (EIGHT words, as in every release of this header but round 5's, which wrote ten through this symbol: see INTEGRATION.md, "ABI notes") */
 int tds_map_info(const tds_map_t *map, int64_t *info);
+/* the first `n_words` of: the eight words above, then [8] entries of the rendering grid (lone faces + pairs, tds_common.h: QuadEntry),
+ * [9] pairs of same-key faces that share an edge; words beyond TDS_MAP_INFO_WORDS read 0 */
+#define TDS_MAP_INFO_WORDS 10
+int tds_map_info_ex(const tds_map_t *map, int64_t *info, int n_words);
 /* the distinct face keys of the map (HOST array of `cap` entries; *n receives their number, -1 when there are more than 64): with the caller's
  * actor keys they decide which rasteriser serves a launch -- at most 15 keys in all: the bit-plane kernels -- and with it how much scratch
  * tds_raster_scene can use (tds_raster_scene_workspace_bytes_for) */
@@ -147,6 +151,18 @@ typedef struct tds_mapset tds_mapset_t;
 int tds_mapset_create(const tds_map_t *const *maps, int n, tds_mapset_t **out);
 int tds_mapset_destroy(tds_mapset_t *set);
 int tds_mapset_keys(const tds_mapset_t *set, uint32_t *keys, int cap, int *n);      /* tds_map_keys over the union of the set's maps */
+
+/* Which scenes of a collated batch share a mesh.  The reference pads every element of a collated mesh batch to the largest one
+ * (mesh.py:172-200 `pad`, :113-123 / :232-245 `collate`), so two scenes on the same map hold identical rows, byte for byte; it then carries
+ * B private copies through every batch operation (simulator.py:444-511).  These two let the host group the B rows of a DEVICE tensor by content
+ * without a copy to the host, so that it builds one tds_map_t per DISTINCT mesh:
+ *   tds_rows_hash_u64   out[r] = 64-bit content hash of row r (rows of `row_bytes` bytes -- a multiple of 4 -- `row_stride_bytes` apart);
+ *                       `seed` selects the hash function (two seeds: 128 bits);
+ *   tds_rows_equal_u8   equal[r] = 0 where row r differs from row rep[r] (the caller presets `equal` to 1): the exact confirmation of a
+ *                       grouping by hash.
+ * rows, out, rep, equal: device pointers. */
+int tds_rows_hash_u64(const void *rows, int64_t n_rows, int64_t row_bytes, int64_t row_stride_bytes, uint64_t seed, uint64_t *out, void *stream);
+int tds_rows_equal_u8(const void *rows, int64_t n_rows, int64_t row_bytes, int64_t row_stride_bytes, const int32_t *rep, uint8_t *equal, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K2b  offroad              simulator.py:1035-1044; infractions.py:86-229 (pure-torch path, squared distances)

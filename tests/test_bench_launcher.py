@@ -30,6 +30,11 @@ def check_line(line, n, steps, warmup):
     assert line['config']['global_batch'] == n * 1024 and line['config']['agents'] == 64
     assert f'x{n}' in line['config']['parallelism'] and 'no collectives' in line['config']['parallelism']
     assert line['value'] > 0 and line['dry_run'] is True
+    # which device every rank ran on is part of the record (none in a dry run: no rank can tell, distinct_devices is null)
+    assert 'distinct_devices' in line and line['distinct_devices'] is None
+    reports = line['per_rank'] if n > 1 else [dict(device_identity=line['device_identity'])]
+    for r in reports:
+        assert set(r['device_identity']) >= {'device', 'uuid', 'pci', 'arch', 'compute_units', 'reserved_usable', 'visible'}
 
 
 def test_self_launch_two_ranks_dry_run():
@@ -43,6 +48,16 @@ def test_device_list_is_narrowed_per_rank():
     # the launcher hands rank r the r-th entry of an inherited device list
     line = run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--dry-run', env=dict(HIP_VISIBLE_DEVICES='5,3,1'))
     check_line(line, 2, 1, 0)
+    assert [r['device_identity']['visible'] for r in line['per_rank']] == ['5', '3']
+
+
+def test_distinct_devices_counts_physical_gpus():
+    sys.path.insert(0, ROOT)
+    import bench
+    rep = lambda uuid, pci=None: dict(device_identity=dict(uuid=uuid, pci=pci))
+    assert bench.distinct_devices([rep('a'), rep('b'), rep('a')]) == 2
+    assert bench.distinct_devices([rep(None, '0000:05:00'), rep(None, '0000:05:00')]) == 1
+    assert bench.distinct_devices([rep(None), rep('None')]) is None
 
 
 def test_single_process_dry_run_and_torchrun_shape():

@@ -80,3 +80,8 @@ def test_eight_real_workers_on_one_gpu():
     for p in per_rank:
         assert p['avg_launch_ms'] > 0 and len(p['ring_probe']['kept']) == 2 and len(set(p['ring_probe']['kept'])) == 2 and not p['ring_probe']['aliased']
         assert len(p['ring_probe']['launch_ms']) >= 2 and p['ring_probe']['fill_ms'] > 0
+    # the record says which physical GPU every rank sat on -- here all eight on the one GPU of the box
+    ids = [p['device_identity'] for p in per_rank]
+    assert all(i['uuid'] not in (None, 'None') or i['pci'] for i in ids) and all(i['arch'].startswith('gfx950') and i['compute_units'] > 0 for i in ids)
+    assert len({(i['uuid'], i['pci']) for i in ids}) == 1 and line['distinct_devices'] == 1
+    assert all(i['reserved_usable'] in (True, False) for i in ids)

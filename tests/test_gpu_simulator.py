@@ -284,6 +284,117 @@ def test_scenes_with_different_maps(oracle):
         np.testing.assert_allclose(s1.grad[b:b + 1].cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def two_towns(order):
+    """Town01 and Town02 collated (mesh.py:232-245: padded to the larger one) and laid out as the batch `order` (0 = Town01, 1 = Town02) on the device"""
+    from torchdrivesim_amd.mesh import BirdviewMesh
+    towns = []
+    for name in ('town01_mesh.npz', 'town02_mesh.npz'):
+        t = load_golden(name)
+        towns.append(BirdviewMesh(verts=torch.from_numpy(t['verts'])[None], faces=torch.from_numpy(t['faces'].astype(np.int64))[None],
+                                  categories=[str(c) for c in t['categories']], colors={}, zs={},
+                                  vert_category=torch.from_numpy(t['vert_category'].astype(np.int64))[None]))
+    pair = BirdviewMesh.collate(towns)
+    return pair.to(DEV)[list(order)], pair
+
+
+def test_mixed_maps_batch_builds_one_map_per_distinct_mesh(oracle):
+    """B = 64 scenes collated from Town01 / Town02 in mixed order build exactly TWO rendering maps (and two geometry-only
+    maps for the off-road query) -- counted through _ops.map_creations, i.e. tds_map_create calls --, pixels and off-road losses equal the
+    oracle's for scenes of both towns, and copy / select_batch_elements / extend / shard_simulator create none."""
+    from torchdrivesim_amd import _ops, parallel
+    from torchdrivesim_amd.utils import Resolution
+    B, A, res, fov = 64, 6, 64, 35.0
+    gen = np.random.default_rng(21)
+    order = gen.integers(0, 2, B)
+    order[:4] = [1, 0, 0, 1]
+    road, pair = two_towns(order)
+    cats = pair.categories
+    state = np.zeros((B, A, 4), np.float32)
+    for b in range(B):
+        v = pair.verts[order[b]].numpy()[pair.vert_category[order[b]].numpy() == cats.index('road')]
+        v = v[np.abs(v).sum(1) > 0]                          # (padding rows)
+        state[b, :, :2] = v[gen.integers(0, len(v))] + gen.normal(0, 6.0, (A, 2))
+        state[b, :, 2] = gen.uniform(-np.pi, np.pi, A)
+    size = np.tile(np.array([4.5, 2.0], np.float32), (B, A, 1))
+    present = np.ones((B, A), bool)
+    _ops.map_cache.clear()
+    sim = make_sim(state, size, present, road)
+    n0 = _ops.map_creations
+    img = sim.render_egocentric(res=Resolution(res, res), fov=fov)
+    assert _ops.map_creations == n0 + 2, 'one rendering map per DISTINCT mesh'
+    smap = sim._scene()['maps'][0][0]
+    assert isinstance(smap, _ops.StaticMapSet) and len(smap.maps) == 2
+    np.testing.assert_array_equal(smap.scene_map.cpu().numpy(), order if order[0] == 0 else 1 - order)       # groups are numbered by first occurrence
+    off = sim.compute_offroad()
+    assert _ops.map_creations == n0 + 4, 'one geometry-only map per distinct mesh for the off-road query'
+    img, off = img.cpu().numpy(), off.cpu().numpy()
+    s = sim.get_state()
+    sc = torch.stack([torch.sin(s[..., 2]), torch.cos(s[..., 2])], -1).cpu().numpy()
+    for b in (0, 1, 2, 3, B - 1):
+        m = pair[[int(order[b])]]
+        v, f, vc = m.verts[0].numpy(), m.faces[0].numpy().astype(np.int32), m.vert_category[0].numpy()
+        sv, sa, sf = oracle.static_mesh_arrays(v, f, vc, cats)
+        ref = oracle.render_scenes(state[b:b + 1], size[b:b + 1], np.ones((1, A, A), bool), state[b:b + 1, :, :2].copy(), sc[b:b + 1], sv, sa, sf, fov, res,
+                                   agent_sc=sc[b:b + 1])
+        np.testing.assert_array_equal(img[b:b + 1], ref)
+        assert ref.std() > 0
+        ref_off = oracle.offroad(state[b:b + 1], size[b:b + 1], v, f, threshold=0.5, present=np.ones((1, A), bool), sc=sc[b:b + 1])
+        np.testing.assert_allclose(off[b:b + 1], ref_off, rtol=1e-5, atol=1e-6)
+    # batch operations find the handles in the cache
+    n1 = _ops.map_creations
+    idx = [5, 1, 2, 40, 41, 0]
+    sub = sim.select_batch_elements(idx, in_place=False)
+    np.testing.assert_array_equal(sub.render_egocentric(res=Resolution(res, res), fov=fov).cpu().numpy(), img[idx])
+    np.testing.assert_array_equal(sub.compute_offroad().cpu().numpy(), off[idx])
+    only1 = sim.select_batch_elements([b for b in range(B) if order[b] == 1][:3], in_place=False)          # a sub-batch on ONE town: a plain map, from the cache
+    sub_img = only1.render_egocentric(res=Resolution(res, res), fov=fov).cpu().numpy()
+    np.testing.assert_array_equal(sub_img, img[[b for b in range(B) if order[b] == 1][:3]])
+    twice = sub.extend(2, in_place=False)
+    np.testing.assert_array_equal(twice.render_egocentric(res=Resolution(res, res), fov=fov).cpu().numpy(), np.repeat(img[idx], 2, axis=0))
+    cp = sim.copy()
+    np.testing.assert_array_equal(cp.render_egocentric(res=Resolution(res, res), fov=fov).cpu().numpy(), img)
+    shard = parallel.shard_simulator(sim, 1, 2)
+    np.testing.assert_array_equal(shard.render_egocentric(res=Resolution(res, res), fov=fov).cpu().numpy(), img[B // 2:])
+    np.testing.assert_array_equal(shard.compute_offroad().cpu().numpy(), off[B // 2:])
+    assert _ops.map_creations == n1, 'batch operations must reuse the device maps'
+
+
+def test_group_rows_confirms_hash_groups_exactly():
+    """_ops.group_rows: groups numbered by first occurrence, expanded batches are one group, one differing word splits a group"""
+    from torchdrivesim_amd import _ops
+    g = torch.Generator().manual_seed(3)
+    rows = torch.randn(3, 1000, 3, generator=g)
+    order = [2, 0, 2, 1, 0, 2]
+    a = rows[order].to(DEV)
+    faces = torch.randint(0, 1000, (3, 777, 3), generator=g)[order].to(DEV)
+    sm, reps, hashes = _ops.group_rows([a, faces])
+    assert sm.tolist() == [0, 1, 0, 2, 1, 0] and reps == [0, 1, 3] and len(set(hashes)) == 3
+    b = a.clone()
+    b[5, 999, 2] += 1.0                                       # the last word of the last row
+    sm, reps, _ = _ops.group_rows([b, faces])
+    assert sm.tolist() == [0, 1, 0, 2, 1, 3] and reps == [0, 1, 3, 5]
+    c = a.clone()
+    c[2, 0, 0], c[2, 0, 1] = a[2, 0, 1].clone(), a[2, 0, 0].clone()   # two words swapped: the hash depends on the position
+    assert _ops.group_rows([c, faces])[0].tolist() == [0, 1, 2, 3, 1, 0]
+    sm, reps, _ = _ops.group_rows([a[:1].expand(5, -1, -1), faces[:1].expand(5, -1, -1)])
+    assert sm.tolist() == [0] * 5 and reps == [0]
+    # rows that only differ in a tensor that is not expanded
+    sm, _, _ = _ops.group_rows([a[:1].expand(6, -1, -1), faces])
+    assert sm.tolist() == [0, 1, 0, 2, 1, 0]
+    # the exact confirmation: identical hashes forced by hashing a constant column, different bytes elsewhere -> (collision path) every row its own group
+    saved = _ops.row_hashes
+    try:
+        _ops.row_hashes = lambda tensors: torch.zeros(tensors[0].shape[0], 2, dtype=torch.int64, device=tensors[0].device)
+        sm, reps, _ = _ops.group_rows([a])
+        assert sm.tolist() == [0, 1, 0, 2, 3, 0] and reps == [0, 1, 3, 4]
+        for i in range(6):
+            for j in range(6):
+                if sm[i] == sm[j]:
+                    assert order[i] == order[j]
+    finally:
+        _ops.row_hashes = saved
+
+
 def test_waypoint_goals_are_drawn_by_the_fused_path(oracle):
     """render_egocentric with waypoint goals (simulator.py:1013-1029 -> mesh.py:1120-1145): the fused path draws the discs as per-camera
     triangles; same pixels as the reference's dataflow (explicit mesh from generate(), render_frame) and as the oracle fed with that mesh,

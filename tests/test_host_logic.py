@@ -268,7 +268,7 @@ def test_scene_cache_is_keyed_on_its_sources():
     tensors it is derived from, not on the addresses of torch.cat temporaries."""
     sim = make_sim(2, 3, npc=2)
     built = []
-    sim.renderer.make_static_map = lambda *a, **k: built.append(1) or type('M', (), dict(rank_of=lambda self, z: 1))()
+    sim.renderer.scene_maps = lambda *a, **k: built.append(1) or type('M', (), dict(rank_of=lambda self, z: 1))()
     sim._scene(); sim._scene(); sim._scene()
     assert len(built) == 1                                              # NPC scenes: cat temporaries differ per call, the cache still holds
     sim.npc_controller.npc_size = sim.npc_controller.npc_size.clone()   # replaced NPC sizes: rebuilt

@@ -52,6 +52,9 @@ _SIGNATURES = {
     'tds_map_create': [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _f32, ctypes.POINTER(_vp)],
     'tds_map_destroy': [_vp],
     'tds_map_info': [_vp, ctypes.POINTER(_i64)],
+    'tds_map_info_ex': [_vp, ctypes.POINTER(_i64), _i32],
+    'tds_rows_hash_u64': [_vp, _i64, _i64, _i64, ctypes.c_uint64, _vp, _vp],
+    'tds_rows_equal_u8': [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
     'tds_mapset_create': [ctypes.POINTER(_vp), _i32, ctypes.POINTER(_vp)],
     'tds_mapset_destroy': [_vp],
     'tds_offroad_multi_f32': [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],

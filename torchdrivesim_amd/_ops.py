@@ -345,6 +345,8 @@ class StaticMap:
         fc = None if face_rgb is None else np.ascontiguousarray(np.asarray(face_rgb), dtype=np.uint32)
         lv = None if levels is None else np.ascontiguousarray(np.asarray(levels), dtype=np.float32)
         handle = ctypes.c_void_p()
+        global map_creations
+        map_creations += 1
         nat.call('tds_map_create', self.device, vp(verts), vp(faces), vp(fz), vp(fc), verts.shape[0], faces.shape[0], vp(lv),
                  0 if lv is None else len(lv), float(cell_size), ctypes.byref(handle))
         self._h = handle
@@ -365,7 +367,7 @@ class StaticMap:
 
     def info(self):
         buf = (ctypes.c_int64 * 10)()
-        nat.call('tds_map_info', self.device, self.handle, buf)
+        nat.call('tds_map_info_ex', self.device, self.handle, buf, 10)
         return dict(V=buf[0], F=buf[1], nx=buf[2], ny=buf[3], entries=buf[4], bytes=buf[5], n_levels=buf[6], near_candidates=buf[7],
                     render_entries=buf[8], pairs=buf[9])
 
@@ -373,16 +375,144 @@ class StaticMap:
         """1-based painter rank of a rendering level (larger = drawn later = on top)"""
         return self.levels.index(float(level)) + 1
 
-    def close(self):
+    def _destroy(self):
         if getattr(self, '_h', None) is not None:
             h, self._h = self._h, None
             nat.call('tds_map_destroy', self.device, h)
 
+    def close(self):
+        """destroy the device map now -- unless the process-wide cache handed it out (`shared`): other simulators may hold it, and it is
+        destroyed when the last holder drops it"""
+        if not getattr(self, 'shared', False):
+            self._destroy()
+
     def __del__(self):
         try:
-            self.close()
+            self._destroy()
         except Exception:
             pass
+
+
+#: how many tds_map_create calls this process has made (tests count them: one per DISTINCT mesh, none for a batch operation)
+map_creations = 0
+
+_ROW_SEEDS = (0x9e3779b97f4a7c15, 0xc2b2ae3d27d4eb4f)
+
+
+def _rows_view(t):
+    """(tensor to read, number of rows, bytes per row, bytes between rows) for the row kernels: whole 4-byte words, dense inside a row;
+    a batch that is ONE row expanded (stride 0) is one row."""
+    if t.dim() == 0:
+        raise RuntimeError('group_rows needs tensors with a leading batch axis')
+    if t.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16, torch.float16, torch.bfloat16):
+        t = t.to(torch.int32)
+    n = t.shape[0]
+    if n > 1 and t.stride(0) == 0:
+        t, n = t[:1], 1
+    if t.numel() and not t[0].is_contiguous():
+        t = t.contiguous()
+    row_bytes = (t[0].numel() if n else 0) * t.element_size()
+    stride = t.stride(0) * t.element_size() if n > 1 else row_bytes
+    return t, n, row_bytes, stride
+
+
+def row_hashes(tensors):
+    """(B, 2 * len(tensors)) int64 device tensor: two 64-bit content hashes of every batch row of every tensor (tds_rows_hash_u64).  A batch
+    that is one row expanded is hashed once and the hash repeated."""
+    B = tensors[0].shape[0]
+    dev = tensors[0].device
+    cols = []
+    for t in tensors:
+        if t.shape[0] != B:
+            raise RuntimeError('row_hashes: the tensors do not share the batch axis')
+        v, n, row_bytes, stride = _rows_view(t.detach())
+        for seed in _ROW_SEEDS:
+            h = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+            if n:
+                nat.call('tds_rows_hash_u64', dev, ctypes.c_void_p(v.data_ptr()), n, row_bytes, stride, ctypes.c_uint64(seed), ctypes.c_void_p(h.data_ptr()),
+                         nat.stream_ptr(dev))
+            cols.append(h[:n].expand(B) if n != B else h)
+    return torch.stack(cols, dim=1) if cols else torch.zeros(B, 0, dtype=torch.int64, device=dev)
+
+
+def group_rows(tensors):
+    """Which batch elements of the (device) tensors are identical in ALL of them -- the scenes of a collated batch that share a mesh
+    (mesh.py:172-200: padded rows of the same map are identical byte for byte).  Returns (scene_map, reps, hashes):
+        scene_map  (B,) numpy int32, group of every batch element, groups numbered by first occurrence;
+        reps       list, the first batch element of every group;
+        hashes     list of tuples, the content hashes of every group's rows (keys of the process-wide map cache).
+    Grouping is by hash on the device, then CONFIRMED exactly (tds_rows_equal_u8 against the group's representative); a row that shares a
+    hash but not the bytes becomes a group of its own.  One small device -> host copy (B hashes); the meshes stay on the device."""
+    B = tensors[0].shape[0]
+    if B == 0:
+        return np.zeros(0, np.int32), [], []
+    dev = tensors[0].device
+    h = row_hashes(tensors).cpu().numpy()                                         # B x 2T
+    index, reps, scene_map = {}, [], np.empty(B, np.int32)
+    for b in range(B):
+        key = h[b].tobytes()
+        g = index.get(key)
+        if g is None:
+            g = index[key] = len(reps)
+            reps.append(b)
+        scene_map[b] = g
+    if len(reps) < B:
+        rep = torch.from_numpy(np.asarray(reps, np.int32)[scene_map]).to(dev)
+        equal = torch.ones(B, dtype=u8, device=dev)
+        for t in tensors:
+            v, n, row_bytes, stride = _rows_view(t.detach())
+            if n == B:
+                nat.call('tds_rows_equal_u8', dev, ctypes.c_void_p(v.data_ptr()), n, row_bytes, stride, nat.dev_ptr(rep, i32, 'rep'), nat.dev_ptr(equal, u8, 'equal'),
+                         nat.stream_ptr(dev))
+        bad = np.nonzero(equal.cpu().numpy() == 0)[0]
+        for b in bad:                                                            # a hash collision: the row gets a map of its own
+            scene_map[b] = len(reps)
+            reps.append(int(b))
+    hashes = [tuple(int(x) for x in h[r]) for r in reps]
+    return scene_map, reps, hashes
+
+
+class MapCache:
+    """Process-wide cache of device maps by CONTENT: (device, what the map was built for, content hashes of the mesh rows, parameters) ->
+    StaticMap, with the rows it was built from kept beside it (device clones, about a megabyte per map) so that a hit is confirmed byte for
+    byte.  Maps are immutable, so simulators, their copies, sub-batches (`select_batch_elements`), extensions and shards share handles
+    instead of running tds_map_create again (the reference carries B private mesh copies through these operations, simulator.py:444-511).
+    Least recently used entries are dropped beyond `capacity` maps (TDS_MAP_CACHE, default 64); a dropped map lives on while a simulator
+    holds it."""
+
+    def __init__(self, capacity=None):
+        import os
+        self.capacity = int(os.environ.get('TDS_MAP_CACHE', 64)) if capacity is None else capacity
+        self._d = collections.OrderedDict()
+        self._lock = threading.Lock()
+        self.hits = self.misses = 0
+
+    def get(self, key, rows, build):
+        """the cached map of `key` if its stored rows equal `rows` (list of device tensors), else build() -> StaticMap, stored"""
+        with self._lock:
+            ent = self._d.get(key)
+            if ent is not None:
+                smap, kept = ent
+                if smap._h is not None and len(kept) == len(rows) and all(a.shape == b.shape and a.dtype == b.dtype and bool(torch.equal(a, b)) for a, b in zip(kept, rows)):
+                    self._d.move_to_end(key)
+                    self.hits += 1
+                    return smap
+            self.misses += 1
+            smap = build()
+            smap.shared = True
+            self._d[key] = (smap, [r.detach().clone() for r in rows])
+            self._d.move_to_end(key)
+            while len(self._d) > max(self.capacity, 0):
+                self._d.popitem(last=False)
+            return smap
+
+    def clear(self):
+        with self._lock:
+            self._d.clear()
+
+
+map_cache = MapCache()
+atexit.register(map_cache.clear)
 
 
 class StaticMapSet:

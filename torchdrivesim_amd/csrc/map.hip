@@ -580,11 +580,83 @@ TDS_EXPORT int tds_map_keys(const tds_map_t *map, uint32_t *keys, int cap, int *
     return TDS_OK;
 }
 
-TDS_EXPORT int tds_map_info(const tds_map_t *map, int64_t *info) {
-    TDS_CHECK_ARG(map && info, "tds_map_info: null pointer");
-    info[0] = map->V; info[1] = map->F; info[2] = map->view.nx; info[3] = map->view.ny;
-    info[4] = map->n_entries; info[5] = map->bytes; info[6] = map->n_levels; info[7] = map->n_cand;
-    info[8] = map->n_qentries; info[9] = map->n_pairs;
+TDS_EXPORT int tds_map_info_ex(const tds_map_t *map, int64_t *info, int n_words) {
+    TDS_CHECK_ARG(map && info && n_words >= 0, "tds_map_info_ex: bad arguments");
+    const int64_t all[TDS_MAP_INFO_WORDS] = {map->V, map->F, map->view.nx, map->view.ny, map->n_entries, map->bytes, map->n_levels, map->n_cand,
+                                             map->n_qentries, map->n_pairs};
+    for (int i = 0; i < n_words; ++i) info[i] = i < TDS_MAP_INFO_WORDS ? all[i] : 0;
+    return TDS_OK;
+}
+
+// eight words, as every caller built against the first header expects (round 5 wrote ten through the same symbol: ADVICE r5)
+TDS_EXPORT int tds_map_info(const tds_map_t *map, int64_t *info) { return tds_map_info_ex(map, info, 8); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Which scenes of a collated batch share a mesh (mesh.py:172-200 pads every element of a collated batch to the largest one, so the rows
+// of two scenes on the same map are identical byte for byte): a 64-bit content hash per batch row and an exact row comparison, so that
+// the host builds ONE device map per distinct mesh instead of one per scene.  Both read every row once, at the rate of the HBM stream.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int ROW_CHUNK_WORDS = 8192;          // 4-byte words of a row per workgroup
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {          // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+// out[row] += sum over the row's words of mix64(word, position): a sum, so the order in which workgroups arrive does not matter
+__global__ void __launch_bounds__(256) rows_hash_kernel(const uint32_t *__restrict__ rows, int64_t row_words, int64_t stride_words, uint64_t seed,
+                                                       unsigned long long *__restrict__ out) {
+    const int64_t row = blockIdx.y;
+    const uint32_t *p = rows + row * stride_words;
+    const int64_t w0 = (int64_t)blockIdx.x * ROW_CHUNK_WORDS, w1 = min(w0 + ROW_CHUNK_WORDS, row_words);
+    uint64_t h = 0;
+    for (int64_t i = w0 + threadIdx.x; i < w1; i += 256) h += mix64(((uint64_t)p[i] | ((uint64_t)(uint32_t)i << 32)) + seed + (uint64_t)(i >> 32));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor((unsigned long long)h, d);
+    if ((threadIdx.x & 63) == 0 && h != 0) atomicAdd(out + row, (unsigned long long)h);
+}
+// equal[row] = 0 where row differs from row rep[row] (the caller presets 1)
+__global__ void __launch_bounds__(256) rows_equal_kernel(const uint32_t *__restrict__ rows, int64_t row_words, int64_t stride_words, int64_t row0,
+                                                        const int32_t *__restrict__ rep, uint8_t *__restrict__ equal) {
+    const int64_t row = row0 + blockIdx.y, other = rep[row];
+    if (other == row) return;
+    const uint32_t *p = rows + row * stride_words, *q = rows + other * stride_words;
+    const int64_t w0 = (int64_t)blockIdx.x * ROW_CHUNK_WORDS, w1 = min(w0 + ROW_CHUNK_WORDS, row_words);
+    bool diff = false;
+    for (int64_t i = w0 + threadIdx.x; i < w1; i += 256) diff = diff || (p[i] != q[i]);
+    if (diff) equal[row] = 0;
+}
+}  // namespace
+
+TDS_EXPORT int tds_rows_hash_u64(const void *rows, int64_t n_rows, int64_t row_bytes, int64_t row_stride_bytes, uint64_t seed, uint64_t *out, void *stream) {
+    TDS_CHECK_ARG(n_rows >= 0 && n_rows < 65536 * 16 && row_bytes >= 0 && (row_bytes & 3) == 0 && (row_stride_bytes & 3) == 0 && row_stride_bytes >= 0,
+                  "tds_rows_hash_u64: rows are whole 4-byte words, at most 2^20 of them");
+    TDS_CHECK_ARG(n_rows == 0 || (out && (rows || row_bytes == 0)), "tds_rows_hash_u64: null pointer");
+    TDS_CHECK_ARG(((uintptr_t)rows & 3) == 0 && ((uintptr_t)out & 7) == 0, "tds_rows_hash_u64: misaligned pointer");
+    if (n_rows == 0) return TDS_OK;
+    if (tds::zero_async(out, (size_t)n_rows * 8, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_rows_hash_u64: clearing the output failed"); return TDS_EHIP; }
+    if (row_bytes == 0) return TDS_OK;
+    const int64_t words = row_bytes / 4, chunks = (words + ROW_CHUNK_WORDS - 1) / ROW_CHUNK_WORDS;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {                              // gridDim.y <= 65535
+        const int64_t nr = std::min<int64_t>(65535, n_rows - r0);
+        hipLaunchKernelGGL(rows_hash_kernel, dim3((unsigned)chunks, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)rows + r0 * (row_stride_bytes / 4), words, row_stride_bytes / 4, seed, (unsigned long long *)out + r0);
+    }
+    TDS_LAUNCH_CHECK("rows_hash_kernel");
+    return TDS_OK;
+}
+
+TDS_EXPORT int tds_rows_equal_u8(const void *rows, int64_t n_rows, int64_t row_bytes, int64_t row_stride_bytes, const int32_t *rep, uint8_t *equal, void *stream) {
+    TDS_CHECK_ARG(n_rows >= 0 && n_rows < 65536 * 16 && row_bytes >= 0 && (row_bytes & 3) == 0 && (row_stride_bytes & 3) == 0 && row_stride_bytes >= 0,
+                  "tds_rows_equal_u8: rows are whole 4-byte words, at most 2^20 of them");
+    TDS_CHECK_ARG(n_rows == 0 || (rep && equal && (rows || row_bytes == 0)), "tds_rows_equal_u8: null pointer");
+    TDS_CHECK_ARG(((uintptr_t)rows & 3) == 0, "tds_rows_equal_u8: misaligned pointer");
+    if (n_rows == 0 || row_bytes == 0) return TDS_OK;
+    const int64_t words = row_bytes / 4, chunks = (words + ROW_CHUNK_WORDS - 1) / ROW_CHUNK_WORDS;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535)                                // gridDim.y <= 65535
+        hipLaunchKernelGGL(rows_equal_kernel, dim3((unsigned)chunks, (unsigned)std::min<int64_t>(65535, n_rows - r0)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)rows, words, row_stride_bytes / 4, r0, rep, equal);
+    TDS_LAUNCH_CHECK("rows_equal_kernel");
     return TDS_OK;
 }
 

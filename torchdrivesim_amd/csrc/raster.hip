@@ -2480,8 +2480,12 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
     // the list of this camera: poly records (scan_step_poly) -- flags | plane index, P0, P1, P2 in `lists`, P3 in `lists3`
     uint4 *mine = lists + (size_t)img * caps;
     uint32_t *mine3 = lists3 + (size_t)img * caps;
+    // (actors and the masked-agent dot run as in the kernel without per-camera triangles -- the SceneArgs steps, whatever SA is -- and the
+    // per-camera triangles get a loop of their own below: as a fourth phase of the producer's state machine they cost this kernel 400
+    // instead of 112 bytes of scratch per lane)
+    const SceneArgs &ab = a;
     ScanState st;
-    scan_init<SA, true>(st, a, c, cam, img, lane, 0, 0, res);
+    scan_init<SceneArgs, true>(st, ab, c, cam, img, lane, 0, 0, res);
     int count = 0;
     bool poison = false;
     auto emit = [&](bool acc, uint32_t key, uint32_t pf, const uint32_t (&P)[4], bool big) {
@@ -2494,13 +2498,32 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
             count += __popcll(bm);
         }
     };
-    // actors, the masked-agent dot, per-camera triangles: the producer steps of the fused kernel, up to the static map
+    // actors, the masked-agent dot: the producer steps of the fused kernel, up to the static map
     while (st.phase != 2) {
         bool acc, big;
         uint32_t key, pf, P[4] = {0, 0, 0, 0};
         int px[4], py[4];
-        (void)scan_step_poly<1, SA>(st, a, c, cam, img, lane, 0, 0, res, acc, key, P, pf, big, px, py);
+        (void)scan_step_poly<1, SceneArgs>(st, ab, c, cam, img, lane, 0, 0, res, acc, key, P, pf, big, px, py);
         emit(acc, key, pf, P, big);
+    }
+    // per-camera triangles, already in world coordinates (scan_step_poly, phase 3): one lane each, lone triangles
+    if constexpr (has_extras<SA>::value) {
+        for (int t0 = 0; t0 < a.K; t0 += 64) {
+            bool acc = false, big = false;
+            uint32_t key = 0, pf = 0, P[4] = {0, 0, 0, 0};
+            int px[4], py[4];
+            const int t = t0 + lane;
+            if (t < a.K) {
+                key = a.extra_key[img * a.K + t];
+                if (key != 0u) {
+                    const float2 *v = (const float2 *)a.extra_tri + (img * a.K + t) * 3;
+                    const float2 va = v[0], vb = v[1], vc = v[2];
+                    const float fx[4] = {va.x + (-cam.cx), vb.x + (-cam.cx), vc.x + (-cam.cx), vc.x + (-cam.cx)}, fy[4] = {va.y + (-cam.cy), vb.y + (-cam.cy), vc.y + (-cam.cy), vc.y + (-cam.cy)};
+                    acc = trim_project_poly(cam, c.scale, res, 0, res, fx, fy, 0u, P, pf, big, px, py, c.no_trim);
+                }
+            }
+            emit(acc, key, pf, P, big);
+        }
     }
     // The static map.  With nothing to rasterise between two chunks of entries the walk would wait for every load (1.2 us each):
     // the entries are taken SCAN_DEPTH chunks at a time, all their loads in flight together.

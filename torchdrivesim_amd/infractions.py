@@ -41,20 +41,24 @@ OFFROAD_CELL_SIZE = float(os.environ.get('TDS_OFFROAD_CELL', 3.0))
 
 
 def _static_maps_for(mesh: BaseMesh, device) -> List:
-    """One device map per DISTINCT batch element of the mesh, cached on the mesh object: [(StaticMap, scene indices)]."""
+    """The geometry-only device map(s) of a batch of meshes -- ONE per distinct batch element (`_ops.group_rows`), taken from the process-wide
+    content cache or built once -- remembered on the mesh object: [(StaticMap or StaticMapSet, None)]."""
     key = (mesh.verts.data_ptr(), mesh.faces.data_ptr(), tuple(mesh.verts.shape), tuple(mesh.faces.shape), str(device))
     cache = getattr(mesh, '_tds_offroad_maps', None)
     if cache is not None and cache[0] == key:
         return cache[1]
-    verts, faces = mesh.verts[..., :2].detach(), mesh.faces.detach()
-    B = mesh.batch_size
-    same = B == 1 or (verts.stride(0) == 0 and faces.stride(0) == 0) or \
-        (bool((verts == verts[:1]).all()) and bool((faces == faces[:1]).all()))
-    if same:
-        maps = [(_ops.StaticMap(verts[0], faces[0], device=device, cell_size=OFFROAD_CELL_SIZE), None)]
+    dev = torch.device(device)
+    tensors = [t.detach() if t.is_cuda else t.detach().to(dev) for t in (mesh.verts, mesh.faces)]
+    scene_map, reps, hashes = _ops.group_rows(tensors)
+    per_group = []
+    for r, h in zip(reps, hashes):
+        rows = [t[r] for t in tensors]
+        ckey = ('offroad', str(dev), h, tuple(tuple(x.shape) for x in rows), OFFROAD_CELL_SIZE)
+        per_group.append(_ops.map_cache.get(ckey, rows, lambda rows=rows: _ops.StaticMap(rows[0][..., :2], rows[1], device=dev, cell_size=OFFROAD_CELL_SIZE)))
+    if len(per_group) == 1:
+        maps = [(per_group[0], None)]
     else:
-        per_scene = [_ops.StaticMap(verts[b], faces[b], device=device, cell_size=OFFROAD_CELL_SIZE) for b in range(B)]
-        maps = [(_ops.StaticMapSet(per_scene, torch.arange(B, dtype=torch.int32)), None)]           # one launch for the batch
+        maps = [(_ops.StaticMapSet(per_group, torch.from_numpy(scene_map)), None)]           # one launch for the batch
     try:
         object.__setattr__(mesh, '_tds_offroad_maps', (key, maps))
     except Exception:

@@ -85,6 +85,27 @@ class HipRenderer(BirdviewRenderer):
         return _ops.StaticMap(verts[:, :2], faces, face_z, face_rgb, levels, device=device or rgb_mesh.device,
                               cell_size=min(max(0.65 * fov, 8.0), 32.0))
 
+    def scene_maps(self, rgb_mesh: RGBMesh, actor_levels=(), device=None):
+        """The device map(s) of a BATCH of static meshes: ONE per distinct batch element (`_ops.group_rows`: the scenes of a collated batch
+        that share a map hold identical padded rows, mesh.py:172-200), each taken from the process-wide content cache (`_ops.map_cache`) or
+        built once.  Returns a StaticMap when the whole batch shares one mesh, else a StaticMapSet whose `scene_map` says which map scene b
+        uses; all maps of a set carry the same level table (the actors' levels + every z of the batch)."""
+        dev = torch.device(device or rgb_mesh.device)
+        tensors = [t if t.is_cuda else t.to(dev) for t in (rgb_mesh.verts, rgb_mesh.faces, rgb_mesh.attrs)]
+        scene_map, reps, hashes = _ops.group_rows(tensors)
+        # the level table of every map: the actors' levels + every z of the batch's meshes.  (For a single mesh its own levels are in its
+        # table anyway; listing them keeps the cache key of a sub-batch on ONE of the towns equal to the key the mixed batch built it under.)
+        extra = [float(z) for z in actor_levels] + [float(z) for z in torch.unique(torch.cat([tensors[0][r, :, 2] for r in reps])).tolist()]
+        extra_key = tuple(sorted(set(extra)))
+        maps = []
+        for r, h in zip(reps, hashes):
+            rows = [t[r] for t in tensors]
+            key = ('render', str(dev), h, tuple(tuple(x.shape) for x in rows), extra_key, float(self.scale))
+            maps.append(_ops.map_cache.get(key, rows, lambda r=r: self.make_static_map(rgb_mesh[r:r + 1], extra, device=dev)))
+        if len(maps) == 1:
+            return maps[0]
+        return _ops.StaticMapSet(maps, torch.from_numpy(scene_map))
+
     def render_scene(self, static_map: _ops.StaticMap, state: Tensor, agent_sc: Tensor, tmpl: Tensor, actor_key: Tensor, mask: Tensor,
                      camera_xy: Tensor, camera_sc: Tensor, res: Optional[Resolution] = None, fov: Optional[float] = None,
                      key_table=None, differentiable: bool = False, extra_tri: Optional[Tensor] = None,

@@ -758,16 +758,9 @@ class Simulator:
         for kind in ctrl_kinds:
             cats = [f'{kind}_{st}' for st in controls[kind].allowed_states] if kind == 'traffic_light' else [kind]
             actor_levels += [float(lv[c]) for c in cats]
-        same = B == 1 or (bg.verts.stride(0) == 0 and bg.faces.stride(0) == 0) or \
-            (bool((bg.verts == bg.verts[:1]).all()) and bool((bg.faces == bg.faces[:1]).all()) and bool((bg.attrs == bg.attrs[:1]).all()))
-        if same:
-            maps = [(self.renderer.make_static_map(bg[0:1], actor_levels, device=dev), None)]
-        else:
-            # scenes with different meshes: one device map per scene, all with the same level table (the union over the batch), served
-            # by ONE launch through a map set
-            all_levels = actor_levels + [float(z) for z in torch.unique(bg.verts[..., 2]).tolist()]
-            per_scene = [self.renderer.make_static_map(bg[b:b + 1], all_levels, device=dev) for b in range(B)]
-            maps = [(_ops.StaticMapSet(per_scene, torch.arange(B, dtype=torch.int32)), None)]
+        # one device map per DISTINCT mesh of the batch (a collated batch of 512 x Town01 + 512 x Town02 builds two), shared through the
+        # process-wide content cache: `copy`, `select_batch_elements`, `extend`, `to` and `shard_simulator` end up here again and find the handles
+        maps = [(self.renderer.scene_maps(bg, actor_levels, device=dev), None)]
         tmpl = actor_template(sizes.detach()).contiguous()          # B x N x 7 x 2 (a render that differentiates the sizes builds its own)
         keys, key_tables, wp_keys = [], [], []
         for smap, _ in maps:
