@@ -304,3 +304,30 @@ def test_reserved_cu_layout_is_judged_from_where_the_streams_really_ran():
     # CUs that neither stream reaches
     ok, why = _ops.check_reserved_layout(raster[:-8], metric, 4, 256)
     assert not ok and 'cover' in why
+
+
+def test_reserved_probe_never_raises(monkeypatch):
+    """reserved_layout_ok / Simulator._reserved_usable promise "never raises, falls back with ONE warning" -- also when creating or
+    probing the CU-masked streams fails (here: no GPU at all, then a failing tds_stream_create), and a verdict taken under stream capture
+    ('not verified') is not kept for good."""
+    from torchdrivesim_amd import _ops
+    monkeypatch.setattr(_ops, '_reserved_streams', {})
+    ok, why = _ops.reserved_layout_ok(torch.device('cuda', 0))          # this container has no GPU: whatever fails, fails inside
+    assert ok is False and isinstance(why, str) and why
+
+    def boom(idx, per_xcd):
+        raise RuntimeError('tds_stream_create failed (code -2): out of streams')
+    monkeypatch.setattr(_ops, '_reserved_streams', {})
+    monkeypatch.setattr(_ops, '_make_reserved_entry', boom)
+    monkeypatch.setattr(torch.cuda, 'device', lambda idx: __import__('contextlib').nullcontext())
+    ok, why = _ops.reserved_layout_ok(torch.device('cuda', 0))
+    assert ok is False and 'out of streams' in why
+    assert _ops.reserved_layout_ok(torch.device('cuda', 0)) == (ok, why)            # cached: the probe is not repeated on every render
+    # a verdict taken under capture is re-judged outside capture
+    calls = []
+    monkeypatch.setattr(_ops, '_reserved_streams', {(0, 4): ('rs', 'ms', [], (True, 'not verified: created under stream capture'))})
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(_ops, 'stream_places', lambda s: calls.append(s) or [])
+    monkeypatch.setattr(_ops.nat, 'lib', lambda: type('L', (), dict(tds_device_cu_count=staticmethod(lambda idx, ref: 0)))())
+    ok, why = _ops.reserved_layout_ok(torch.device('cuda', 0))
+    assert calls == ['rs', 'ms'] and not why.startswith('not verified')

@@ -780,7 +780,7 @@ def stream_places(stream, n: int = 8192):
     dev = stream.device
     out = torch.full((n,), -1, dtype=i32, device=dev)
     stream.wait_stream(torch.cuda.current_stream(dev))
-    nat.check(nat.lib().tds_stream_places(ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(out.data_ptr()), n), 'tds_stream_places')
+    nat.call('tds_stream_places', dev, ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(out.data_ptr()), n)      # (with `dev` current)
     stream.synchronize()
     return sorted(set(out.cpu().tolist()))
 
@@ -808,36 +808,54 @@ def _reserved_entry(device, per_xcd):
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ent = _reserved_streams.get((idx, per_xcd))
+    if ent is not None and ent[0] is not None and ent[3][1].startswith('not verified') and not torch.cuda.is_current_stream_capturing():
+        # the streams were made under stream capture, where no probe can run: judged now, at the first call outside capture
+        try:
+            with torch.cuda.device(idx):
+                cus = ctypes.c_int(0)
+                nat.check(nat.lib().tds_device_cu_count(idx, ctypes.byref(cus)), 'tds_device_cu_count')
+                verdict = check_reserved_layout(stream_places(ent[0]), stream_places(ent[1]), per_xcd, cus.value)
+        except Exception as exc:                                     # noqa: BLE001 -- 'never raises': the mode falls back with one warning
+            verdict = (False, f'the probe of the CU-masked streams failed: {exc}')
+        ent = _reserved_streams[(idx, per_xcd)] = (ent[0], ent[1], ent[2], verdict)
     if ent is None:
-        L = nat.lib()
-        cus = ctypes.c_int(0)
-        nat.check(L.tds_device_cu_count(idx, ctypes.byref(cus)), 'tds_device_cu_count')
-        n_words = (cus.value + 31) // 32
-        reserved = [0] * n_words
-        for bit in range(min(8 * per_xcd, cus.value)):
-            reserved[bit // 32] |= 1 << (bit % 32)
-        every = [0] * n_words
-        for bit in range(cus.value):
-            every[bit // 32] |= 1 << (bit % 32)
-        rest = [e & ~r for e, r in zip(every, reserved)]
-        if cus.value < 64 or not any(rest) or not any(reserved):
-            ent = (None, None, [], (False, f'the device reports {cus.value} CUs: too few to keep {per_xcd} per XCD free of the raster launch'))
-        else:
-            handles = []
-            for mask in (rest, reserved):
-                arr = (ctypes.c_uint32 * n_words)(*mask)
-                h = ctypes.c_void_p()
-                nat.check(L.tds_stream_create(idx, ctypes.cast(arr, ctypes.c_void_p), n_words, ctypes.byref(h)), 'tds_stream_create')
-                handles.append(h)
-            rs = torch.cuda.ExternalStream(handles[0].value, device=torch.device('cuda', idx))
-            ms = torch.cuda.ExternalStream(handles[1].value, device=torch.device('cuda', idx))
-            if torch.cuda.is_current_stream_capturing():
-                verdict = (True, 'not verified: created under stream capture')
-            else:
-                verdict = check_reserved_layout(stream_places(rs), stream_places(ms), per_xcd, cus.value)
-            ent = (rs, ms, handles, verdict)
+        try:
+            with torch.cuda.device(idx):
+                ent = _make_reserved_entry(idx, per_xcd)
+        except Exception as exc:                                     # noqa: BLE001 -- reserved_layout_ok / Simulator._reserved_usable promise not to raise
+            ent = (None, None, [], (False, f'creating or probing the CU-masked streams failed: {exc}'))
         _reserved_streams[(idx, per_xcd)] = ent
     return ent
+
+
+def _make_reserved_entry(idx, per_xcd):
+    """(raster stream, metric stream, handles, (ok, reason)) of device `idx` (current); (None, None, [], (False, why)) on a device too small"""
+    L = nat.lib()
+    cus = ctypes.c_int(0)
+    nat.check(L.tds_device_cu_count(idx, ctypes.byref(cus)), 'tds_device_cu_count')
+    n_words = (cus.value + 31) // 32
+    reserved = [0] * n_words
+    for bit in range(min(8 * per_xcd, cus.value)):
+        reserved[bit // 32] |= 1 << (bit % 32)
+    every = [0] * n_words
+    for bit in range(cus.value):
+        every[bit // 32] |= 1 << (bit % 32)
+    rest = [e & ~r for e, r in zip(every, reserved)]
+    if cus.value < 64 or not any(rest) or not any(reserved):
+        return None, None, [], (False, f'the device reports {cus.value} CUs: too few to keep {per_xcd} per XCD free of the raster launch')
+    handles = []
+    for mask in (rest, reserved):
+        arr = (ctypes.c_uint32 * n_words)(*mask)
+        h = ctypes.c_void_p()
+        nat.check(L.tds_stream_create(idx, ctypes.cast(arr, ctypes.c_void_p), n_words, ctypes.byref(h)), 'tds_stream_create')
+        handles.append(h)
+    rs = torch.cuda.ExternalStream(handles[0].value, device=torch.device('cuda', idx))
+    ms = torch.cuda.ExternalStream(handles[1].value, device=torch.device('cuda', idx))
+    if torch.cuda.is_current_stream_capturing():
+        verdict = (True, 'not verified: created under stream capture')          # judged at the first call outside capture (_reserved_entry)
+    else:
+        verdict = check_reserved_layout(stream_places(rs), stream_places(ms), per_xcd, cus.value)
+    return rs, ms, handles, verdict
 
 
 #: set to a list to have raster_scene append (start, end) torch.cuda.Event pairs recorded around every kernel launch

@@ -473,7 +473,7 @@ __device__ float nearest_face_d2_grad(const MapView &m, float px, float py, floa
 // same point, weigh a child each at an inner node and a face each at a leaf; boxes AT the running minimum are still opened (a face in them may
 // tie it, and the lowest face index among ties gives the gradient); the gradient is taken once, from the winning face
 constexpr int BL = 8;             // lanes per corner (a power of two, <= 16: a wavefront holds whole agents)
-constexpr int BVH_STACK = 64;     // (the depth of the hierarchy is below 8, a visit leaves at most 7 entries behind)
+using tds::BVH_STACK;             // (tds_common.h; tds_map_create refuses to attach a hierarchy the stack cannot hold)
 __device__ float nearest_face_d2_grad_bvh(const tds::NearView &nv, float px, float py, float &gx, float &gy, float stop, int sub) {
     static_assert(BL == 8, "nearest_face_d2_grad_bvh: a lane per child of a node");
     __shared__ int2 stacks[GBLOCK / BL][BVH_STACK];
@@ -662,7 +662,7 @@ TDS_EXPORT int tds_collision_bwd_f32(const float *boxes, const float *sc, const 
     TDS_CHECK_ARG(boxes && sc && present && grad_out, "tds_collision_bwd_f32: null pointer");
     // whole scene per workgroup where its tables fit (see collision_scene_bwd_kernel); one wavefront per (scene, agent) otherwise
     const size_t lds_scene = ((size_t)N * 12 + 2 * (size_t)A + (size_t)A * N) * sizeof(float) + (size_t)A * N * sizeof(uint16_t);
-    if (A * N <= 4096 && lds_scene <= 64 * 1024) {
+    if (A * N <= 4096 && lds_scene + 64 <= 64 * 1024) {              // + the kernel's static words (n_near): the sum must fit the 64 KiB a launch gets by default
         if (metric == TDS_METRIC_IOU)
             hipLaunchKernelGGL(collision_scene_bwd_kernel<TDS_METRIC_IOU>, dim3((unsigned)B), dim3(GBLOCK), lds_scene, (hipStream_t)stream, boxes, sc,
                                present, grad_out, grad_boxes, grad_sc, (int)A, (int)N);

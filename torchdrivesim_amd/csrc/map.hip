@@ -142,7 +142,8 @@ void build_near_lists(const float *verts, const int32_t *faces, int64_t F, float
 // Host: the hierarchy over the faces with finite vertices (tds::BvhNode).  A node's faces are cut into up to eight parts by three rounds of
 // median splits, each along the longer axis of the part's centroids; parts of at most 8 faces are leaves (one face per lane of a group of the
 // off-road kernels), larger ones nodes of their own: the depth stays below 8 for any mesh tds_map_create accepts (fewer than 2^24 faces).
-void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<tds::BvhNode> &nodes, std::vector<int32_t> &idx) {
+// -> number of inner levels of the hierarchy (0: none)
+int build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<tds::BvhNode> &nodes, std::vector<int32_t> &idx) {
     struct Box { float x0, y0, x1, y1; };
     std::vector<Box> fb((size_t)F);
     std::vector<float> cx((size_t)F), cy((size_t)F);
@@ -156,7 +157,7 @@ void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<
         cx[(size_t)f] = 0.5f * (b.x0 + b.x1); cy[(size_t)f] = 0.5f * (b.y0 + b.y1);
         idx.push_back((int32_t)f);
     }
-    if (idx.empty()) return;
+    if (idx.empty()) return 0;
     const Box none = {INFINITY, INFINITY, -INFINITY, -INFINITY};
     auto box_of = [&](int lo, int hi) {
         Box b = none;
@@ -178,10 +179,11 @@ void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<
         std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int32_t a, int32_t b) { return key[(size_t)a] < key[(size_t)b] || (key[(size_t)a] == key[(size_t)b] && a < b); });
         return mid;
     };
-    struct Work { int lo, hi, node; };
+    struct Work { int lo, hi, node, level; };
     std::vector<Work> work;
+    int depth = 1;
     nodes.push_back(tds::BvhNode{});
-    work.push_back(Work{0, (int)idx.size(), 0});
+    work.push_back(Work{0, (int)idx.size(), 0, 1});
     while (!work.empty()) {
         const Work w = work.back();
         work.pop_back();
@@ -209,12 +211,14 @@ void build_bvh(const float *verts, const int32_t *faces, int64_t F, std::vector<
                 n.child[k] = -1 - ((lo << 4) | (hi - lo));
             } else {
                 nodes.push_back(tds::BvhNode{});
-                work.push_back(Work{lo, hi, (int)nodes.size() - 1});
+                work.push_back(Work{lo, hi, (int)nodes.size() - 1, w.level + 1});
+                depth = std::max(depth, w.level + 1);
                 n.child[k] = (int32_t)nodes.size() - 1;
             }
         }
         nodes[(size_t)w.node] = n;
     }
+    return depth;
 }
 }  // namespace
 
@@ -479,7 +483,12 @@ TDS_EXPORT int tds_map_create(const float *verts, const int32_t *faces, const fl
     }
     std::vector<tds::BvhNode> bvh_nodes;
     std::vector<int32_t> bvh_idx;
-    if (with_near && !cand.empty() && TDS_BVH_BUILD) build_bvh(verts, faces, F, bvh_nodes, bvh_idx);
+    if (with_near && !cand.empty() && TDS_BVH_BUILD) {
+        // the kernels' descent keeps a fixed stack per point: a hierarchy deeper than it can hold is not attached (the query then walks the
+        // grid rings, slower and exact).  F < 2^24 and eight-way nodes over leaves of up to 8 faces keep the depth below 8.
+        const int depth = build_bvh(verts, faces, F, bvh_nodes, bvh_idx);
+        if (!tds::bvh_fits_stack(depth)) { bvh_nodes.clear(); bvh_idx.clear(); }
+    }
     hipError_t e = hipGetDevice(&m->device);
     size_t be = std::max<size_t>(entries.size(), 1) * sizeof(GridEntry), bc = cell_start.size() * sizeof(int32_t);
     if (e == hipSuccess) e = hipMalloc(&m->d_entries, be);
@@ -778,7 +787,7 @@ __device__ __forceinline__ float nearest_face_d2(const MapView &m, float px, flo
 // far, so the result is the minimum over ALL faces, bit for bit, and `stop` ends the descent as in the other walks.  (Round 5 began with
 // two children per node, both weighed by every lane: three times the depth, 0.60 ms for 65 536 strayed agents.)
 static_assert(OL == 8, "nearest_face_d2_bvh: a lane per child of a node");
-constexpr int BVH_STACK = 64;           // (the depth of the hierarchy is below 8, a visit leaves at most 7 entries behind)
+using tds::BVH_STACK;                   // (tds_common.h; tds_map_create refuses to attach a hierarchy the stack cannot hold)
 __device__ __forceinline__ float box_lb(float px, float py, float x0, float y0, float x1, float y1) {
     const float ex = fmaxf(fmaxf(x0 - px, px - x1), 0.0f), ey = fmaxf(fmaxf(y0 - py, py - y1), 0.0f);
     return (ex * ex + ey * ey) * 0.998f - 1e-3f;

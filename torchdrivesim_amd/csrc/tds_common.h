@@ -108,6 +108,11 @@ struct BvhNode {                // 160 bytes, eight children: a lane of the off-
     float4 box[8];              // (x0, y0, x1, y1) of child k; an empty slot holds (+inf, +inf, -inf, -inf): infinitely far from every point
     int32_t child[8];           // >= 0: an inner node; < 0: a leaf, -1 - (first << 4 | count): `count` (<= 8) faces from bvh_idx[first]
 };
+// entries of the per-point stack of the ordered descent (map.hip: nearest_face_d2_bvh, backward.hip: nearest_face_d2_grad_bvh).  A visit of an
+// inner node pops one entry and pushes at most 8, so a hierarchy of `depth` inner levels needs at most 7 * depth + 1 entries; the builder
+// measures its depth and tds_map_create attaches the hierarchy only if that fits (else the query falls back to the walk over grid rings).
+constexpr int BVH_STACK = 64;
+inline bool bvh_fits_stack(int depth) { return 7 * depth + 8 <= BVH_STACK; }
 struct NearView {
     const NearCand *cand;       // null: no lists (maps with rendering data, empty maps)
     const int32_t *cand_start;  // nx*ny + 1
