@@ -163,7 +163,7 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
-def stamped_traffic(B, A, mode='f32'):
+def stamped_traffic(B, A, mode='f32', res=None):
     """(HBM bytes per launch from the PMC passes committed in profiles/raster_traffic.json, note) -- null unless it was measured on
     exactly this kernel source and this workload."""
     tpath = os.path.join(ROOT, 'profiles', 'raster_traffic.json')
@@ -175,9 +175,24 @@ def stamped_traffic(B, A, mode='f32'):
         return None, f'no PMC figure for mode {mode}'
     if ent.get('kernel_source_sha') != kernel_source_stamp():
         return None, f"PMC figure refused: measured on kernel source {ent.get('kernel_source_sha')}, this build is {kernel_source_stamp()}"
-    if (ent.get('batch'), ent.get('agents'), ent.get('res')) != (B, A, RES):
+    if (ent.get('batch'), ent.get('agents'), ent.get('res')) != (B, A, res if res is not None else RES):
         return None, 'PMC figure is for another workload'
     return ent.get('hbm_bytes_per_launch'), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {ent.get('source')}"
+
+
+def stamped_limiter(B, A, mode, res=None):
+    """What bounds a mode that is NOT bound by HBM, from the PMC passes committed in profiles/raster_traffic.json (same stamp rule as the traffic):
+    dict(bound='valu', valu_busy = share of the SIMDs with a VALU instruction in flight (SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES / 32),
+    cycles_per_valu_instruction, valu_lane_occupancy, ...) -- or dict(bound='valu', note=why there is no figure)."""
+    tpath = os.path.join(ROOT, 'profiles', 'raster_traffic.json')
+    ent = json.load(open(tpath)).get(mode) if os.path.exists(tpath) else None
+    if not isinstance(ent, dict) or not ent.get('valu'):
+        return dict(bound='valu', note=f'no PMC figure committed for mode {mode}')
+    if ent.get('kernel_source_sha') != kernel_source_stamp():
+        return dict(bound='valu', note=f"PMC figure refused: measured on kernel source {ent.get('kernel_source_sha')}, this build is {kernel_source_stamp()}")
+    if (ent.get('batch'), ent.get('agents'), ent.get('res')) != (B, A, res if res is not None else RES):
+        return dict(bound='valu', note='PMC figure is for another workload')
+    return dict(bound='valu', **ent['valu'], source=f"rocprofv3 --pmc passes, {ent.get('source')}")
 
 
 class _ImageProbe(torch.autograd.Function):
@@ -212,7 +227,7 @@ class _ImageProbe(torch.autograd.Function):
         return ctx.saved_tensors[0], None
 
 
-def other_configs(device, steps, warmup, only=None, overlap='reserved'):
+def other_configs(device, steps, warmup, only=None, overlap='reserved', overlap_diff='off'):
     """BASELINE.json's other single-GPU configurations (2, 3, 5) and the uint8 output mode of the headline kernel, measured in
     this run after the timed region: ms/step, agent-steps/s, the dominant kernel and its fraction of the HBM roof."""
     from torchdrivesim_amd import _ops, lanelet2
@@ -244,12 +259,18 @@ def other_configs(device, steps, warmup, only=None, overlap='reserved'):
         state0 = sim.get_state().clone()
 
         ring = None
-        if not name.startswith('config5') and overlap == 'reserved':
-            # as the headline: the loop's stream is kept off four CUs per XCD, the metrics run beside the raster launch on those (the differentiable
-            # configuration cannot: its render is an autograd node of the caller's stream)
+        # as the headline: the loop's stream is kept off four CUs per XCD, the metrics run beside the raster launch on those.  The differentiable
+        # configuration can fork too since round 6 (its metric nodes are autograd nodes of the side stream, so their backward runs beside the
+        # rasteriser's; same gradients: tests/test_gpu_simulator.py) but gains nothing from it at this size -- measured on one box, ms per step:
+        # off 4.070 / 4.074, 'stream' 4.090 / 4.076, 'reserved' 4.115 (its backward kernel is not bound by the write stream and pays for the CUs
+        # 'reserved' keeps it off; profiles/r06_config5_overlap.log) -- so `overlap_diff` defaults to off
+        mode = overlap_diff if name.startswith('config5') else overlap
+        if mode == 'reserved':
             sim.overlap_infractions = 'reserved'
             torch.cuda.synchronize(device)
             torch.cuda.set_stream(sim.raster_stream())
+        elif mode == 'stream' and name.startswith('config5'):
+            sim.overlap_infractions = True
         if not name.startswith('config5'):
             # the forward-only configurations render into a two-buffer ring like the headline (the differentiable one cannot: autograd owns its image)
             from torchdrivesim_amd.rendering import allocate_image_ring
@@ -269,7 +290,15 @@ def other_configs(device, steps, warmup, only=None, overlap='reserved'):
             sim.kinematic_model.set_state(s0)
             sim.step(act)
             img = sim.render_egocentric(res=res, fov=FOV)
-            image_term = _ImageProbe.apply(img, sink['w']) if name == 'config5' else img.sum() * (1.0 / 255.0)
+            if name == 'config5':
+                image_term = _ImageProbe.apply(img, sink['w'])
+            else:
+                # the benchmark's own reduction over 12.9 GB, timed apart like config 5's probe (HIP events on the loop's stream)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                image_term = img.sum() * (1.0 / 255.0)
+                ev[1].record()
+                _ImageProbe.events.append(ev)
             loss = image_term + sim.compute_collision().sum() + sim.compute_offroad().sum()
             loss.backward()
             sink['g'] = (s0.grad, act.grad)
@@ -292,14 +321,17 @@ def other_configs(device, steps, warmup, only=None, overlap='reserved'):
                    dominant_kernel_frac_of_hbm_peak=None if not k_fwd else B * A * ALGO_BYTES_PER_IMAGE / (k_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS)
         if ring is not None:
             ent['ring_probe'] = dict(launch_ms=ring_rep['launch_ms'], fast=ring_rep['fast'], kept=ring_rep['kept'], fill_ms=ring_rep['fill_ms'], yardstick=ring_rep['yardstick'])
-            ent['overlap'] = overlap
+            ent['overlap'] = mode
         else:
             # autograd owns the image of the differentiable step: a fresh tensor per step from the image pool (spread-out physical pages)
             ent['image_allocation'] = 'per step, torch memory pool over tds_torch_alloc (csrc/alloc.hip)'
         if k_bwd is not None:
             ent['raster_backward_kernel_ms'] = k_bwd
-        if name == 'config5' and _ImageProbe.events:
-            # the image term of the LOSS (25.8 GB read by torch.dot) is the benchmark's, not the library's: reported so that it can be told apart
+        if name.startswith('config5'):
+            ent['overlap'] = mode
+        if name.startswith('config5') and _ImageProbe.events:
+            # the image term of the LOSS (config5: 25.8 GB read by torch.dot; config5_sum: 12.9 GB read by sum()) is the benchmark's, not the
+            # library's: reported so that it can be told apart
             ent['loss_probe_ms'] = float(np.mean([a.elapsed_time(b) for a, b in _ImageProbe.events[-steps:]]))
             _ImageProbe.events.clear()
             # the entry LEADS with the library's figure (a reader of the first number saw the probe); the probe-inclusive
@@ -375,7 +407,10 @@ def u8_mode(device, steps, warmup, B, A):
     traffic, note = stamped_traffic(B, A, 'u8')
     del sim, img
     torch.cuda.empty_cache()
-    return dict(mode='uint8 output (3*H*W bytes per camera)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+    lim = stamped_limiter(B, A, 'u8')
+    return dict(mode='uint8 output (3*H*W bytes per camera)', **lim,
+                bound_note='instruction issue (VALU), not HBM: achieved / peak / frac are the HBM figures of the same launch, for comparison with the float32 mode',
+                achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                 traffic=traffic, traffic_source=note, kernel='raster_scene_bits_kernel<uint8> (persistent launch)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
 
 
@@ -403,7 +438,11 @@ def low_res_mode(device, steps, warmup, B, A, res=128):
     achieved = algo / (ms * 1e-3) / 1e9
     del sim, img
     torch.cuda.empty_cache()
-    return dict(mode=f'{res}x{res} float32 output', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=None,
+    traffic, note = stamped_traffic(B, A, f'f32_{res}', res=res)
+    lim = stamped_limiter(B, A, f'f32_{res}', res=res)
+    return dict(mode=f'{res}x{res} float32 output', **lim,
+                bound_note='instruction issue (VALU), not HBM: achieved / peak / frac are the HBM figures of the same call, for comparison with the 256 x 256 mode',
+                achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=note,
                 kernel='scan_faces_kernel + raster_list_bits_kernel (the split form of the bit-plane path)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
 
 

@@ -644,13 +644,58 @@ def test_infractions_beside_the_rasteriser_equal_the_serial_ones():
         sim.overlap_infractions = True
         sim.present_mask[:, 1] = True
     assert type(sim).overlap_infractions is False          # off unless asked for
-    # gradients: the differentiable path never forks
+    # gradients: a differentiable step forks too (round 6; test_differentiable_step_with_metrics_beside_the_rasteriser compares the gradients)
     s0 = sim.get_state().detach().clone().requires_grad_(True)
     sim.kinematic_model.set_state(s0)
     sim.cfg.collision_metric = CollisionMetric('iou')
     img = sim.render_egocentric(res=Resolution(64, 64), fov=35.0)
     (sim.compute_collision().sum() + sim.compute_offroad().sum() + img.sum() / 255.0).backward()
     assert torch.isfinite(s0.grad).all()
+
+
+@pytest.mark.parametrize('mode', [True, 'reserved'])
+def test_differentiable_step_with_metrics_beside_the_rasteriser(mode):
+    """BASELINE config 5 with overlap_infractions on (round 6): the metric nodes of a differentiable step are autograd nodes of the side stream --
+    forward beside the raster launch, backward beside the rasteriser's backward (the engine runs a node's backward on the stream of its
+    forward).  Same values, same gradients as the serial step, over several steps (the second one takes the foreseen path)."""
+    import bench
+    from torchdrivesim_amd.utils import Resolution
+    dev = torch.device(DEV)
+    sim, actions, _ = bench.build_simulator(16, 64, dev, seed=11)
+    res = Resolution(256, 256)
+    state0 = sim.get_state().clone()
+    w = torch.rand(16, 64, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+
+    def run(overlap):
+        sim.overlap_infractions = overlap
+        # (the serial reference of 'reserved' runs on the same CU-masked stream: the rasteriser's backward sizes its launch by the CUs it may use,
+        # and with it the order of its float sums)
+        stream = sim.raster_stream() if mode == 'reserved' else torch.cuda.current_stream(dev)
+        torch.cuda.synchronize(dev)
+        out, forked = [], 0
+        with torch.cuda.stream(stream):
+            for i in range(3):
+                s0 = state0.clone().requires_grad_(True)
+                act = actions[i].clone().requires_grad_(True)
+                sim.kinematic_model.set_state(s0)
+                sim.step(act)
+                img = sim.render_egocentric(res=res, fov=35.0)
+                forked += sim._fork is not None
+                col, off = sim.compute_collision(), sim.compute_offroad()
+                loss = (img * w).sum() / 255.0 + col.sum() + (off * off).sum()
+                loss.backward()
+                out.append((col.detach().clone(), off.detach().clone(), s0.grad.clone(), act.grad.clone()))
+            torch.cuda.synchronize(dev)
+        sim.overlap_infractions = False
+        return out, forked
+
+    serial, n0 = run(False)
+    beside, n1 = run(mode)
+    assert n0 == 0 and n1 == 3, 'the differentiable render did not fork'
+    for a, b in zip(serial, beside):
+        for x, y in zip(a, b):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+    assert serial[0][2].abs().sum() > 0 and serial[0][1].abs().sum() > 0
 
 
 def test_foreseen_infractions_are_enqueued_ahead_of_the_raster_launch():

@@ -25,8 +25,10 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--only', default=None, help='config2, config3 or config5')
+    ap.add_argument('--overlap', default='reserved', choices=('reserved', 'stream', 'off'), help='configs 2 / 3: where the metrics run (bench.py --overlap)')
+    ap.add_argument('--overlap-diff', default='off', choices=('reserved', 'stream', 'off'), help='config 5: the same for the differentiable step')
     args = ap.parse_args()
-    for entry in bench.other_configs(torch.device('cuda', 0), args.steps, args.warmup, only=args.only):
+    for entry in bench.other_configs(torch.device('cuda', 0), args.steps, args.warmup, only=args.only, overlap=args.overlap, overlap_diff=args.overlap_diff):
         print(json.dumps(entry), flush=True)
 
 

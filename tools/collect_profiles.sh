@@ -42,15 +42,16 @@ for cfg in config2 config3 config5; do
   cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${cfg}_kernel_stats.csv
   rm -rf $OUT/kt
 done
-for mode in f32 u8; do
-  extra=""; [ $mode = u8 ] && extra="--u8"
+# float32 256 x 256 (the headline kernel), uint8 256 x 256, and the split form at 128 x 128 / 64 x 64 (K3s scan_faces_kernel + K3r raster_list_bits_kernel)
+for mode in f32 u8 f32_128 f32_64; do
+  extra=""; [ $mode = u8 ] && extra="--u8"; [ $mode = f32_128 ] && extra="--res 128"; [ $mode = f32_64 ] && extra="--res 64"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
     i=$((i+1))
-    rocprofv3 --pmc $set --kernel-include-regex "raster" --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py --batch 1024 --iters 2 $extra > $OUT/p$i.log 2>&1
+    rocprofv3 --pmc $set --kernel-include-regex "raster|scan_faces" --output-format csv -d $OUT/p$i -o p$i -- python3 $R/tools/profile_raster.py --batch 1024 --iters 2 $extra > $OUT/p$i.log 2>&1
   done
-  python3 $R/tools/pmc_summary.py $OUT raster > $OUT/raster_pmc_$mode.json
+  python3 $R/tools/pmc_summary.py $OUT "raster|scan_faces" > $OUT/raster_pmc_$mode.json
   rm -rf $OUT/p[0-9] $OUT/p[0-9].log
 done
 head -5 $OUT/bench_kernel_stats.csv | cut -c1-160

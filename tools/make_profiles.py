@@ -77,14 +77,22 @@ for name, cmd in commands.items():
 out, traffic = dict(kernel_source_sha=stamp, batch=B, agents=A, res=RES,
                     command='tools/collect_profiles.sh: rocprofv3 --pmc <set> --kernel-include-regex raster -- python3 tools/profile_raster.py '
                             '--batch 1024 --iters 2 [--u8]  (one pass per counter set, counters only, the PRODUCT library)'), {}
-for mode, bpp in (('f32', 4), ('u8', 1)):
+for mode, bpp, mres in (('f32', 4, RES), ('u8', 1, RES), ('f32_128', 4, 128), ('f32_64', 4, 64)):
     path = os.path.join(src, f'raster_pmc_{mode}.json')
     if not os.path.exists(path):
         continue
     pmc = json.load(open(path))
-    key = max(pmc, key=lambda k: pmc[k].get('WRITE_SIZE', {}).get('mean', 0))
-    c = {n: v['mean'] for n, v in pmc[key].items()}
-    algo = B * A * 3 * RES * RES * bpp
+    if mres == RES:
+        key = max(pmc, key=lambda k: pmc[k].get('WRITE_SIZE', {}).get('mean', 0))
+        c = {n: v['mean'] for n, v in pmc[key].items()}
+    else:
+        # the split form: two kernels per render call (K3s, K3r) -- the counters of both, summed
+        key = ' + '.join(sorted(pmc))
+        c = {}
+        for k in pmc:
+            for n, v in pmc[k].items():
+                c[n] = c.get(n, 0.0) + v['mean']
+    algo = B * A * 3 * mres * mres * bpp
     wb, fb = c['WRITE_SIZE'] * 1024, c['FETCH_SIZE'] * 1024
     waves = c.get('SQ_WAVES', 0) or 1
     ent = dict(kernel=key, counters=c, write_bytes_per_launch=wb, fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch_corrected=2 * fb,
@@ -103,14 +111,24 @@ for mode, bpp in (('f32', 4), ('u8', 1)):
                # lanes doing work per VALU instruction: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (where the pass collected it)
                valu_lane_occupancy=(c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU'])) if c.get('SQ_THREAD_CYCLES_VALU') and c.get('SQ_ACTIVE_INST_VALU') else None)
     out[mode] = ent
-    traffic[mode] = dict(batch=B, agents=A, res=RES, hbm_bytes_per_launch=wb + 2 * fb, kernel_source_sha=stamp, source=f'profiles/{tag}_raster_pmc.json')
+    # what bench.py quotes beside a mode that is bound by instruction issue, not by HBM: the share of the SIMDs with a VALU
+    # instruction in flight, the average issue cost of one (4 cycles is the rate of a dependent add chain: tools/valu_calibrate.hip), the lanes at
+    # work per instruction, and the time the VALU instructions alone take on 1 024 SIMDs at 2.4 GHz
+    valu = None
+    if ent['valu_busy_simds_per_se_of_32'] is not None:
+        valu = dict(valu_busy=ent['valu_busy_simds_per_se_of_32'] / 32.0,
+                    cycles_per_valu_instruction=4.0 / ent['valu_issue_fraction_of_add_chain'] if ent['valu_issue_fraction_of_add_chain'] else None,
+                    valu_lane_occupancy=ent['valu_lane_occupancy'],
+                    valu_instructions_per_launch=c.get('SQ_INSTS_VALU'),
+                    valu_issue_ms_at_4_cycles=c.get('SQ_INSTS_VALU', 0) * 4 / (1024 * 2.4e9) * 1e3)
+    traffic[mode] = dict(batch=B, agents=A, res=mres, hbm_bytes_per_launch=wb + 2 * fb, kernel_source_sha=stamp, source=f'profiles/{tag}_raster_pmc.json', valu=valu)
 out['notes'] = ('WRITE_SIZE / FETCH_SIZE are reported in KiB. FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (an upper bound here: part '
                 'of the reads are 32-byte grid-entry gathers). traffic = WRITE_SIZE + 2 FETCH_SIZE. lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / '
                 'SQ_LDS_IDX_ACTIVE (round 1: 0.49 with the row-major plane layout).')
 json.dump(out, open(os.path.join(dst, f'{tag}_raster_pmc.json'), 'w'), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(dst, 'raster_traffic.json'), 'w'), indent=1)
-for mode in ('f32', 'u8'):
+for mode in ('f32', 'u8', 'f32_128', 'f32_64'):
     if mode in out:
         e = out[mode]
         print(mode, {k: e[k] for k in ('write_bytes_per_launch', 'fetch_bytes_per_launch_raw', 'traffic_over_algorithmic', 'valu_instructions_per_wave',

@@ -705,8 +705,7 @@ class Simulator:
         state = srcs[0]
         cached = getattr(self, '_sc_cache', None)
         if len(srcs) != len(stamp) or any(a is not b or a._version != v for a, (b, v) in zip(srcs, stamp)) or self.npc_count > 0 or \
-                (torch.is_grad_enabled() and any(t.requires_grad for t in srcs)) or torch.cuda.current_stream(state.device) != main or \
-                cached is None or cached[0] is not state or cached[1] != state._version:
+                torch.cuda.current_stream(state.device) != main or cached is None or cached[0] is not state or cached[1] != state._version:
             return fn()
         if key is not None and key not in self._fork_used:
             self._fork_used.append(key)                              # foreseen at the next render
@@ -902,7 +901,12 @@ class Simulator:
             if out is not None and len(scene['maps']) != 1:
                 raise RuntimeError('`out=` needs a batch that is served by one launch')
             out_arg, out = ({} if out is None else dict(out=out)), []
-            if not diff:
+            # the metrics run beside the launch; a differentiable render forks too when the launch stays on the caller's stream (the plain second
+            # stream, or 'reserved' with the loop on sim.raster_stream()): the metric nodes are then autograd nodes of the side stream, and the
+            # engine runs their backward there as well -- beside the rasteriser's backward
+            if not diff or self.overlap_infractions is True or \
+                    (self.overlap_infractions == 'reserved' and state.is_cuda and self._reserved_usable(state.device) and
+                     torch.cuda.current_stream(state.device) == _ops.reserved_streams(state.device, Simulator._reserved_per_xcd)[0]):
                 r = res if res is not None else getattr(self.renderer, 'res', None)
                 self._mark_fork(write_bound=self.renderer.out_dtype == torch.float32 and (r is None or min(r.height, r.width) > 208))
             # render_egocentric with gradients: the cameras are the exposed agents themselves -- one autograd node takes state and headings and
