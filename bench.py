@@ -59,7 +59,8 @@ def load_town02():
 
 def build_simulator(B, A, device, seed, metric='iou', lanelet_map=None, mixed=False):
     """`mixed`: the batch is collated from Town01 and Town02 (mesh.py:232-245 of the reference: padded to the larger mesh), even scenes on
-    Town01, odd scenes on Town02, every scene's agents on its own town's roads."""
+    Town01, odd scenes on Town02, every scene's agents on its own town's roads.  `mixed='town02'`: the same collated rows, every scene on Town02
+    (one distinct mesh: a single map)."""
     from torchdrivesim_amd.kinematic import KinematicBicycle
     from torchdrivesim_amd.mesh import BirdviewMesh
     from torchdrivesim_amd.rendering import HipRendererConfig, renderer_from_config
@@ -73,7 +74,7 @@ def build_simulator(B, A, device, seed, metric='iou', lanelet_map=None, mixed=Fa
         state, size, present, actions = synth_agents(B, A, verts[vcat == cats.index('road')], seed)
     else:
         v2, f2, vc2, c2 = load_town02()
-        which = np.arange(B) % 2
+        which = np.arange(B) % 2 if mixed is True else np.full(B, int(mixed == 'town02'))
         road = BirdviewMesh.collate([town(verts, faces, vcat, cats), town(v2, f2, vc2, c2)]).to(device)[which.tolist()]       # B padded rows, a real (not expanded) batch
         state, size, present, actions = synth_agents(B, A, verts[vcat == cats.index('road')], seed)
         s2 = synth_agents(B, A, v2[vc2 == c2.index('road')], seed + 1)[0]
@@ -502,12 +503,31 @@ def mixed_maps_mode(device, steps, warmup, B, A, overlap, headline_ms, ring):
     k = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events]))
     _ops.raster_events = None
     frac_lit = float((sink['img'][:8] != 0).float().mean())
+    # the same loop with EVERY scene on Town02 (one map): Town02's roads are denser than Town01's (0.42 against 0.23 faces per square metre, twice
+    # the faces per view), so a mixed batch is to be held against the mean of the two single-map batches, not against Town01 alone
+    del sim
+    sim, actions, _ = build_simulator(B, A, device, seed=4321, mixed='town02')
+    if overlap == 'reserved':
+        sim.overlap_infractions = 'reserved'
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    _ops.raster_events = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize(device)
+    dt2 = (time.perf_counter() - t0) / steps
+    k2 = float(np.mean([a.elapsed_time(b) for a, b in _ops.raster_events]))
+    _ops.raster_events = None
     torch.cuda.set_stream(torch.cuda.default_stream(device))
     del sim
     sink.clear()
     return dict(what=f'the headline loop at B={B}xA={A}, {RES}x{RES} float32, on a batch collated from Town01 (even scenes) and Town02 (odd scenes), '
                      'rendered into the headline\'s own two output buffers',
                 ms_per_step=1e3 * dt, agent_steps_per_s=B * A / dt, vs_single_map_headline=None if not headline_ms else 1e3 * dt / headline_ms,
+                single_map_town02=dict(ms_per_step=1e3 * dt2, dominant_kernel_ms=k2),
+                vs_mean_of_the_single_map_runs_of_both_towns=None if not headline_ms else 1e3 * dt / (0.5 * (headline_ms + 1e3 * dt2)),
                 dominant_kernel='raster_scene_bits_kernel', dominant_kernel_ms=k,
                 dominant_kernel_frac_of_hbm_peak=B * A * ALGO_BYTES_PER_IMAGE / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 map_creations=dict(rendering=n1 - n0, offroad=n2 - n1, after_select_batch_elements=n3 - n2),
