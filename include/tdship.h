@@ -206,7 +206,7 @@ int tds_offroad_multi_bwd_f32(const tds_mapset_t *set, const int32_t *scene_map,
  *
  * workspace: optional DEVICE scratch (tds_raster_scene_workspace_bytes) for the two-kernel forms -- a first kernel scans the map grid
  * once per camera and lists the surviving faces, a second one rasterises from the lists: per-strip lists for the packed-key kernels
- * (more than 15 keys), one list of up to 1 636 faces or pairs of faces per camera (20 bytes each) for the bit-plane kernels up to 144 x 144 (float32) / 208 x 208 (uint8),
+ * (more than 15 keys), one list of up to 1 636 faces or pairs of faces per camera (20 bytes each) for the bit-plane kernels up to 160 x 160 (float32; above 116 x 116 only multiples of 16) / 216 x 216 (uint8),
  * where that form is faster than the fused kernel (above, the fused kernel runs and the recommended size holds no lists).  A list that overflows only sends its camera (or strip) to the kernel that scans for
  * itself: the pixels never depend on the size of the scratch.  With workspace == NULL every launch scans the grid itself (same pixels,
  * slower at low resolutions).  The scratch carries no state between calls.
@@ -260,7 +260,7 @@ int tds_raster_scene_multi(const tds_mapset_t *set, const int32_t *scene_map, co
 /* recommended scratch size for n_img = B * Nc cameras at this resolution (0 if the fast path cannot be used): enough for every path */
 int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t *bytes);
 /* the same for a launch of which the caller knows the number of distinct keys (map keys + actor keys, tds_map_keys): with at most 15 the
- * bit-plane kernels run, which use the face lists up to 144 x 144 (float32) / 208 x 208 (uint8) only and above nothing but the 64 bytes of
+ * bit-plane kernels run, which use the face lists up to 160 x 160 (float32; above 116 x 116 only multiples of 16) / 216 x 216 (uint8) only and above nothing but the 64 bytes of
  * work queues -- 128 bytes instead of 32 KB per camera at 256 x 256.  n_keys < 0 or > 15: as tds_raster_scene_workspace_bytes. */
 int tds_raster_scene_workspace_bytes_for(int64_t n_img, int res, int out_mode, int n_keys, int64_t *bytes);
 

@@ -144,6 +144,10 @@ def test_a_buffer_that_does_not_fit_with_its_spacers_is_built_dense_and_nothing_
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     free0, total = torch.cuda.mem_get_info(DEV)
+    if free0 < 0.9 * total:
+        # the test takes all free device memory but 9 GB: only with the device to itself (another process allocating meanwhile would make it
+        # fail for reasons that are not the library's -- ADVICE r5)
+        pytest.skip(f'the device is shared: {free0 / 2 ** 30:.0f} of {total / 2 ** 30:.0f} GiB free')
     want = 6 << 30
     # leave room for the buffer and half of its spacers: the spacer chunks run out on the way
     hold_bytes = free0 - want - (want // 2)

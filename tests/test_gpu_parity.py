@@ -594,6 +594,51 @@ def test_k3_split_form_equals_the_fused_kernel_and_the_oracle(ops, oracle, town,
         ops._workspaces.clear()
 
 
+def test_k3_per_camera_triangles_in_every_form(ops, oracle, town, testing_lib):
+    """Per-camera triangles (waypoint discs: `extra_tri` / `extra_key` of tds_raster_scene) through every form of the bit-plane path: the fused
+    kernel's third producer phase, K3s's own loop over them (round 6: scan_faces_kernel<SceneArgsEx>, 150 triangles per camera = three rounds of
+    64), lists that overflow, the packed-key kernels; float32 and uint8.  Same pixels everywhere, and they differ from the scene without them."""
+    g = load_golden('g45_mesh_preraster.npz')
+    st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']
+    B, A = st.shape[:2]
+    smap = make_map(ops, town['verts'], town['faces'], town['vert_category'], town['categories'])
+    mask = dev(np.ascontiguousarray(np.broadcast_to(pr[:, None, :], (B, A, A))))
+    sd = dev(st)
+    agent_sc, tmpl, keys = ops.heading_sc(sd[..., 2]), dev(oracle.actor_template(sz)), actor_keys(smap, B, A)
+    gen = np.random.default_rng(3)
+    K = 150
+    centre = st[:, :, None, None, :2] + gen.uniform(-18, 18, (B, A, K, 1, 2))
+    tri = dev((centre + gen.uniform(-1.5, 1.5, (B, A, K, 3, 2))).astype(np.float32))
+    wkey = (smap.rank_of(LEVELS['vehicle']) << 24) | pack((139, 64, 0))           # a key of its own: one more bit plane
+    ekey = torch.full((B, A, K), wkey, dtype=torch.int64).to(torch.int32).to(DEV)
+    ekey[:, :, ::7] = 0                                                             # key 0: no triangle
+    real_ws = ops._raster_workspace
+    try:
+        for res, fov in ((64, 35.0), (128, 35.0), (256, 35.0)):
+            for dtype in (torch.float32, torch.uint8):
+                ref = None
+                for flags, small_ws, bits in ((8192, False, True), (16384, False, True), (16384, True, True), (0, False, True), (0, False, False)):
+                    testing_lib.tds_raster_set_debug(flags)
+                    ops._workspaces.clear()
+                    if small_ws:
+                        n_img = B * A
+                        nbytes = ((n_img + 1) * 4 + 255) // 256 * 256 + (n_img * 4 + 255) // 256 * 256 + n_img * 300 * 20
+                        ops._raster_workspace = lambda d, n, r, *rest: torch.empty(nbytes, dtype=torch.uint8, device=d)
+                    ops.use_bitplanes = bits
+                    try:
+                        img = ops.raster_scene(smap, sd, agent_sc, tmpl, keys, mask, sd[..., :2].contiguous(), agent_sc, fov, res, dtype, extra_tri=tri, extra_key=ekey)
+                    finally:
+                        ops._raster_workspace = real_ws
+                        ops.use_bitplanes = True
+                    ref = img if ref is None else ref
+                    assert torch.equal(img, ref), f'res {res} {dtype} flags {flags} small workspace {small_ws} bit planes {bits}: {(img != ref).sum().item()} values differ'
+                plain = ops.raster_scene(smap, sd, agent_sc, tmpl, keys, mask, sd[..., :2].contiguous(), agent_sc, fov, res, dtype)
+                assert (plain != ref).any()
+    finally:
+        testing_lib.tds_raster_set_debug(0)
+        ops._workspaces.clear()
+
+
 def test_k3_u8_mode_equals_f32(ops, oracle, town):
     g = load_golden('g45_mesh_preraster.npz')
     st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']

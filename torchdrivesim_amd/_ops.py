@@ -641,7 +641,7 @@ use_index_slices = True   # test hook: False makes the raster backward read the 
 
 def _raster_workspace(dev, n_img, res, out_mode=None, n_keys=-1):
     """n_keys: distinct keys of the launch (map + actors) when the caller knows them (-1: not known) -- with at most 15 the bit-plane kernels
-    run, which above 144 x 144 (float32) / 208 x 208 (uint8) need nothing but their 64 bytes of work queues (128 bytes instead of 2.1 GB at
+    run, which above 160 x 160 (float32) / 216 x 216 (uint8) need nothing but their 64 bytes of work queues (128 bytes instead of 2.1 GB at
     B x A = 65 536 cameras of 256 x 256)"""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     n_keys = int(n_keys) if (out_mode is not None and 0 <= n_keys <= 15) else -1

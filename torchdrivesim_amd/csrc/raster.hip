@@ -2857,8 +2857,20 @@ static int common_checks(const char *fn, int64_t n_img, int res, int out_mode, c
 namespace {
 constexpr int DEFAULT_CAPS = 512;         // faces per strip list that the recommended workspace provides
 constexpr int LIST_CAPS = 2048;           // faces per camera list of the split bit-plane path that the recommended workspace provides
-// the split form (K3s + K3r) serves resolutions up to these; above, the fused launch hides the scan behind its write stream or its row loops
-constexpr int SPLIT_MAX_RES_F32 = 144, SPLIT_MAX_RES_U8 = 208;      // (round 5 sweep, fused / split ms: float32 128 4.02 / 3.16, 144 4.19 / 4.39, 160 4.31 / 4.22, 176 4.60 / 4.97; uint8 192 4.37 / 4.16, 208 4.77 / 4.81, 224 4.94 / 7.4)
+// The split form (K3s + K3r) serves resolutions up to these; above, the fused launch hides the scan behind its write stream or its row loops.
+// ONE sweep on one build and box (round 6, tools/split_threshold_sweep.sh, B = 1024 x 64, ms per call, fused / split -- each pair from one process;
+// profiles/r06_split_threshold_sweep.log):
+//   float32   96 4.00 / 2.72   104 4.09 / 3.02   112 4.13 / 3.24   116 4.14 / 3.98   120 4.19 / 4.46   124 4.18 / 4.20   128 4.12 / 3.24   136 4.33 / 5.38
+//            144 4.36 / 3.93   152 4.46 / 5.03   160 4.48 / 4.28   168 5.11 / 6.20   176 4.80 / 5.02   192 4.97 / 5.48
+//   uint8    128 3.99 / 2.91   160 4.16 / 3.38   176 4.51 / 3.70   192 4.50 / 4.14   208 4.69 / 4.33   216 4.65 / 4.38   224 4.94 / 5.18 (7.35 once the strip no longer
+//            holds the whole image)   256 5.09 / 5.64
+// float32: K3r is bound by its write stream from about 116 x 116 on and pays for output columns (res x 4 bytes) that straddle 64-byte sectors, so above
+// SPLIT_ANY_RES_F32 the split form is taken only where res is a multiple of 16 (split_serves).
+constexpr int SPLIT_MAX_RES_F32 = 160, SPLIT_ANY_RES_F32 = 116, SPLIT_MAX_RES_U8 = 216;
+inline bool split_serves(int res, bool f32) {
+    if (!f32) return res <= SPLIT_MAX_RES_U8;
+    return res <= SPLIT_ANY_RES_F32 || (res <= SPLIT_MAX_RES_F32 && (res & 15) == 0);
+}
 inline int64_t ws_bytes_for(int64_t n_img, int strips, int caps) {
     return n_img * strips * ((int64_t)caps * (int64_t)sizeof(uint4) + (int64_t)sizeof(uint32_t));
 }
@@ -2881,7 +2893,7 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes(int64_t n_img, int res, int64_t 
     // (only where the split form can be chosen for either output type; the testing build can force it anywhere)
     const int64_t lists = (((n_img + 1) * 4 + 255) & ~(int64_t)255) + ((n_img * 4 + 255) & ~(int64_t)255) + n_img * LIST_CAPS * 16;
 #ifndef TDS_TESTING
-    if (res <= (SPLIT_MAX_RES_F32 > SPLIT_MAX_RES_U8 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8))
+    if (split_serves(res, true) || split_serves(res, false))
 #endif
     if (lists > *bytes) *bytes = lists;
     *bytes = ((*bytes + 63) & ~(int64_t)63) + QUEUE_BYTES + 64;          // + the work queues of a persistent launch, at the end (workspace_queue)
@@ -2896,7 +2908,7 @@ TDS_EXPORT int tds_raster_scene_workspace_bytes_for(int64_t n_img, int res, int 
     // the bit-plane kernels: face lists where the split form can run for this output type, the work queues of the persistent launch always
     int64_t lists = 0;
 #ifndef TDS_TESTING
-    if (res <= (out_mode == TDS_OUT_F32 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8))
+    if (split_serves(res, out_mode == TDS_OUT_F32))
 #endif
         lists = (((n_img + 1) * 4 + 255) & ~(int64_t)255) + ((n_img * 4 + 255) & ~(int64_t)255) + n_img * LIST_CAPS * 16;
     *bytes = ((lists + 63) & ~(int64_t)63) + QUEUE_BYTES + 64;
@@ -3018,13 +3030,8 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                 const uint32_t *only = nullptr;
                 {
                     const bool f32 = out_mode == TDS_OUT_F32;
-                    // measured at B = 1024 x 64 (fused / split, ms): float32 96 x 96 3.89 / 3.17, 128 3.95 / 3.60, 160 4.33 / 4.79; uint8 128 4.03 / 3.04,
-                    // 192 4.53 / 4.34, 256 5.3 / 5.9 -- from there on the fused launch hides the scan behind its write stream or its row loops
-                    bool split = !want_slices && nwv == 4 && workspace != nullptr && res <= (f32 ? SPLIT_MAX_RES_F32 : SPLIT_MAX_RES_U8);
-                    // float32 above 128: only where a column of the output (res x 4 bytes) is a whole number of 64-byte sectors -- K3r is bound by
-                    // its write stream there and pays for columns that straddle sectors (136: 4.47 ms against the fused kernel's 4.19; 144: 3.89
-                    // against 4.21; 120, still below the fused kernel: 3.71 against 128's 3.16)
-                    if (f32 && res > 128 && (res & 15) != 0) split = false;
+                    // (where the split form pays: the sweep beside SPLIT_MAX_RES_*)
+                    bool split = !want_slices && nwv == 4 && workspace != nullptr && split_serves(res, f32);
                     if (TDS_DBG(g_debug) & 8192) split = false;                              // testing: the fused kernel everywhere
                     if (TDS_DBG(g_debug) & 16384) split = !want_slices && nwv == 4 && workspace != nullptr;      // testing: the split form everywhere
                     const size_t off_counts = (((size_t)n_img + 1) * 4 + 255) & ~(size_t)255;
@@ -3048,7 +3055,10 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                         if (lw == 0) lw = (int64_t)res * tws <= (f32 ? 104 * 104 : 128 * 128) ? 2 : 4;
                         while (tws > 32 && bits_lds_bytes(kt.n, res, tws, lw, out_mode) > (size_t)g_list_lds_kb * 1024) tws -= 32;
                         const size_t lds_s = bits_lds_bytes(kt.n, res, tws, lw, out_mode);
-                        if (lds_s <= 150 * 1024) {
+                        // (more keys than the sweep's five can push a large image over the LDS budget: K3r in several strips per camera loses to
+                        // the fused kernel from about 160 x 160 on -- uint8 224: 7.35 against 4.94 ms -- unless the testing build forces the form)
+                        const bool narrowed = tws < ((res + 31) & ~31) && res >= 160 && !(TDS_DBG(g_debug) & 16384);
+                        if (lds_s <= 150 * 1024 && !narrowed) {
                             if (aux) { aux->n_keys = kt.n; aux->index_bits = nb; for (int i = 0; i < 16; ++i) aux->keys[i] = i < kt.n ? kt.key[i] : 0u; }
                             if (tds::zero_async(poisoned, 4, (hipStream_t)stream) != hipSuccess) { tds::set_error("tds_raster_scene: clearing the workspace failed"); return TDS_EHIP; }
                             CommonArgs cs = cm;

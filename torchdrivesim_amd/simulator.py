@@ -656,7 +656,9 @@ class Simulator:
 
     def _mark_fork(self, write_bound: bool = True) -> None:
         """called by render() right before the raster launch: everything the metrics read has been enqueued by now.
-        `write_bound`: the launch that follows is bound by the HBM write stream (float32 images above 208 x 208: the fused persistent kernel).
+        `write_bound`: the launch that follows is bound by the HBM write stream -- float32 images above 208 x 208.  (That is a statement about the
+        BOUND, not about which kernel serves the launch: the fused persistent kernel starts above 160 x 160, raster.hip: split_serves, but a
+        float32 launch between 160 and 208 pixels is still limited by instruction issue -- 192 x 192: 4.97 ms for 29 GB = 0.73 of the roof.)
         Only then does 'reserved' pay -- a compute-bound launch (uint8, low resolutions) would give an eighth of its CUs away for nothing, so
         the mode is skipped for it (the metrics run behind the launch)."""
         prev, self._fork = self._fork, None
