@@ -452,7 +452,7 @@ def mixed_maps_mode(device, steps, warmup, B, A, overlap, headline_ms, ring):
     mesh.py:232-245): one device map per DISTINCT mesh (two rendering maps, two off-road maps; `_ops.group_rows` finds them by content on the
     device), served by the same launches through a map set.  Reports the set-up (grouping + map builds, until the first image exists) and the
     step beside the single-map headline of this run.  `ring`: the headline's own two output buffers -- the same physical pages under both
-    measurements (what a write stream reaches depends on them), so that the difference is the maps'."""
+    measurements (what a write stream reaches depends on them, DESIGN_HISTORY.md section 4), so that the difference is the maps'."""
     from torchdrivesim_amd import _ops
     from torchdrivesim_amd.utils import Resolution
     res = Resolution(RES, RES)
@@ -720,14 +720,14 @@ def main():
         # The images go to two caller-owned buffers, allocated once and used in turn (step i renders while the consumer of step i - 1 still
         # holds the other one): a training loop owns its observation ring.  The reference allocates per call (rendering/cv2.py:52).  What the
         # write stream of the launch reaches depends on the PHYSICAL pages under the buffer (about one 51.5 GB hipMalloc in three is served
-        # at 7/8 of the rate for as long as it lives): the buffers come from the library's allocator, which spreads the
+        # at 7/8 of the rate for as long as it lives; DESIGN_HISTORY.md section 4): the buffers come from the library's allocator, which spreads the
         # pages out (csrc/alloc.hip), and allocate_image_ring still measures every candidate against the fill_ rate of the same run; what
         # it saw is reported per rank (`roofline.ring_probe`, `per_rank`).  The reference-shaped call without `out=` is measured after the
         # timed region and reported beside (`default_path`).
         from torchdrivesim_amd.rendering import allocate_image_ring
         # The metrics run BESIDE the raster launch: the loop's stream (sim.raster_stream()) is kept off four CUs per XCD -- the write-bound launch loses
         # nothing on 224 of 256 CUs -- and the metric kernels, foreseen from the previous step, are enqueued on a stream confined to those 32 CUs
-        # (tds_stream_create, hipExtStreamCreateWithCUMask).  Same kernels, same bits; `--overlap off` puts them behind the launch.
+        # (tds_stream_create, hipExtStreamCreateWithCUMask; DESIGN_HISTORY.md section 4).  Same kernels, same bits; `--overlap off` puts them behind the launch.
         sim.overlap_infractions = {'reserved': 'reserved', 'stream': True, 'off': False}[args.overlap]
         loop_stream = sim.raster_stream() if args.overlap == 'reserved' else torch.cuda.current_stream(device)
         torch.cuda.synchronize(device)

@@ -126,7 +126,7 @@ typedef struct tds_map tds_map_t;
  * face_z F (rendering level of the face's FIRST vertex, cv2.py:44-46), face_rgb F (colour of the first vertex already
  * quantised as cv2.py:50: 0x00RRGGBB), levels: n_levels distinct rendering levels sorted DESCENDING that contain every
  * face_z and every actor level that will be rendered with this map (<= 255).  face_z / face_rgb / levels may be NULL
- * for a map that is only used by tds_offroad_f32; such a map also gets per-cell nearest-face candidate lists (exact; DESIGN.md K2b),
+ * for a map that is only used by tds_offroad_f32; such a map also gets per-cell nearest-face candidate lists (exact; DESIGN.md 5.4),
  * which make the off-road query one short linear walk, and a bounding-volume hierarchy over its faces for points beyond the lists' grid.  cell_size <= 0 selects the default (8 m).
  * The handle lives on the CURRENT HIP device. */
 int tds_map_create(const float *verts, const int32_t *faces, const float *face_z, const uint32_t *face_rgb, int64_t V,
@@ -270,7 +270,7 @@ int tds_raster_scene_workspace_bytes_for(int64_t n_img, int res, int out_mode, i
  * The rasteriser is bound by the HBM write stream, and what a write stream reaches on MI355X depends on the PHYSICAL pages under the
  * buffer: a large hipMalloc is served at 1, 15/16 or 7/8 of the rate for as long as it lives, whatever its virtual address and whatever
  * the store pattern (about one 51.5 GB allocation in three is at 7/8); a buffer whose physical pages are spread over twice its size
- * hardly ever is (one of 100 probed, at 15/16; DESIGN.md section 4, tools/alloc_probe.hip).  tds_buffer_create builds such a buffer: chunks of 8 MiB created alternately
+ * hardly ever is (one of 100 probed, at 15/16; DESIGN_HISTORY.md section 4, tools/alloc_probe.hip).  tds_buffer_create builds such a buffer: chunks of 8 MiB created alternately
  * with spacer chunks that are released once the buffer is mapped (hipMemCreate / hipMemMap; needs twice the size free while it runs,
  * and falls back to dense chunks when that is not there).  Below 256 MiB, or with TDS_BUFFER_DENSE, it is one hipMalloc.
  * These are explicit create / destroy calls like tds_map_create: no per-step entry point allocates.

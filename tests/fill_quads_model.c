@@ -7,7 +7,7 @@
  * process_batch_bits in two organisations ("hull of both triangles' intervals" and the leaner "master + third chain" of model_pair_x
  * below), was bit-exact against the oracle on every GPU parity test, and LOST on the clock -- the row items of a pair need twice the
  * cross-lane traffic and the cut rows, which costs more than the halved number of rows gives back (uint8 256 x 256, one box: 5.09 ms
- * triangle by triangle, 5.75 paired).  The model stays as the proof of the rule for whoever takes it up again.
+ * triangle by triangle, 5.75 paired; DESIGN_HISTORY.md section 4).  The model stays as the proof of the rule for whoever takes it up again.
  *
  * What is being proved.  tests/fill_rows_model.c proves the per-triangle row rule: in every row the painted pixels of a triangle are ONE
  * interval, the hull of the row ends of its active 16.16 edge chains (outline edges inside the image merged into the rows).  For a pair,

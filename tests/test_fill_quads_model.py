@@ -2,7 +2,7 @@
 The PAIR rule -- two same-key triangles that share an edge (a triangulated quad of the road / lane-marking mesh) can have their interior rows
 painted once, as the hull of the two triangles' row intervals -- as sequential C (tests/fill_quads_model.c), checked pair by pair against the
 oracle's cv::fillConvexPoly restatement called once per triangle (rendering/cv2.py:44-59 of the reference: one cv2.fillConvexPoly per face).
-Round 5 built the rule into the bit-plane kernel (bit-exact) and took it out again: slower than triangle by triangle.
+Round 5 built the rule into the bit-plane kernel (bit-exact) and took it out again: slower than triangle by triangle (DESIGN_HISTORY.md section 4).
 The rendering grid still PAIRS the faces (map.hip) and the scan kernel handles a pair at once; the model documents what a paired
 rasteriser has to do.  CPU only.
 """

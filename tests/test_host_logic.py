@@ -331,3 +331,38 @@ def test_reserved_probe_never_raises(monkeypatch):
     monkeypatch.setattr(_ops.nat, 'lib', lambda: type('L', (), dict(tds_device_cu_count=staticmethod(lambda idx, ref: 0)))())
     ok, why = _ops.reserved_layout_ok(torch.device('cuda', 0))
     assert calls == ['rs', 'ms'] and not why.startswith('not verified')
+
+
+def test_map_cache_is_keyed_on_content_and_confirms_a_hit():
+    """_ops.MapCache (round 6: one device map per DISTINCT mesh, shared by simulators, their copies, sub-batches and shards): a hit needs the same
+    key AND the same bytes (the key carries hashes; the rows kept beside the map decide), the least recently used entries go beyond the capacity,
+    a map the cache handed out is `shared` (close() leaves it to its other holders)."""
+    from torchdrivesim_amd import _ops
+
+    class FakeMap:
+        _h = 1
+        closed = False
+
+        def _destroy(self):
+            self.closed = True
+        close = _ops.StaticMap.close
+
+    cache = _ops.MapCache(capacity=2)
+    rows = [torch.arange(6.0).reshape(2, 3), torch.arange(4)]
+    built = []
+
+    def build():
+        built.append(FakeMap())
+        return built[-1]
+
+    a = cache.get(('render', 'cuda:0', (1, 2)), rows, build)
+    assert cache.get(('render', 'cuda:0', (1, 2)), [r.clone() for r in rows], build) is a and len(built) == 1 and (cache.hits, cache.misses) == (1, 1)
+    b = cache.get(('render', 'cuda:0', (1, 2)), [rows[0] + 1, rows[1]], build)          # the same hashes, other bytes: never served the wrong map
+    assert b is not a and len(built) == 2
+    a.close()
+    assert a.shared and not a.closed                                                      # shared maps are not destroyed by one holder's close()
+    cache.get(('render', 'cuda:0', (3, 4)), rows, build)
+    cache.get(('offroad', 'cuda:0', (3, 4)), rows, build)
+    assert len(cache._d) == 2 and len(built) == 4                                         # capacity 2: the oldest entries went
+    cache.clear()
+    assert len(cache._d) == 0

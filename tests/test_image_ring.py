@@ -5,7 +5,7 @@ import torch
 
 from torchdrivesim_amd.rendering import allocate_image_ring
 
-F, M, S, FILL = 7.07, 7.45, 8.3, 7.45          # ms: fast / in-between / slow launches and torch's fill_
+F, M, S, FILL = 7.07, 7.45, 8.3, 7.45          # ms: fast / in-between / slow launches and torch's fill_ (DESIGN_HISTORY.md section 4)
 
 
 class FakeTimer:

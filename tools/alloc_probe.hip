@@ -1,4 +1,4 @@
-// What is a "slow" output allocation?  
+// What is a "slow" output allocation?  (DESIGN_HISTORY.md section 4)
 //
 // A stand-alone reproduction of the WRITE pattern of the headline raster launch -- no rasterisation, no torch: 768 resident workgroups
 // (three per CU, held there by 52 KiB of LDS each), every XCD streams into its own contiguous eighth of a 51.5 GB buffer, a workgroup

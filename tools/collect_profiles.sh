@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the same command without the profiler, before and after the traced run: rocprofv3's tracing slows this kernel by 1 % on some boxes and by 7 - 16 % on
-# others, so the committed trace comes with the plain figures of the same box and minute
+# others (DESIGN_HISTORY.md section 4), so the committed trace comes with the plain figures of the same box and minute
 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_plain_before.log 2>/dev/null
 for try in 1 2; do          # two traced runs: the launch time of this kernel differs from process to process on one box (7.2 - 7.9 ms); both are kept
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof_$try.log 2>&1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the part's HBM takes when a kernel only WRITES: torch's fill_ / zero_ over the 51.5 GB the headline raster launch writes
-(B=1024 x A=64 x 3 x 256 x 256 float32).  DESIGN.md section 4 quotes it beside the raster kernel's launch time on the same box.
+(B=1024 x A=64 x 3 x 256 x 256 float32).  DESIGN_HISTORY.md section 4 quotes it beside the raster kernel's launch time on the same box.
    python tools/fill_bandwidth.py"""
 import torch
 

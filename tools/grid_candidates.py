@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How many grid entries the rasteriser's scan offers per view (CPU, numpy): the map's one grid (every face in all the cells its bounding box
 touches, per-row cell ranges under the rotated view) against a two-level variant (small faces in ONE cell of a four times finer grid scanned with
-the window grown by the cell size).  DESIGN.md section 4, "Two rendering grids": 1 752 against 1 375 candidates for 1 210 accepted faces.
+the window grown by the cell size).  DESIGN_HISTORY.md section 4, "Two rendering grids": 1 752 against 1 375 candidates for 1 210 accepted faces.
    python tools/grid_candidates.py"""
 import numpy as np, sys
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch time of the headline raster kernel into each of several 51.5 GB output tensors of one process, and torch's fill_ over the same tensors
-(an allocation is persistently fast, 7.2 ms, or slow, 8.4 ms, for this kernel; fill_ takes 7.45 ms on both).
+(DESIGN_HISTORY.md section 4: an allocation is persistently fast, 7.2 ms, or slow, 8.4 ms, for this kernel; fill_ takes 7.45 ms on both).
    python tools/output_buffer_speed.py [library.so under tools/scratch | -]"""
 import sys, os, torch, numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where inside a 51.5 GB output allocation does the headline raster kernel lose its time?  (an allocation is
+"""Where inside a 51.5 GB output allocation does the headline raster kernel lose its time?  (DESIGN_HISTORY.md section 4: an allocation is
 persistently "fast", 7.2 ms, or "slow", 8.4 ms, for this kernel while fill_ takes 7.45 ms on both.)
 
 For each of N float32 output tensors of the bench shape, allocated one after the other in a fresh process (optionally behind a filler

@@ -489,6 +489,7 @@ class MapCache:
 
     def get(self, key, rows, build):
         """the cached map of `key` if its stored rows equal `rows` (list of device tensors), else build() -> StaticMap, stored"""
+        key = (key, id(nat.lib()))             # (the testing build is a separate image of the library: its handles stay with it)
         with self._lock:
             ent = self._d.get(key)
             if ent is not None:
@@ -665,7 +666,7 @@ def _raster_workspace(dev, n_img, res, out_mode=None, n_keys=-1):
 # ---- where the images live --------------------------------------------------------------------------------------------------------
 #: The raster launch is bound by the HBM write stream, and what that stream reaches depends on the PHYSICAL pages under the image: about one
 #: large hipMalloc in three is served at 7/8 of the rate for as long as it lives, a buffer whose pages are spread out hardly ever is (one of 100 probed in round 4, in the 15/16 class; csrc/alloc.hip,
-#: DESIGN.md section 4).  So images of SPREAD_MIN bytes and more are not taken from torch's default pool but from a torch memory pool whose
+#: DESIGN_HISTORY.md section 4).  So images of SPREAD_MIN bytes and more are not taken from torch's default pool but from a torch memory pool whose
 #: blocks the library builds (tds_torch_alloc / tds_torch_free behind torch.cuda.memory.CUDAPluggableAllocator): the reference-shaped call
 #: `render_egocentric()` -- a fresh tensor per call, rendering/cv2.py:52 -- gets such a block, cached and stream-ordered by torch's
 #: allocator like any other.  False: plain torch.empty (tests, tools/alloc experiments).

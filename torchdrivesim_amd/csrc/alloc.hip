@@ -9,7 +9,7 @@
 // imbalance over 16 units of the memory system that a physically contiguous range of this size can fall into and a scattered one cannot:
 // 1 GiB contiguous chunks all fill at 5.8 TB/s while the driver's scattered leftovers reach 7.0, and buffers assembled from chunks whose
 // physical addresses are spread over TWICE the range were fast in 18 of 18 probe runs and in 99 of 100 ring candidates of 50 fresh bench starts -- one at 15/16 -- (tools/alloc_probe.hip, profiles/r04_alloc_probe.log, r04_fresh_starts.log;
-// DESIGN.md section 4).  So a buffer is built from chunks of 8 MiB created alternately with spacer chunks that are released once the buffer is
+// DESIGN_HISTORY.md section 4).  So a buffer is built from chunks of 8 MiB created alternately with spacer chunks that are released once the buffer is
 // mapped (hipMemCreate / hipMemMap): the chunks end up about 16 MiB apart in physical memory and the holes go back to the driver.
 //
 // The reference allocates its image per call (rendering/cv2.py:52: np.zeros); here the Python host routes the image allocations of HipRenderer

@@ -2018,7 +2018,7 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, int k, bool acc, unsigned 
 // vertex order; acc1 / acc2: which of them still have to be rasterised) and rasterise the queue whenever it is full.  `flags`: the poly
 // record's.  The rasteriser works triangle by triangle: painting the rows of a pair as one was built and measured in round 5
 // (tests/fill_quads_model.c is the exact rule) and lost -- the third chain and the extra cut rows cost the row items more than the halved
-// row count gives back.
+// row count gives back (DESIGN_HISTORY.md section 4).
 __device__ __forceinline__ void drain_poly(BitCtx &w, bool acc1, bool acc2, uint32_t flags, const uint32_t (&P)[4], bool more) {
     const uint32_t b0 = (flags >> 10) & 3u, b1 = (flags >> 12) & 3u, b2 = (flags >> 14) & 3u;
     // two rounds: the first triangles of all polys, then the second ones (a triangle of the queue is plane | outline edges << 4 + three vertices)

@@ -164,7 +164,7 @@ def allocate_image_ring(render, shape, dtype=torch.float32, device='cuda', count
 
     Why check: the rasteriser is bound by the write stream, and on MI355X what a write stream reaches depends on the PHYSICAL pages under the
     buffer -- a 51.5 GB hipMalloc is served at 1, 15/16 or 7/8 of the rate (7.03 / 7.45 / 8.05 ms per launch) for as long as it lives,
-    about one in three at 7/8, while torch's fill_ takes 7.4 - 7.5 ms on all of them (tools/alloc_probe.hip).  The
+    about one in three at 7/8, while torch's fill_ takes 7.4 - 7.5 ms on all of them (DESIGN_HISTORY.md section 4, tools/alloc_probe.hip).  The
     buffers here come from `_ops.owned_image` -- the library's allocator that spreads the physical pages out (csrc/alloc.hip), which rarely
     produces a slower buffer (one of 100 in round 4, at 15/16 of the rate) -- and every candidate is still MEASURED, against an absolute yardstick of the same run:
         a candidate is fast  iff  its launch takes at most `fast` x the fill_ time (the fastest fill_ seen over the candidates)
