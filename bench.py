@@ -183,8 +183,9 @@ def stamped_traffic(B, A, mode='f32', res=None):
 
 def stamped_limiter(B, A, mode, res=None):
     """What bounds a mode that is NOT bound by HBM, from the PMC passes committed in profiles/raster_traffic.json (same stamp rule as the traffic):
-    dict(bound='valu', valu_busy = share of the SIMDs with a VALU instruction in flight (SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES / 32),
-    cycles_per_valu_instruction, valu_lane_occupancy, ...) -- or dict(bound='valu', note=why there is no figure)."""
+    dict(bound='valu', valu_busy_simds_per_se_of_32 = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES (raw; a saturating add chain reads 47.5),
+    valu_issue_fraction_of_add_chain = that / 47.5, cycles_per_valu_instruction = 4 / the fraction, valu_lane_occupancy, ...) -- or
+    dict(bound='valu', note=why there is no figure)."""
     tpath = os.path.join(ROOT, 'profiles', 'raster_traffic.json')
     ent = json.load(open(tpath)).get(mode) if os.path.exists(tpath) else None
     if not isinstance(ent, dict) or not ent.get('valu'):
@@ -408,7 +409,7 @@ def u8_mode(device, steps, warmup, B, A):
     traffic, note = stamped_traffic(B, A, 'u8')
     del sim, img
     torch.cuda.empty_cache()
-    lim = stamped_limiter(B, A, 'u8')
+    lim = valu_roof(stamped_limiter(B, A, 'u8'), ms)
     return dict(mode='uint8 output (3*H*W bytes per camera)', **lim,
                 bound_note='instruction issue (VALU), not HBM: achieved / peak / frac are the HBM figures of the same launch, for comparison with the float32 mode',
                 achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
@@ -440,11 +441,20 @@ def low_res_mode(device, steps, warmup, B, A, res=128):
     del sim, img
     torch.cuda.empty_cache()
     traffic, note = stamped_traffic(B, A, f'f32_{res}', res=res)
-    lim = stamped_limiter(B, A, f'f32_{res}', res=res)
+    lim = valu_roof(stamped_limiter(B, A, f'f32_{res}', res=res), ms)
     return dict(mode=f'{res}x{res} float32 output', **lim,
                 bound_note='instruction issue (VALU), not HBM: achieved / peak / frac are the HBM figures of the same call, for comparison with the 256 x 256 mode',
                 achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=note,
                 kernel='scan_faces_kernel + raster_list_bits_kernel (the split form of the bit-plane path)', avg_launch_ms=ms, algorithmic_bytes_per_launch=algo)
+
+
+def valu_roof(lim, launch_ms):
+    """adds `frac_of_valu_issue_roof` to a stamped_limiter() entry: the time the launch's VALU instructions take at one per 4 cycles on every SIMD
+    (1 024 SIMDs at 2.4 GHz: the issue rate of wave64 on 16-lane SIMDs; PMC instruction count of the same build) over the launch time measured in
+    THIS run -- the compute-side counterpart of `frac` for a launch that is bound by instruction issue"""
+    if lim.get('valu_issue_ms_at_4_cycles') and launch_ms:
+        lim = dict(lim, frac_of_valu_issue_roof=lim['valu_issue_ms_at_4_cycles'] / launch_ms)
+    return lim
 
 
 def mixed_maps_mode(device, steps, warmup, B, A, overlap, headline_ms, ring):

@@ -107,6 +107,28 @@ def test_traffic_figure_is_refused_for_another_build(tmp_path, monkeypatch):
     assert val is None and 'refused' in note
 
 
+def test_limiter_of_the_instruction_bound_modes_is_stamped_like_the_traffic(tmp_path, monkeypatch):
+    """roofline_u8 / _128 / _64 say bound = 'valu' and quote the PMC-derived VALU figures of profiles/raster_traffic.json -- only for the build and the
+    workload they were measured on"""
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = dict(u8=dict(batch=1024, agents=64, res=256, hbm_bytes_per_launch=1.3e10, kernel_source_sha='feedfacefeedface', source='profiles/x.json',
+                        valu=dict(valu_busy_simds_per_se_of_32=29.3, valu_issue_fraction_of_add_chain=0.617, cycles_per_valu_instruction=6.5, valu_lane_occupancy=0.73, valu_instructions_per_launch=2.75e9, valu_issue_ms_at_4_cycles=4.48)),
+                f32_64=dict(batch=1024, agents=64, res=64, hbm_bytes_per_launch=3.3e9, kernel_source_sha='feedfacefeedface', source='profiles/x.json', valu=None))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles')
+    json.dump(fake, open(tmp_path / 'profiles' / 'raster_traffic.json', 'w'))
+    monkeypatch.setattr(bench, 'kernel_source_stamp', lambda: 'feedfacefeedface')
+    lim = bench.stamped_limiter(1024, 64, 'u8')
+    assert lim['bound'] == 'valu' and lim['valu_busy_simds_per_se_of_32'] == 29.3 and lim['cycles_per_valu_instruction'] == 6.5 and 'x.json' in lim['source']
+    assert bench.stamped_limiter(256, 64, 'u8') == dict(bound='valu', note='PMC figure is for another workload')
+    assert 'no PMC figure' in bench.stamped_limiter(1024, 64, 'f32_64', res=64)['note']          # an entry without VALU counters
+    assert 'no PMC figure' in bench.stamped_limiter(1024, 64, 'f32_128', res=128)['note']
+    monkeypatch.setattr(bench, 'kernel_source_stamp', lambda: 'deadbeefdeadbeef')
+    lim = bench.stamped_limiter(1024, 64, 'u8')
+    assert lim['bound'] == 'valu' and 'refused' in lim['note'] and 'valu_issue_fraction_of_add_chain' not in lim
+
+
 def test_a_dying_worker_ends_the_launch_promptly():
     """rank 1 exits at start-up while rank 0 waits for it in the rendezvous: the launcher polls its children, reports the failure and
     ends rank 0 instead of waiting for the timeout"""

@@ -116,7 +116,10 @@ for mode, bpp, mres in (('f32', 4, RES), ('u8', 1, RES), ('f32_128', 4, 128), ('
     # work per instruction, and the time the VALU instructions alone take on 1 024 SIMDs at 2.4 GHz
     valu = None
     if ent['valu_busy_simds_per_se_of_32'] is not None:
-        valu = dict(valu_busy=ent['valu_busy_simds_per_se_of_32'] / 32.0,
+        # valu_busy_simds_per_se_of_32 is the RAW quantity SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES ("SIMDs of a shader engine with a VALU instruction
+        # in flight"); it is not bounded by 32 -- a saturating dependent add chain reads 47.5 (profiles/r04_valu_calibration.log) -- so the calibrated
+        # figure beside it, valu_issue_fraction_of_add_chain = raw / 47.5, is the one to read as "how busy"
+        valu = dict(valu_busy_simds_per_se_of_32=ent['valu_busy_simds_per_se_of_32'], valu_issue_fraction_of_add_chain=ent['valu_issue_fraction_of_add_chain'],
                     cycles_per_valu_instruction=4.0 / ent['valu_issue_fraction_of_add_chain'] if ent['valu_issue_fraction_of_add_chain'] else None,
                     valu_lane_occupancy=ent['valu_lane_occupancy'],
                     valu_instructions_per_launch=c.get('SQ_INSTS_VALU'),
