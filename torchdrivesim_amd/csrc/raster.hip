@@ -2016,9 +2016,8 @@ __device__ __forceinline__ void drain_bits(BitCtx &w, int k, bool acc, unsigned 
 
 // Queue the triangles of the poly records K3r reads from its camera's list (at most one poly per lane: one or two triangles, each in its own
 // vertex order; acc1 / acc2: which of them still have to be rasterised) and rasterise the queue whenever it is full.  `flags`: the poly
-// record's.  The rasteriser works triangle by triangle: painting the rows of a pair as one was built and measured in round 5
-// (tests/fill_quads_model.c is the exact rule) and lost -- the third chain and the extra cut rows cost the row items more than the halved
-// row count gives back (DESIGN_HISTORY.md section 4).
+// record's.  The rasteriser works triangle by triangle (painting the rows of a pair as one is exact -- tests/fill_quads_model.c -- and slower:
+// DESIGN_HISTORY.md, appendix R1).
 __device__ __forceinline__ void drain_poly(BitCtx &w, bool acc1, bool acc2, uint32_t flags, const uint32_t (&P)[4], bool more) {
     const uint32_t b0 = (flags >> 10) & 3u, b1 = (flags >> 12) & 3u, b2 = (flags >> 14) & 3u;
     // two rounds: the first triangles of all polys, then the second ones (a triangle of the queue is plane | outline edges << 4 + three vertices)
@@ -2377,8 +2376,8 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
         }
         for (int i = tid * 4; i < plane_dw; i += BBLOCK * 4) *(uint4 *)(planes + i) = make_uint4(0, 0, 0, 0);
         if (tid == 15) lkeys[15] = (uint32_t)BWAVES;
-        // uint8 output (the kernel is bound by instruction issue): waves that rasterise take precedence over the waves of other workgroups that
-        // are streaming out (measured: -2 %).  float32 output is bound by the HBM write stream: there the raise costs 2 % (7.41 -> 7.23 ms median)
+        // uint8 output (bound by instruction issue): waves that rasterise take precedence over waves of other workgroups that are streaming out;
+        // float32 output is bound by the write stream and loses by the raise (DESIGN_HISTORY.md, appendix R2)
         if constexpr (sizeof(OutT) != 4) __builtin_amdgcn_s_setprio(1);
         w.eq_head = 0; w.eq_count = 0;
         w.slots[lane] = 0;
@@ -2400,9 +2399,8 @@ __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_s
             make_polygon(cam, ci.scale, ci.res);
         }
         __syncthreads();
-        // (the fused kernel walks the grid of single triangles: the 48-byte entries of the grid with paired faces cost it four more registers
-        // for the chunk in flight, and it has none to spare -- measured on one box, uint8 256 x 256: 5.09 ms with triangles, 5.53 with pairs;
-        // the split form, whose scan kernel holds nothing else, takes the pairs: scan_faces_kernel)
+        // (the fused kernel walks the grid of single triangles: the 48-byte entries of the grid with paired faces cost it four more registers for
+        // the chunk in flight, which it does not have -- DESIGN_HISTORY.md, appendix R3; the split form's scan kernel takes the pairs)
         ScanState st;
         scan_init(st, a, ci, cam, img, lane, wave, X0, TWp);
         st.dyn = lkeys + 15;
@@ -2453,9 +2451,8 @@ constexpr int SMALL_TALL_RES = TDS_SMALL_TALL_RES;      // from this resolution 
 constexpr int SCAN_DEPTH = TDS_SCAN_DEPTH;    // chunks of 64 grid entries whose loads K3s keeps in flight
 constexpr uint32_t LIST_POISON = 0xffffffffu;
 
-// (chunks in flight x waves per SIMD the registers are cut for, ms at B = 1024 x 64, round 3, 32-byte triangle entries: 4 x 3 1.18, 4 x 4 0.98,
-// 3 x 5 0.87, 2 x 6 0.85, 2 x 8 1.00; round 5, 48-byte entries of the rendering grid with paired faces -- half as many, 12 registers each --:
-// 2 x 6 1.35 (468 bytes of scratch per lane), 1 x 8 0.97, 1 x 6 0.85, 2 x 4 0.78, 1 x 5 0.72)
+// (SCAN_DEPTH chunks in flight x TDS_SCAN_OCC waves per SIMD: the sweep is DESIGN_HISTORY.md, appendix R4; 1 x 5 is its optimum and
+// tests/test_kernel_resources.py holds the kernel to the 112 bytes of scratch it has there)
 template <typename SA>
 __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kernel(SA a, CommonArgs c, KeyTable kt, uint32_t *__restrict__ counts, uint4 *__restrict__ lists,
                                                                      uint32_t *__restrict__ lists3, int caps, uint32_t *__restrict__ poisoned) {
@@ -2567,12 +2564,9 @@ __global__ void __launch_bounds__(SCAN_WAVES * 64, TDS_SCAN_OCC) scan_faces_kern
     }
 }
 
-// (60 VGPRs with uint8 output, 72 - 79 with float32: LDS, not registers, sets how many workgroups share a CU.  NOT a persistent launch:
-// the loop over the items costs 30 VGPRs -- 111 instead of 75 -- and with them a fifth of the waves: 64 x 64 2.8 -> 3.2 ms)
-// BWAVES: wavefronts per workgroup.  A 64 x 64 camera holds five chunks of faces per wave of four: too little to keep four waves in step
-// between the barriers of a workgroup (SQ_WAIT_ANY 40 % of the wave cycles) -- small images get fewer waves per workgroup and more workgroups.
-// (Round 5: registers cut for seven / eight waves per SIMD -- 72 / 64 VGPRs instead of 77 - 82, a few spills --: 64 x 64 2.25 -> 2.22 / 2.22 ms, 128 x 128 3.12 -> 3.07 / 3.38,
-//  uint8 192 x 192 4.12 -> 4.16 / 4.31: within the noise or worse, not taken.)
+// K3r.  75 - 81 VGPRs, no scratch: LDS, not registers, sets how many workgroups share a CU.  NOT a persistent launch (the loop over the items
+// costs 30 VGPRs and a fifth of the waves).  BWAVES: wavefronts per workgroup -- a small image holds too few chunks of faces to keep four waves in
+// step between the barriers of a workgroup, so small images get two waves per workgroup and more workgroups.  (Sweeps: DESIGN_HISTORY.md, appendix R5.)
 template <int NB, typename OutT, int BWAVES>
 __global__ void __launch_bounds__(BWAVES * 64) raster_list_bits_kernel(CommonArgs c, KeyTable kt, int TWp, const uint32_t *__restrict__ counts,
                                                                       const uint4 *__restrict__ lists, const uint32_t *__restrict__ lists3, int caps) {
@@ -2689,9 +2683,8 @@ inline uint32_t *workspace_queue(void *workspace, int64_t &bytes) {
     return (uint32_t *)((char *)workspace + off);
 }
 // workgroups of a persistent launch: exactly as many as are resident at a time -- three per CU (168 VGPRs: three waves per SIMD), fewer when
-// the LDS of one exceeds a third of the CU's 160 KiB.  Rounds 3 launched 8 per CU ("a surplus takes the place of workgroups that could
-// not start with the others"): a workgroup that cannot start waits in the dispatcher either way, and the waiting surplus costs -- measured
-// in round 4 (same box, debug flag 65536 = the old surplus): float32 B = 1024 7.02 -> 6.97 ms, uint8 5.20 -> 5.10, B = 256 1.88 -> 1.81.
+// the LDS of one exceeds a third of the CU's 160 KiB.  (A surplus of waiting workgroups costs: DESIGN_HISTORY.md, appendix R6; fewer than the
+// resident number, or head / tail items in strips, do not pay either: profiles/r06_tail_attempts.log.)
 #ifdef TDS_TESTING
 int g_debug = 0;
 #endif
@@ -3047,11 +3040,7 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
                         // waves per workgroup of K3r: by the pixels of a strip (testing hook: g_list_waves)
                         int lw = g_list_waves;
                         int tws = (res + 31) & ~31;
-                        // (ms at B = 1024 x 64 with 1 / 2 / 4 waves: 32 x 32 2.30 / 2.33 / 2.45, 64 x 64 2.53 / 2.45 / 2.59, 96 x 96 3.32 / 2.89 / 3.03, 128 x 128 4.75 / 3.80 / 3.57)
-                        // (round 5, poly records: uint8 112 x 112 2.71 / 3.04, 128 2.84 / 3.08, 144 3.34 / 3.29, 160 3.62 / 3.39; float32 112 3.11 / 3.14, 128 3.23 / 3.15.
-                        //  Tried on the record loop of K3r and dropped: a chunk of 32 records with a lane per TRIANGLE instead of 64 records with a lane per
-                        //  record (64 x 64 2.27 -> 2.44 ms, 128 x 128 3.38 -> 3.65: two triangles per lane interleave, one per lane waits); the records of
-                        //  the next chunk requested one iteration ahead (2.17 -> 2.26, 3.09 -> 3.28: the pre-claimed chunk unbalances the waves' tails))
+                        // (two waves up to 104 x 104 float32 / 128 x 128 uint8 pixels of a strip, four above: the sweep is DESIGN_HISTORY.md, appendix R7)
                         if (lw == 0) lw = (int64_t)res * tws <= (f32 ? 104 * 104 : 128 * 128) ? 2 : 4;
                         while (tws > 32 && bits_lds_bytes(kt.n, res, tws, lw, out_mode) > (size_t)g_list_lds_kb * 1024) tws -= 32;
                         const size_t lds_s = bits_lds_bytes(kt.n, res, tws, lw, out_mode);
