@@ -18,7 +18,9 @@ def scene_shard(total_scenes: int, rank: int, world_size: int) -> Tuple[int, int
 
 
 def shard_simulator(sim, rank: int, world_size: int):
-    """A new Simulator holding only this rank's scenes (pure batch-axis selection; the static map handle is rebuilt lazily)."""
+    """A new Simulator holding only this rank's scenes (pure batch-axis selection, simulator.py:480-511 of the reference).  The shard's device maps
+    are found again by content in the process-wide cache (`_ops.map_cache`: one map per DISTINCT mesh), so sharding on the device that already
+    holds the maps creates none; a rank that shards on its own device builds one map per distinct mesh of ITS scenes."""
     start, stop = scene_shard(sim.batch_size, rank, world_size)
     return sim.select_batch_elements(list(range(start, stop)), in_place=False)
 
