@@ -324,6 +324,10 @@ def other_configs(device, steps, warmup, only=None, overlap='reserved', overlap_
         if ring is not None:
             ent['ring_probe'] = dict(launch_ms=ring_rep['launch_ms'], fast=ring_rep['fast'], kept=ring_rep['kept'], fill_ms=ring_rep['fill_ms'], yardstick=ring_rep['yardstick'])
             ent['overlap'] = mode
+            # what torch's fill_ takes over the very buffers of this loop: at B = 256 the raster launch beats it (a 12.9 GB write burst is short for
+            # this memory system: profiles/r06_tail_attempts.log), so the launch's fraction of the 8 TB/s is read beside this figure
+            ent['same_buffer_fill_ms'] = ring_rep['fill_ms']
+            ent['raster_launch_over_fill'] = None if not k_fwd else k_fwd / ring_rep['fill_ms']
         else:
             # autograd owns the image of the differentiable step: a fresh tensor per step from the image pool (spread-out physical pages)
             ent['image_allocation'] = 'per step, torch memory pool over tds_torch_alloc (csrc/alloc.hip)'
