@@ -57,3 +57,50 @@ def test_a_captured_step_replays_bit_for_bit(overlap):
         assert torch.equal(img, want[0]) and torch.equal(col, want[1]) and torch.equal(off, want[2]) and torch.equal(new, want[3])
         assert bool(img.flatten(2).amax(-1).gt(0).all())
         state.copy_(state_next)                           # the next replay continues from here
+
+
+def test_a_captured_differentiable_step_replays_with_the_eager_gradients():
+    """Forward AND backward of BASELINE config 5's step -- kinematics, rasteriser (index slices + its backward), IoU collision, off-road -- captured
+    into one HIP graph (round 6): nothing in the library's autograd functions allocates outside torch's allocator or
+    synchronises, so `torch.autograd.grad` inside `torch.cuda.graph` records the whole step; replays give the eager gradients (to the
+    reproducibility of the collision backward's LDS float atomics).  (Measured at B = 256: the replay is not faster than the eager loop on
+    ROCm 7.0 -- 9.85 against 9.60 ms per step incl. the loss probe, tools/config5_graph_probe.py -- so bench.py keeps config 5 eager.)"""
+    import bench
+    from torchdrivesim_amd.utils import Resolution
+    dev = torch.device(DEV)
+    B, A = 12, 64
+    res = Resolution(256, 256)
+    sim, actions, _ = bench.build_simulator(B, A, dev, seed=33)
+    state0 = sim.get_state().clone()
+    w = torch.rand(B, A, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+
+    def fwd_bwd(s0, act):
+        sim.kinematic_model.set_state(s0)
+        sim.step(act)
+        img = sim.render_egocentric(res=res, fov=35.0)
+        col, off = sim.compute_collision(), sim.compute_offroad()
+        loss = (img * w).sum() / 255.0 + col.sum() + (off * off).sum()
+        return torch.autograd.grad(loss, [s0, act]) + (col.detach(), off.detach())
+
+    s_in = state0.clone().requires_grad_(True)
+    a_in = actions[0].clone().requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fwd_bwd(s_in, a_in)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd_bwd(s_in, a_in)
+    for i in range(3):
+        with torch.no_grad():
+            a_in.copy_(actions[i + 1])
+        g.replay()
+        torch.cuda.synchronize()
+        want = fwd_bwd(state0.clone().requires_grad_(True), actions[i + 1].clone().requires_grad_(True))
+        assert torch.equal(out[2], want[2]) and torch.equal(out[3], want[3])                  # forward values: bit for bit
+        for x, y in zip(want[:2], out[:2]):
+            assert torch.isfinite(y).all() and float(x.abs().max()) > 0
+            torch.testing.assert_close(y, x, rtol=1e-5, atol=1e-6 * float(x.abs().max()))
