@@ -263,7 +263,7 @@ def other_configs(device, steps, warmup, only=None, overlap='reserved', overlap_
         ring = None
         # as the headline: the loop's stream is kept off four CUs per XCD, the metrics run beside the raster launch on those.  The differentiable
         # configuration can fork too since round 6 (its metric nodes are autograd nodes of the side stream, so their backward runs beside the
-        # rasteriser's; same gradients up to the LDS float atomics of the collision backward: tests/test_gpu_simulator.py) but gains nothing from it at this size -- measured on one box, ms per step:
+        # rasteriser's; same gradients bit for bit: tests/test_gpu_simulator.py) but gains nothing from it at this size -- measured on one box, ms per step:
         # off 4.070 / 4.074, 'stream' 4.090 / 4.076, 'reserved' 4.115 (its backward kernel is not bound by the write stream and pays for the CUs
         # 'reserved' keeps it off; profiles/r06_config5_overlap.log) -- so `overlap_diff` defaults to off
         mode = overlap_diff if name.startswith('config5') else overlap

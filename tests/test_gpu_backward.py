@@ -116,3 +116,36 @@ def test_collision_gradient_of_a_large_scene_equals_that_of_its_far_apart_halves
         (o * wgt[:, sl].to(DEV)).sum().backward()
         assert part.grad.abs().max().item() > 0
         torch.testing.assert_close(whole.grad[:, sl], part.grad, rtol=1e-5, atol=1e-6 * part.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('metric', ['iou', 'discs'])
+def test_collision_gradient_of_a_scene_is_bit_reproducible(metric):
+    """The whole-scene collision backward is deterministic since round 6 (it summed per box with LDS float atomics in arrival order: an ulp of a
+    gradient moved from run to run): near list in pair order, a slot per pair, every box collects its contributions in a fixed order.  Ten
+    runs of the same backward give the same bits -- on a sparse scene and on a DENSE one (64 agents within a few metres: about 4 000 near pairs, worked
+    off in several chunks of the 1 024-pair table) -- and the dense gradients agree with the row kernel's (one wavefront per row, atomics) to rounding."""
+    from torchdrivesim_amd import _ops
+    gen = torch.Generator().manual_seed(5)
+    for spread, B, A in ((60.0, 8, 64), (6.0, 4, 64)):
+        xy = (torch.rand(B, A, 2, generator=gen) - 0.5) * spread
+        boxes = torch.cat([xy, 4 + torch.rand(B, A, 1, generator=gen), 1.8 + 0.4 * torch.rand(B, A, 1, generator=gen), (torch.rand(B, A, 1, generator=gen) - 0.5) * 6], -1).to(DEV)
+        present = (torch.rand(B, A, generator=gen) > 0.1).to(DEV)
+        wgt = torch.rand(B, A, generator=gen).to(DEV)
+
+        def grad(t):
+            t = t.clone().requires_grad_(True)
+            out = _ops.collision(t, present, metric=metric)
+            (out * wgt).sum().backward()
+            return out.detach(), t.grad
+
+        out, first = grad(boxes)
+        assert (out > 0).sum().item() > 10 and first.abs().max().item() > 0 and torch.isfinite(first).all()
+        for _ in range(9):
+            assert torch.equal(grad(boxes)[1], first)
+        if spread < 10:
+            # the same scene as rows of a scene too large for the whole-scene kernel (65 x 64 > 4096 pairs: one extra box, absent and far away)
+            far = torch.tensor([1.0e4, 1.0e4, 4.0, 2.0, 0.0], device=DEV).expand(B, 1, 5)
+            big = torch.cat([boxes, far], 1).clone().requires_grad_(True)
+            o2 = _ops.collision(big, torch.cat([present, torch.zeros(B, 1, dtype=torch.bool, device=DEV)], 1), metric=metric)
+            (o2[:, :A] * wgt).sum().backward()
+            torch.testing.assert_close(big.grad[:, :A], first, rtol=2e-4, atol=2e-5 * first.abs().max().item())

@@ -62,8 +62,7 @@ def test_a_captured_step_replays_bit_for_bit(overlap):
 def test_a_captured_differentiable_step_replays_with_the_eager_gradients():
     """Forward AND backward of BASELINE config 5's step -- kinematics, rasteriser (index slices + its backward), IoU collision, off-road -- captured
     into one HIP graph (round 6): nothing in the library's autograd functions allocates outside torch's allocator or
-    synchronises, so `torch.autograd.grad` inside `torch.cuda.graph` records the whole step; replays give the eager gradients (to the
-    reproducibility of the collision backward's LDS float atomics).  (Measured at B = 256: the replay is not faster than the eager loop on
+    synchronises, so `torch.autograd.grad` inside `torch.cuda.graph` records the whole step; replays give the eager gradients.  (Measured at B = 256: the replay is not faster than the eager loop on
     ROCm 7.0 -- 9.85 against 9.60 ms per step incl. the loss probe, tools/config5_graph_probe.py -- so bench.py keeps config 5 eager.)"""
     import bench
     from torchdrivesim_amd.utils import Resolution

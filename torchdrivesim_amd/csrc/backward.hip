@@ -297,16 +297,22 @@ __global__ void __launch_bounds__(GBLOCK) collision_bwd_kernel(const float *__re
 // Whole scene per workgroup (the backward of collision_scene_iou_kernel): with one wavefront per row the pair function ran twice per
 // row for the handful of lanes whose partner is near (0.22 ms at B = 256 x 64 x 64 against 0.026 ms for the forward).  Here the near
 // pairs of the scene's rows that carry a gradient are gathered into an LDS list first and evaluated on full waves: overlaps ->
-// arg-max per row (first index on ties) -> gradients of every near pair but the row's maximum, accumulated per box in LDS (the
-// scene's boxes belong to this workgroup alone: no global atomics, no zeroing beforehand) and stored once.  Same pair functions, same rules as
-// collision_bwd_kernel; only the order in which a box's contributions are added differs (it was not fixed there either).
-// LDS: boxes N x 6, sums N x 6, gout / arg-max A, overlaps A x N (float), the pair list A x N (uint16).
+// arg-max per row (first index on ties) -> gradients of every near pair but the row's maximum, summed per box and stored once (the
+// scene's boxes belong to this workgroup alone: no global atomics, no zeroing beforehand).  Same pair functions, same rules as
+// collision_bwd_kernel.
+// DETERMINISTIC since round 6 (it used ds_add_f32 in arrival order: an ulp of a gradient moved from run to run): the near list is built
+// in pair order (ballot + prefix over the waves, not an atomic counter), every listed pair leaves its two box gradients in a slot of an
+// LDS table, and one thread per box adds its box's contributions in a fixed order -- its row's pairs by partner, then the pairs of the
+// other rows that have it as partner, by row -- found through a pair -> slot map.  Lists longer than the table are worked off in chunks,
+// in list order.
+// LDS: boxes N x 6, sums N x 6, gout / arg-max A, overlaps A x N (float), the pair list A x N (uint16), the slot map A x N (uint16),
+// the gradient table `cap` x 12.
 template <int METRIC>
-__global__ void __launch_bounds__(GBLOCK) collision_scene_bwd_kernel(const float *__restrict__ boxes, const float *__restrict__ sc,
+__global__ void __launch_bounds__(GBLOCK, 2) collision_scene_bwd_kernel(const float *__restrict__ boxes, const float *__restrict__ sc,
                                                                      const uint8_t *__restrict__ present, const float *__restrict__ gout,
-                                                                     float *__restrict__ gboxes, float *__restrict__ gsc, int A, int N) {
+                                                                     float *__restrict__ gboxes, float *__restrict__ gsc, int A, int N, int cap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int n_near;
+    __shared__ int wave_cnt[2][GBLOCK / 64];               // (two sets, used in turn: one barrier per round of the list build)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b = blockIdx.x;
     float *bx = smem;                                       // N x 6
@@ -315,7 +321,8 @@ __global__ void __launch_bounds__(GBLOCK) collision_scene_bwd_kernel(const float
     int *arg = (int *)(go + A);                             // A
     float *O = (float *)(arg + A);                          // A x N
     uint16_t *list = (uint16_t *)(O + A * N);               // A x N at most (A x N <= 4096)
-    if (tid == 0) n_near = 0;
+    uint16_t *slot = list + A * N;                          // A x N: pair -> place in the list (0xffff: not listed)
+    float *pg = (float *)(slot + A * N);                    // cap x 12: the box gradients of the listed pairs of the current chunk (list + slot: 4 A N bytes)
     for (int j = tid; j < N; j += GBLOCK) {
         const Box q = load_box(boxes, sc, b * N + j);
         bx[6 * j] = q.x; bx[6 * j + 1] = q.y; bx[6 * j + 2] = q.l; bx[6 * j + 3] = q.w; bx[6 * j + 4] = q.s; bx[6 * j + 5] = q.c;
@@ -324,13 +331,28 @@ __global__ void __launch_bounds__(GBLOCK) collision_scene_bwd_kernel(const float
     for (int i = tid; i < A; i += GBLOCK) go[i] = gout[b * A + i];
     __syncthreads();
     auto box_at = [&](int j) { Box q; q.x = bx[6 * j]; q.y = bx[6 * j + 1]; q.l = bx[6 * j + 2]; q.w = bx[6 * j + 3]; q.s = bx[6 * j + 4]; q.c = bx[6 * j + 5]; return q; };
-    for (int p = tid; p < A * N; p += GBLOCK) {
-        const int i = p / N, j = p - i * N;
-        O[p] = 0.0f;
-        if (go[i] != 0.0f && circles_touch(box_at(i), box_at(j))) list[atomicAdd(&n_near, 1)] = (uint16_t)p;
+    // the near pairs of the rows that carry a gradient, IN PAIR ORDER
+    int total = 0;                                          // (the same in every thread)
+    for (int p0 = 0, round = 0; p0 < A * N; p0 += GBLOCK, round ^= 1) {
+        const int p = p0 + tid;
+        bool near = false;
+        if (p < A * N) {
+            const int i = p / N, j = p - i * N;
+            O[p] = 0.0f;
+            near = go[i] != 0.0f && circles_touch(box_at(i), box_at(j));
+        }
+        const unsigned long long bm = __ballot(near);
+        if (lane == 0) wave_cnt[round][wave] = __popcll(bm);
+        __syncthreads();                                    // (the other set is not written again before every wave has passed the next barrier)
+        int before = total, all = 0;
+#pragma unroll
+        for (int w = 0; w < GBLOCK / 64; ++w) { before += w < wave ? wave_cnt[round][w] : 0; all += wave_cnt[round][w]; }
+        const int q = before + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+        if (p < A * N) slot[p] = near ? (uint16_t)q : (uint16_t)0xffffu;
+        if (near) list[q] = (uint16_t)p;
+        total += all;
     }
     __syncthreads();
-    const int total = n_near;
     BoxGrad dummy1 = {0, 0, 0, 0, 0, 0}, dummy2 = {0, 0, 0, 0, 0, 0};
     for (int q = tid; q < total; q += GBLOCK) {
         const int p = (int)list[q], i = p / N, j = p - i * N;
@@ -356,29 +378,48 @@ __global__ void __launch_bounds__(GBLOCK) collision_scene_bwd_kernel(const float
         if (lane == 0) arg[i] = am;
     }
     __syncthreads();
-    // d(sum - max) / d o_ij = present_j * (1 - [j == arg])
-    for (int q = tid; q < total; q += GBLOCK) {
-        const int p = (int)list[q], i = p / N, j = p - i * N;
-        if (j == arg[i] || !present[b * N + j]) continue;
-        const Box b1 = box_at(i), b2 = box_at(j);
-        BoxGrad gi = {0, 0, 0, 0, 0, 0}, gj = {0, 0, 0, 0, 0, 0};
-        const float o = METRIC == TDS_METRIC_IOU ? iou_pair_bwd(b1, b2, go[i], gi, gj, true) : discs_pair_bwd(b1, b2, go[i], gi, gj, true);
-        if (!(o == o)) continue;                                     // nan_to_num: no gradient through a scrubbed NaN
-        float *ai = acc + 6 * i, *aj = acc + 6 * j;
-        if (gi.x != 0.0f) atomicAdd(ai + 0, gi.x);
-        if (gi.y != 0.0f) atomicAdd(ai + 1, gi.y);
-        if (gi.l != 0.0f) atomicAdd(ai + 2, gi.l);
-        if (gi.w != 0.0f) atomicAdd(ai + 3, gi.w);
-        if (gi.s != 0.0f) atomicAdd(ai + 4, gi.s);
-        if (gi.c != 0.0f) atomicAdd(ai + 5, gi.c);
-        if (gj.x != 0.0f) atomicAdd(aj + 0, gj.x);
-        if (gj.y != 0.0f) atomicAdd(aj + 1, gj.y);
-        if (gj.l != 0.0f) atomicAdd(aj + 2, gj.l);
-        if (gj.w != 0.0f) atomicAdd(aj + 3, gj.w);
-        if (gj.s != 0.0f) atomicAdd(aj + 4, gj.s);
-        if (gj.c != 0.0f) atomicAdd(aj + 5, gj.c);
+    // d(sum - max) / d o_ij = present_j * (1 - [j == arg]); chunk by chunk of the list: the pairs' gradients into the table, then every box
+    // collects its own in a fixed order
+    for (int q0 = 0; q0 < total; q0 += cap) {
+        const int nq = min(cap, total - q0);
+        for (int q = tid; q < nq; q += GBLOCK) {
+            const int p = (int)list[q0 + q], i = p / N, j = p - i * N;
+            BoxGrad gi = {0, 0, 0, 0, 0, 0}, gj = {0, 0, 0, 0, 0, 0};
+            if (j != arg[i] && present[b * N + j]) {
+                const Box b1 = box_at(i), b2 = box_at(j);
+                const float o = METRIC == TDS_METRIC_IOU ? iou_pair_bwd(b1, b2, go[i], gi, gj, true) : discs_pair_bwd(b1, b2, go[i], gi, gj, true);
+                if (!(o == o)) { gi = dummy1; gj = dummy1; }             // nan_to_num: no gradient through a scrubbed NaN
+            }
+            float *t = pg + 12 * q;
+            t[0] = gi.x; t[1] = gi.y; t[2] = gi.l; t[3] = gi.w; t[4] = gi.s; t[5] = gi.c;
+            t[6] = gj.x; t[7] = gj.y; t[8] = gj.l; t[9] = gj.w; t[10] = gj.s; t[11] = gj.c;
+        }
+        __syncthreads();
+        // four threads per box, each a fixed quarter of the box's candidates (its row's pairs by partner: two halves; the other rows' pairs that
+        // have it as partner, by row: two halves), combined in a fixed tree: (a + b) + (c + d), then onto the box's sum so far
+        for (int kk = tid; kk < 4 * N; kk += GBLOCK) {
+            const int k = kk >> 2, part = kk & 3;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
+            auto take = [&](int p, int off) {
+                const int q = (int)slot[p] - q0;
+                if ((unsigned)q < (unsigned)nq) {               // listed (0xffff is beyond every chunk: total <= 4096) and in this chunk
+                    const float *t = pg + 12 * q + off;
+                    s0 += t[0]; s1 += t[1]; s2 += t[2]; s3 += t[3]; s4 += t[4]; s5 += t[5];
+                }
+            };
+            if (part < 2) {
+                if (k < A) { const int h = (N + 1) >> 1; for (int j = part * h; j < min(N, (part + 1) * h); ++j) take(k * N + j, 0); }      // the first box of the pair (k, j)
+            } else {
+                const int h = (A + 1) >> 1;
+                for (int i = (part - 2) * h; i < min(A, (part - 1) * h); ++i) take(i * N + k, 6);                                         // the second box of the pair (i, k)
+            }
+            // lanes 4 k .. 4 k + 3 of one wave hold the box's four partial sums
+            auto tree = [&](float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; };
+            s0 = tree(s0); s1 = tree(s1); s2 = tree(s2); s3 = tree(s3); s4 = tree(s4); s5 = tree(s5);
+            if (part == 0) { acc[6 * k] += s0; acc[6 * k + 1] += s1; acc[6 * k + 2] += s2; acc[6 * k + 3] += s3; acc[6 * k + 4] += s4; acc[6 * k + 5] += s5; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int j = tid; j < N; j += GBLOCK) {                  // every element of both outputs (the heading's gradient flows through grad_sc)
         float *gb = gboxes + (b * N + j) * 5, *gs = gsc + (b * N + j) * 2;
         gb[0] = acc[6 * j]; gb[1] = acc[6 * j + 1]; gb[2] = acc[6 * j + 2]; gb[3] = acc[6 * j + 3]; gb[4] = 0.0f;
@@ -661,14 +702,17 @@ TDS_EXPORT int tds_collision_bwd_f32(const float *boxes, const float *sc, const 
     if (A == 0) return zero_outputs();
     TDS_CHECK_ARG(boxes && sc && present && grad_out, "tds_collision_bwd_f32: null pointer");
     // whole scene per workgroup where its tables fit (see collision_scene_bwd_kernel); one wavefront per (scene, agent) otherwise
-    const size_t lds_scene = ((size_t)N * 12 + 2 * (size_t)A + (size_t)A * N) * sizeof(float) + (size_t)A * N * sizeof(uint16_t);
-    if (A * N <= 4096 && lds_scene + 64 <= 64 * 1024) {              // + the kernel's static words (n_near): the sum must fit the 64 KiB a launch gets by default
-        if (metric == TDS_METRIC_IOU)
-            hipLaunchKernelGGL(collision_scene_bwd_kernel<TDS_METRIC_IOU>, dim3((unsigned)B), dim3(GBLOCK), lds_scene, (hipStream_t)stream, boxes, sc,
-                               present, grad_out, grad_boxes, grad_sc, (int)A, (int)N);
-        else
-            hipLaunchKernelGGL(collision_scene_bwd_kernel<TDS_METRIC_DISCS>, dim3((unsigned)B), dim3(GBLOCK), lds_scene, (hipStream_t)stream, boxes, sc,
-                               present, grad_out, grad_boxes, grad_sc, (int)A, (int)N);
+    const size_t lds_base = ((size_t)N * 12 + 2 * (size_t)A + (size_t)A * N) * sizeof(float) + 2 * (size_t)A * N * sizeof(uint16_t);
+    if (A * N <= 4096 && lds_base <= 96 * 1024) {
+        // the gradient table: as many pairs as fit beside the rest in 144 KiB (a workgroup per scene at 206 VGPRs: two per CU either way), 256 .. 1024
+        int64_t cap = ((int64_t)(144 * 1024) - (int64_t)lds_base) / 48;
+        cap = std::max<int64_t>(256, std::min<int64_t>(1024, cap & ~(int64_t)255));
+        const size_t lds_scene = lds_base + (size_t)cap * 48;
+        auto launch = [&](auto kern) {
+            if (lds_scene + 64 > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scene);
+            hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(GBLOCK), lds_scene, (hipStream_t)stream, boxes, sc, present, grad_out, grad_boxes, grad_sc, (int)A, (int)N, (int)cap);
+        };
+        if (metric == TDS_METRIC_IOU) launch(collision_scene_bwd_kernel<TDS_METRIC_IOU>); else launch(collision_scene_bwd_kernel<TDS_METRIC_DISCS>);
         TDS_LAUNCH_CHECK("collision_scene_bwd_kernel");
         return TDS_OK;                                                         // (that kernel writes every element of both outputs)
     }
