@@ -90,11 +90,11 @@ def test_collision_gradient_finite_differences():
 
 @pytest.mark.parametrize('metric', ['iou', 'discs'])
 def test_collision_gradient_of_a_large_scene_equals_that_of_its_far_apart_halves(metric):
-    """Scenes of up to 4096 pairs take the whole-scene backward kernel, larger ones one wavefront per row: a scene of 96 agents in two
-    clusters a kilometre apart (row kernel) must give each cluster the gradients it gets as a scene of its own (scene kernel)."""
+    """Scenes of up to 16 384 pairs take the whole-scene backward kernel, larger ones one wavefront per row: a scene of 132 agents in two
+    clusters a kilometre apart (17 424 pairs: row kernel) must give each cluster the gradients it gets as a scene of its own (scene kernel)."""
     from torchdrivesim_amd import _ops
     gen = torch.Generator().manual_seed(11)
-    B, H = 3, 48
+    B, H = 3, 66
     def cluster():
         xy = (torch.rand(B, H, 2, generator=gen) - 0.5) * 40
         return torch.cat([xy, 4 + torch.rand(B, H, 1, generator=gen), 1.8 + 0.4 * torch.rand(B, H, 1, generator=gen),
@@ -142,10 +142,25 @@ def test_collision_gradient_of_a_scene_is_bit_reproducible(metric):
         assert (out > 0).sum().item() > 10 and first.abs().max().item() > 0 and torch.isfinite(first).all()
         for _ in range(9):
             assert torch.equal(grad(boxes)[1], first)
+        # exposed agents among more boxes (NPCs: 64 x 100 = 6 400 pairs, beyond the forward scene kernel's 4 096): the same kernel, the same bits every run
+        npc = torch.cat([(torch.rand(B, 36, 2, generator=gen) - 0.5) * spread, 4 + torch.rand(B, 36, 1, generator=gen), 1.9 + torch.zeros(B, 36, 1),
+                         (torch.rand(B, 36, 1, generator=gen) - 0.5) * 6], -1).to(DEV)
+        allb, allp = torch.cat([boxes, npc], 1), torch.cat([present, torch.ones(B, 36, dtype=torch.bool, device=DEV)], 1)
+
+        def grad_npc():
+            t = allb.clone().requires_grad_(True)
+            out = _ops.collision(t, allp, n_exposed=A, metric=metric)
+            (out * wgt).sum().backward()
+            return t.grad
+
+        g0 = grad_npc()
+        assert g0[:, A:].abs().max().item() > 0                      # the NPC boxes get gradients too
+        for _ in range(5):
+            assert torch.equal(grad_npc(), g0)
         if spread < 10:
-            # the same scene as rows of a scene too large for the whole-scene kernel (65 x 64 > 4096 pairs: one extra box, absent and far away)
-            far = torch.tensor([1.0e4, 1.0e4, 4.0, 2.0, 0.0], device=DEV).expand(B, 1, 5)
+            # the same scene as rows of a scene too large for the whole-scene kernel (129 x 129 > 16 384 pairs: 65 extra boxes, absent and far away)
+            far = torch.tensor([1.0e4, 1.0e4, 4.0, 2.0, 0.0], device=DEV).expand(B, 65, 5)
             big = torch.cat([boxes, far], 1).clone().requires_grad_(True)
-            o2 = _ops.collision(big, torch.cat([present, torch.zeros(B, 1, dtype=torch.bool, device=DEV)], 1), metric=metric)
+            o2 = _ops.collision(big, torch.cat([present, torch.zeros(B, 65, dtype=torch.bool, device=DEV)], 1), metric=metric)
             (o2[:, :A] * wgt).sum().backward()
             torch.testing.assert_close(big.grad[:, :A], first, rtol=2e-4, atol=2e-5 * first.abs().max().item())

@@ -13,6 +13,7 @@ using tds::MapView;
 namespace {
 
 constexpr int GBLOCK = 256;
+constexpr int SCENE_BWD_MAX_PAIRS = 16384;          // pairs (exposed agents x boxes) of a scene that collision_scene_bwd_kernel takes: list entries are uint16
 
 struct Box { float x, y, l, w, s, c; };
 struct BoxGrad { float x, y, l, w, s, c; };
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(GBLOCK, 2) collision_scene_bwd_kernel(const fl
     float *go = acc + N * 6;                                // A
     int *arg = (int *)(go + A);                             // A
     float *O = (float *)(arg + A);                          // A x N
-    uint16_t *list = (uint16_t *)(O + A * N);               // A x N at most (A x N <= 4096)
+    uint16_t *list = (uint16_t *)(O + A * N);               // A x N at most (A x N <= SCENE_BWD_MAX_PAIRS)
     uint16_t *slot = list + A * N;                          // A x N: pair -> place in the list (0xffff: not listed)
     float *pg = (float *)(slot + A * N);                    // cap x 12: the box gradients of the listed pairs of the current chunk (list + slot: 4 A N bytes)
     for (int j = tid; j < N; j += GBLOCK) {
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(GBLOCK, 2) collision_scene_bwd_kernel(const fl
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
             auto take = [&](int p, int off) {
                 const int q = (int)slot[p] - q0;
-                if ((unsigned)q < (unsigned)nq) {               // listed (0xffff is beyond every chunk: total <= 4096) and in this chunk
+                if ((unsigned)q < (unsigned)nq) {               // listed (0xffff is beyond every chunk: total <= 16 384) and in this chunk
                     const float *t = pg + 12 * q + off;
                     s0 += t[0]; s1 += t[1]; s2 += t[2]; s3 += t[3]; s4 += t[4]; s5 += t[5];
                 }
@@ -703,9 +704,13 @@ TDS_EXPORT int tds_collision_bwd_f32(const float *boxes, const float *sc, const 
     TDS_CHECK_ARG(boxes && sc && present && grad_out, "tds_collision_bwd_f32: null pointer");
     // whole scene per workgroup where its tables fit (see collision_scene_bwd_kernel); one wavefront per (scene, agent) otherwise
     const size_t lds_base = ((size_t)N * 12 + 2 * (size_t)A + (size_t)A * N) * sizeof(float) + 2 * (size_t)A * N * sizeof(uint16_t);
-    if (A * N <= 4096 && lds_base <= 96 * 1024) {
-        // the gradient table: as many pairs as fit beside the rest in 144 KiB (a workgroup per scene at 206 VGPRs: two per CU either way), 256 .. 1024
-        int64_t cap = ((int64_t)(144 * 1024) - (int64_t)lds_base) / 48;
+    // (up to 16 384 pairs -- 64 exposed agents among 256 boxes, 128 among 128 -- since the kernel is the deterministic one: exposed agents plus NPCs
+    // easily exceed the forward kernel's 4 096; beyond, or where the tables do not fit, one wavefront per row with global atomics)
+    if (A * N <= SCENE_BWD_MAX_PAIRS && lds_base + 256 * 48 <= 150 * 1024) {
+        // the gradient table: 256 .. 1024 pairs, as many as keep the workgroup within 80 KiB of LDS (two workgroups per CU, which is also what its
+        // registers allow) where the scene's own tables leave room for that, else within 150 KiB (one per CU)
+        const int64_t budget = lds_base + 256 * 48 <= 80 * 1024 ? 80 * 1024 : 150 * 1024;
+        int64_t cap = (budget - (int64_t)lds_base) / 48;
         cap = std::max<int64_t>(256, std::min<int64_t>(1024, cap & ~(int64_t)255));
         const size_t lds_scene = lds_base + (size_t)cap * 48;
         auto launch = [&](auto kern) {
