@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run of the K3 scene rasteriser in the modes tests/fuzz_raster.py does not reach (a script, not collected by pytest):
-three agent types (seven distinct keys: at 256 x 256 the bit-plane kernel then renders two half-image strips), with and without the trim
+three agent types (seven distinct keys: at 256 x 256 the bit-plane kernel then renders the whole image in two 8-wave workgroups per CU -- round 6;
+two half-image strips before --, differentiable calls in 4-wave ones), with and without the trim
 rule (CV2RendererConfig.trim_mesh_before_rendering), and the key-index slices of differentiable calls decoded back into the image.
    python tests/fuzz_raster_modes.py [--seeds 6] [--batch 4] [--agents 24]"""
 import argparse, os, sys, time
@@ -56,6 +57,11 @@ for seed in range(a.seeds):
                 oracle.set_trim_mesh(True)
             out = img.cpu().numpy()
             bad = int((out != ref).sum())
+            # the same scene without index slices, float32 and uint8: at 256 x 256 seven keys take the whole image in 8-WAVE workgroups (round 6),
+            # the differentiable call above in 4-wave ones
+            for dt in (torch.float32, torch.uint8):
+                plain = ops.raster_scene(smap, sd, agent_sc, tmpl, keys, dev(mask), dev(state[..., :2].copy()), agent_sc, fov, res, dt, trim=trim)
+                bad += int((plain.cpu().numpy().astype(np.float32) != ref).sum())
             # the slices decode to the same image
             dec_bad = -1
             if slices is not None:

@@ -639,6 +639,50 @@ def test_k3_per_camera_triangles_in_every_form(ops, oracle, town, testing_lib):
         ops._workspaces.clear()
 
 
+def test_k3_six_and_seven_keys_at_256_in_every_workgroup_shape(ops, oracle, town, testing_lib):
+    """Two or three agent types (six / seven distinct keys): at 256 x 256 the bit planes no longer fit three workgroups per CU.  Round 6 renders the
+    whole image in 8-wave workgroups, two per CU (raster.hip: raster_scene_impl; profiles/r06_more_keys.log); the alternatives stay reachable in
+    the testing build -- the whole image in 4-wave workgroups (debug flag 262144), two half-image strips (524288).  Same pixels as the oracle in
+    all three, float32 and uint8."""
+    types = dict(vehicle=(4, (32, 74, 135)), bicycle=(5, (255, 150, 40)), pedestrian=(6, (255, 64, 180)))
+    levels = sorted(set(LEVEL_TABLE) | {float(z) for z, _ in types.values()}, reverse=True)
+    cats = town['categories']
+    cat = np.asarray(town['vert_category'])[town['faces'][:, 0]]
+    smap = ops.StaticMap(town['verts'], town['faces'], np.array([LEVELS[cats[c]] for c in cat], np.float32),
+                         np.array([pack(COLORS[cats[c]]) for c in cat], np.uint32), levels, device=DEV)
+    static = oracle.static_mesh_arrays(town['verts'], town['faces'], town['vert_category'], cats, colors={**oracle.DEFAULT_COLORS, **COLORS},
+                                       levels={**oracle.DEFAULT_LEVELS, **LEVELS})
+    road = town['verts'][np.asarray(town['vert_category']) == cats.index('road')]
+    gen = np.random.default_rng(9)
+    B, A, res, fov = 2, 14, 256, 35.0
+    try:
+        for names in (['vehicle', 'pedestrian'], ['vehicle', 'bicycle', 'pedestrian']):
+            anchor = road[gen.integers(0, len(road), (B, 1))]
+            state = np.concatenate([anchor + gen.uniform(-20, 20, (B, A, 2)), gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
+            size = np.concatenate([gen.uniform(1.0, 8, (B, A, 1)), gen.uniform(0.6, 2.8, (B, A, 1))], -1).astype(np.float32)
+            kind = gen.integers(0, len(names), (B, A))
+            kind[:, :len(names)] = np.arange(len(names))                  # every type occurs
+            mask = np.ascontiguousarray((gen.uniform(size=(B, 1, A)) < 0.9) & (gen.uniform(size=(B, A, A)) < 0.95))
+            body = np.array([(smap.rank_of(types[n][0]) << 24) | pack(types[n][1]) for n in names], np.int64)
+            dkey = (smap.rank_of(LEVELS['direction']) << 24) | pack(COLORS['direction'])
+            keys = torch.from_numpy(np.stack([body[kind], np.full_like(kind, dkey)], -1)).to(torch.int32).to(DEV)
+            lev = np.stack([np.array([types[n][0] for n in names], np.float32)[kind], np.full(kind.shape, LEVELS['direction'], np.float32)], -1)
+            col = np.stack([np.array([types[n][1] for n in names], np.float32)[kind], np.broadcast_to(np.array(COLORS['direction'], np.float32), kind.shape + (3,))], -2) / np.float32(255.0)
+            sd = dev(state)
+            agent_sc = ops.heading_sc(sd[..., 2])
+            ref = oracle.render_scenes(state, size, mask, state[..., :2].copy(), sc_np(agent_sc), *static, fov, res, agent_sc=sc_np(agent_sc),
+                                       actor_levels=lev, actor_colors=col.astype(np.float32))
+            assert ref.any()
+            for flags in (0, 262144, 524288):
+                testing_lib.tds_raster_set_debug(flags)
+                for dtype in (torch.float32, torch.uint8):
+                    img = ops.raster_scene(smap, sd, agent_sc, dev(oracle.actor_template(size)), keys, dev(mask), dev(state[..., :2].copy()), agent_sc, fov, res, dtype)
+                    bad = img.cpu().numpy().astype(np.float32) != ref
+                    assert not bad.any(), f'{len(names)} agent types, debug {flags}, {dtype}: {bad.sum()} values differ'
+    finally:
+        testing_lib.tds_raster_set_debug(0)
+
+
 def test_k3_u8_mode_equals_f32(ops, oracle, town):
     g = load_golden('g45_mesh_preraster.npz')
     st, sz, pr = g['g5_town01_128_state'], g['g5_town01_128_size'], g['g5_town01_128_present']

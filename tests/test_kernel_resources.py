@@ -39,6 +39,9 @@ def test_headline_rasteriser_keeps_three_waves_per_simd(table):
     assert head['waves_per_simd'] >= 3 and head['private_segment_fixed_size'] <= 80 and head['vgpr_count'] <= 168, head
     for name, e in matching(table, r'raster_scene_bits_kernel<4, \d, (float|unsigned char), SceneArgs(Ex)?, (false|true), 3>').items():
         assert e['waves_per_simd'] >= 3 and e['private_segment_fixed_size'] <= 80, (name, e)
+    # the 8-wave instantiations (six or seven keys at 256 x 256: two workgroups of eight waves per CU = four waves per SIMD)
+    for name, e in matching(table, r'raster_scene_bits_kernel<8, \d, (float|unsigned char), SceneArgsEx, false, 3>').items():
+        assert e['waves_per_simd'] >= 4 and e['private_segment_fixed_size'] <= 176, (name, e)
     # the instantiations for four workgroups per CU (LDS allows it): 128 VGPRs
     for name, e in matching(table, r'raster_scene_bits_kernel<4, \d, (float|unsigned char), SceneArgs(Ex)?, false, 4>').items():
         assert e['waves_per_simd'] >= 4 and e['private_segment_fixed_size'] <= 192, (name, e)

@@ -2321,7 +2321,7 @@ template <int BWAVES, int NB, typename OutT, typename SA, bool EMIT = false, int
 __global__ void __launch_bounds__(BWAVES * 64, BWAVES == 4 ? MINWG : 4) raster_scene_bits_kernel(SA a, CommonArgs c, KeyTable kt, int TWp, uint32_t *queue, const uint32_t *only) {
     using E = typename PairTab<NB, OutT>::E;
     constexpr int BBLOCK = BWAVES * 64, P = 1 << (2 * NB);
-    constexpr bool PERSIST = BWAVES == 4 && MINWG == 3;
+    constexpr bool PERSIST = BWAVES == 4 && MINWG == 3;              // (the 8-wave instantiation as a persistent launch: 224 instead of 160 B of scratch, 6 % slower)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int res = c.res, H = res, W = res, wpr = TWp >> 5, K = kt.n;
@@ -3002,13 +3002,21 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
             // strip width: the whole (32-padded) image if the planes fit 64 KiB, else the widest multiple of 32 that does
             int twp = (res + 31) & ~31;
             while (twp > 32 && (size_t)kt.n * res * (twp / 8) > 64 * 1024) twp -= 32;
-            const int nwv = g_bits_waves;
+            int nwv = g_bits_waves;
             // Three workgroups per CU need at most 52 KiB each (160 KiB of LDS, allocated in 2 KiB steps): five keys at 256 x 256 just fit.
-            // A whole image that fits 64 KiB but not 52 runs at two workgroups per CU; two half-image strips at three are a little faster
-            // although each strip scans the grid for itself (six keys at 256 x 256: 10.7 -> 10.1 ms).
-            if (twp == ((res + 31) & ~31) && twp >= 128 && bits_lds_bytes(kt.n, res, twp, nwv, out_mode) > 52 * 1024) {
+            // A whole image that does not (six keys and more: two agent types, traffic lights, waypoints) -- measured at B = 1024 x 64, 256 x 256,
+            // six / seven keys, float32 | uint8 ms (profiles/r06_more_keys.log):
+            //     two half-image strips, four 128-VGPR workgroups per CU (each strip scans the grid for itself)   7.79 / 7.86 | 6.88 / 6.98
+            //     the whole image, two 4-wave workgroups per CU (persistent)                                       7.62 / 7.71 | 6.90 / 6.99
+            //     the whole image, two 8-WAVE workgroups per CU (sixteen waves per CU instead of eight)            7.61 / 7.63 | 6.25 / 6.32
+            // so: eight waves on the whole image where two such workgroups fit a CU (80 KiB each: up to seven keys at 256 x 256), else four waves
+            // on the whole image where two of those fit (eight keys; and differentiable calls, whose index slices the 4-wave kernel writes), else
+            // half strips.
+            if (twp == ((res + 31) & ~31) && twp >= 128 && bits_lds_bytes(kt.n, res, twp, nwv, out_mode) > 52 * 1024 && !(TDS_DBG(g_debug) & 262144)) {      // (262144: testing, the whole image in 4-wave workgroups)
                 const int half = ((twp / 2) + 31) & ~31;
-                if (bits_lds_bytes(kt.n, res, half, nwv, out_mode) <= 52 * 1024) twp = half;
+                if (nwv == 4 && !want_slices && bits_lds_bytes(kt.n, res, twp, 8, out_mode) <= 80 * 1024 && !(TDS_DBG(g_debug) & 524288)) nwv = 8;          // (524288: testing, never eight waves)
+                else if (bits_lds_bytes(kt.n, res, twp, nwv, out_mode) <= 80 * 1024 && !(TDS_DBG(g_debug) & 524288)) { /* the whole image, 4 waves */ }
+                else if (bits_lds_bytes(kt.n, res, half, nwv, out_mode) <= 52 * 1024) twp = half;
             }
             if (g_force_tw >= 32 && g_force_tw < twp) twp = g_force_tw;     // tuning hook
             size_t lds = bits_lds_bytes(kt.n, res, twp, nwv, out_mode);
