@@ -403,7 +403,8 @@ int tds_raster_set_list_waves(int waves);
  * 64 no bit planes, 128 work counters on, 512 no per-face set-up (nothing is painted), 1024 walk the grid but project nothing,
  * 2048 the 170-VGPR instantiation everywhere, 4096 the work counters hold per-XCD finish [0..7] and ~start [8..15] wall clocks (100 MHz),
  * 8192 never the split form (K3s + K3r), 16384 the split form wherever a workspace allows it, 262144 / 524288 an image whose planes do not fit three
- * workgroups per CU (six and more keys at 256 x 256) whole in 4-wave workgroups / in half-image strips instead of whole in 8-wave ones, 32768 K3r without its short path for
+ * workgroups per CU (six and more keys at 256 x 256) whole in 4-wave workgroups / in half-image strips instead of whole in 8-wave ones, 1048576 / 2097152
+ * strips as wide as the LDS allows instead of equal ones / never one strip more than necessary (nine and more keys), 32768 K3r without its short path for
  * small faces, 65536 / 131072 the persistent launch with 8 / 4 workgroups per CU (round 3's surplus) instead of the resident number */
 int tds_raster_set_debug(int flags);
 /* read and reset the 16 work counters of the bit-plane kernel */

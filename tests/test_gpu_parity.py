@@ -639,12 +639,13 @@ def test_k3_per_camera_triangles_in_every_form(ops, oracle, town, testing_lib):
         ops._workspaces.clear()
 
 
-def test_k3_six_and_seven_keys_at_256_in_every_workgroup_shape(ops, oracle, town, testing_lib):
+def test_k3_six_to_ten_keys_at_256_in_every_workgroup_shape(ops, oracle, town, testing_lib):
     """Two or three agent types (six / seven distinct keys): at 256 x 256 the bit planes no longer fit three workgroups per CU.  Round 6 renders the
     whole image in 8-wave workgroups, two per CU (raster.hip: raster_scene_impl; profiles/r06_more_keys.log); the alternatives stay reachable in
     the testing build -- the whole image in 4-wave workgroups (debug flag 262144), two half-image strips (524288).  Same pixels as the oracle in
     all three, float32 and uint8."""
-    types = dict(vehicle=(4, (32, 74, 135)), bicycle=(5, (255, 150, 40)), pedestrian=(6, (255, 64, 180)))
+    types = dict(vehicle=(4, (32, 74, 135)), bicycle=(5, (255, 150, 40)), pedestrian=(6, (255, 64, 180)), ego=(3, (255, 0, 0)), ground_truth=(9, (196, 188, 165)),
+                 prediction=(10, (255, 155, 0)))
     levels = sorted(set(LEVEL_TABLE) | {float(z) for z, _ in types.values()}, reverse=True)
     cats = town['categories']
     cat = np.asarray(town['vert_category'])[town['faces'][:, 0]]
@@ -656,7 +657,10 @@ def test_k3_six_and_seven_keys_at_256_in_every_workgroup_shape(ops, oracle, town
     gen = np.random.default_rng(9)
     B, A, res, fov = 2, 14, 256, 35.0
     try:
-        for names in (['vehicle', 'pedestrian'], ['vehicle', 'bicycle', 'pedestrian']):
+        # ... and nine / ten keys (five / six agent types): their planes exceed 64 KiB for a whole image -- strips of equal width (round 6; testing flag
+        # 1048576: the widest that fit, 192 + 64 columns), for ten keys one strip more than necessary (2097152: not)
+        for names in (['vehicle', 'pedestrian'], ['vehicle', 'bicycle', 'pedestrian'], ['vehicle', 'bicycle', 'pedestrian', 'ego', 'ground_truth'],
+                      ['vehicle', 'bicycle', 'pedestrian', 'ego', 'ground_truth', 'prediction']):
             anchor = road[gen.integers(0, len(road), (B, 1))]
             state = np.concatenate([anchor + gen.uniform(-20, 20, (B, A, 2)), gen.uniform(-np.pi, np.pi, (B, A, 1)), np.zeros((B, A, 1))], -1).astype(np.float32)
             size = np.concatenate([gen.uniform(1.0, 8, (B, A, 1)), gen.uniform(0.6, 2.8, (B, A, 1))], -1).astype(np.float32)
@@ -673,7 +677,7 @@ def test_k3_six_and_seven_keys_at_256_in_every_workgroup_shape(ops, oracle, town
             ref = oracle.render_scenes(state, size, mask, state[..., :2].copy(), sc_np(agent_sc), *static, fov, res, agent_sc=sc_np(agent_sc),
                                        actor_levels=lev, actor_colors=col.astype(np.float32))
             assert ref.any()
-            for flags in (0, 262144, 524288):
+            for flags in ((0, 262144, 524288) if len(names) <= 3 else (0, 1048576, 2097152)):
                 testing_lib.tds_raster_set_debug(flags)
                 for dtype in (torch.float32, torch.uint8):
                     img = ops.raster_scene(smap, sd, agent_sc, dev(oracle.actor_template(size)), keys, dev(mask), dev(state[..., :2].copy()), agent_sc, fov, res, dtype)

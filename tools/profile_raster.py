@@ -25,7 +25,7 @@ def main():
     ap.add_argument('--res', type=int, default=0, help='resolution (default: the bench resolution)')
     ap.add_argument('--cell', type=float, default=0.0, help='grid cell size of the rendering map in metres (0: the library default)')
     ap.add_argument('--six-keys', action='store_true', help='two agent types: one more distinct key than the bench scene (6 bit planes)')
-    ap.add_argument('--agent-types', type=int, default=1, help='1 .. 3 agent types (vehicle, pedestrian, bicycle): 5 .. 7 distinct keys')
+    ap.add_argument('--agent-types', type=int, default=1, help='1 .. 6 agent types (vehicle, pedestrian, bicycle, ego, ground_truth, prediction): 5 .. 10 distinct keys')
     ap.add_argument('--bits-waves', type=int, nargs='*', default=[4])
     ap.add_argument('--list-waves', type=int, nargs='*', default=[], help='testing build: waves per workgroup of the list rasteriser to sweep (1, 2, 4; 0 = automatic)')
     ap.add_argument('--lib', default='', help='another build of libtdship_testing.so (path) to load instead')
@@ -60,11 +60,13 @@ def main():
     if args.six_keys:
         args.agent_types = 2
     if args.agent_types > 1:
-        sim._agent_types = ['vehicle', 'pedestrian', 'bicycle'][:args.agent_types]
+        sim._agent_types = ['vehicle', 'pedestrian', 'bicycle', 'ego', 'ground_truth', 'prediction'][:args.agent_types]
         sim.agent_type = sim.agent_type.clone()
         sim.agent_type[:, ::2] = 1
         if args.agent_types > 2:
             sim.agent_type[:, 1::4] = 2
+        for extra in range(3, args.agent_types):
+            sim.agent_type[:, extra::8] = extra
         sim._scene_cache = None
     if args.u8:
         sim.renderer.cfg.out_dtype = 'uint8'

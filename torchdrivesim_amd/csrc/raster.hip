@@ -3002,6 +3002,17 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
             // strip width: the whole (32-padded) image if the planes fit 64 KiB, else the widest multiple of 32 that does
             int twp = (res + 31) & ~31;
             while (twp > 32 && (size_t)kt.n * res * (twp / 8) > 64 * 1024) twp -= 32;
+            // ... in strips of EQUAL width (nine keys at 256 x 256: 192 + 64 columns left the second strip's workgroups a third of the work and the first
+            // one's two per CU -- 10.4 ms; 128 + 128 at three per CU: profiles/r06_more_keys.log)
+            // and, where one more strip lets three workgroups share a CU instead of two, in one more (ten keys: 3 x 96 columns).
+            if (twp < ((res + 31) & ~31) && !(TDS_DBG(g_debug) & 1048576)) {      // (1048576: testing, the widest strips that fit)
+                int n_strips = (res + twp - 1) / twp;
+                auto equal_width = [&](int n) { return (((res + n - 1) / n) + 31) & ~31; };
+                twp = equal_width(n_strips);
+                if (bits_lds_bytes(kt.n, res, twp, g_bits_waves, out_mode) > 52 * 1024 && equal_width(n_strips + 1) >= 64 &&
+                    bits_lds_bytes(kt.n, res, equal_width(n_strips + 1), g_bits_waves, out_mode) <= 52 * 1024 && !(TDS_DBG(g_debug) & 2097152))      // (2097152: testing, not one more)
+                    twp = equal_width(n_strips + 1);
+            }
             int nwv = g_bits_waves;
             // Three workgroups per CU need at most 52 KiB each (160 KiB of LDS, allocated in 2 KiB steps): five keys at 256 x 256 just fit.
             // A whole image that does not (six keys and more: two agent types, traffic lights, waypoints) -- measured at B = 1024 x 64, 256 x 256,
@@ -3009,13 +3020,12 @@ int raster_scene_impl(const MapSource &ms, const float *state, const float *agen
             //     two half-image strips, four 128-VGPR workgroups per CU (each strip scans the grid for itself)   7.79 / 7.86 | 6.88 / 6.98
             //     the whole image, two 4-wave workgroups per CU (persistent)                                       7.62 / 7.71 | 6.90 / 6.99
             //     the whole image, two 8-WAVE workgroups per CU (sixteen waves per CU instead of eight)            7.61 / 7.63 | 6.25 / 6.32
-            // so: eight waves on the whole image where two such workgroups fit a CU (80 KiB each: up to seven keys at 256 x 256), else four waves
-            // on the whole image where two of those fit (eight keys; and differentiable calls, whose index slices the 4-wave kernel writes), else
-            // half strips.
-            if (twp == ((res + 31) & ~31) && twp >= 128 && bits_lds_bytes(kt.n, res, twp, nwv, out_mode) > 52 * 1024 && !(TDS_DBG(g_debug) & 262144)) {      // (262144: testing, the whole image in 4-wave workgroups)
+            // so: eight waves on the whole image where two such workgroups fit a CU (80 KiB each: up to seven keys at 256 x 256), else half strips
+            // (eight keys: 7.72 against 7.75 for the whole image in 4-wave workgroups; five keys at 320 x 320: 2.76 against 2.84; and differentiable
+            // calls, whose index slices the 4-wave kernel writes).
+            if (twp == ((res + 31) & ~31) && twp >= 128 && bits_lds_bytes(kt.n, res, twp, nwv, out_mode) > 52 * 1024 && !(TDS_DBG(g_debug) & 262144)) {      // (262144: testing, the whole image in 4-wave workgroups, two per CU)
                 const int half = ((twp / 2) + 31) & ~31;
                 if (nwv == 4 && !want_slices && bits_lds_bytes(kt.n, res, twp, 8, out_mode) <= 80 * 1024 && !(TDS_DBG(g_debug) & 524288)) nwv = 8;          // (524288: testing, never eight waves)
-                else if (bits_lds_bytes(kt.n, res, twp, nwv, out_mode) <= 80 * 1024 && !(TDS_DBG(g_debug) & 524288)) { /* the whole image, 4 waves */ }
                 else if (bits_lds_bytes(kt.n, res, half, nwv, out_mode) <= 52 * 1024) twp = half;
             }
             if (g_force_tw >= 32 && g_force_tw < twp) twp = g_force_tw;     // tuning hook
