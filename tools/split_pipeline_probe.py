@@ -16,6 +16,10 @@ from torchdrivesim_amd.utils import Resolution                      # noqa: E402
 
 
 def main():
+    import ctypes
+    if not hasattr(ctypes.CDLL(nat.TESTING_LIB_PATH), 'tds_raster_set_split_chunks'):
+        raise SystemExit('this probe drove an experiment of round 6 through a testing hook (tds_raster_set_split_chunks) that was removed with the experiment: '
+                         'it is kept as the record of what was measured (profiles/r06_split_pipeline_attempt.log), not as a runnable tool')
     dev = torch.device('cuda', 0)
     B = int(os.environ.get('B', 1024))
     with nat.testing() as L:

@@ -19,6 +19,10 @@ def pack(head, tail, lg):
 
 
 def main():
+    import ctypes
+    if not hasattr(ctypes.CDLL(nat.TESTING_LIB_PATH), 'tds_raster_set_tail_split'):
+        raise SystemExit('this probe drove an experiment of round 6 through a testing hook (tds_raster_set_tail_split) that was removed with the experiment: '
+                         'it is kept as the record of what was measured (profiles/r06_tail_attempts.log), not as a runnable tool')
     dev = torch.device('cuda', 0)
     res = Resolution(bench.RES, bench.RES)
     with nat.testing() as L:
