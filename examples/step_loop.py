@@ -43,9 +43,13 @@ def main():
     res = Resolution(args.res, args.res)
     g = torch.Generator(device=dev).manual_seed(0)
     totals = {k: torch.zeros((), device=dev) for k in ('collision', 'offroad', 'wrong_way', 'red_light')}     # summed on the device: no sync per step
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    warmup = 3                                   # the first steps build the device maps, lane tables and workspaces (once per simulator): not timed
+    for it in range(warmup + args.steps):
+        if it == warmup:
+            for v in totals.values():
+                v.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         action = torch.rand((args.batch, args.agents, 2), device=dev, generator=g) * 2 - 1
         programme.tick(0.1)
         controls['traffic_light'].set_state(current_light_state_tensor_from_controller(programme, light_ids).unsqueeze(0).expand(args.batch, -1).to(dev))
